@@ -1,0 +1,160 @@
+/*
+ * fmhip.h — C ABI of the MI355X-native FM trainer (libfmhip.so).
+ *
+ * This is the drop-in boundary for SparkFM's learner plug-in point
+ *     abstract class FMLearn { def learn(fm: FMModel, dataset: DataSet): FMModel }
+ *     (S/fm/FMLearn.scala:10-12, invoked at S/fm/impl/FactorizationMachines.scala:45)
+ * and for the scoring calls under it (FMModel.predict S/fm/FMModel.scala:34-63,
+ * Model.computeRMSE S/Model.scala:13-19).  A JVM-side `HipSGD extends FMLearn`
+ * binds exactly these symbols through JNI; the Python façade in
+ * sparkfm_amd/ binds them through ctypes.
+ *
+ * S/ = src/main/scala/io/edstud/spark/ of edmundhung/SparkFM.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes, no C++/torch types; every call returns an int status
+ *    (0 = FMHIP_OK, negative = error class) and never throws or aborts;
+ *    fmhip_last_error() returns the calling thread's last message.
+ *  - host parameter layout is the reference's: w has n+1 slots (n = num_attribute =
+ *    largest feature index, S/fm/FMModel.scala:18); v is breeze's column-major
+ *    DenseMatrix(k, n+1) (S/fm/FMModel.scala:19): element (f, i) at v[f + i*k].
+ *  - host rows are CSR: row_ptr[n_rows+1] (int64), col[nnz] (int32, the breeze
+ *    SparseVector `index` array, stored order, need not be sorted), val[nnz], y[n_rows]
+ *    — the RDD[(Double, SparseVector[Double])] of S/DataSet.scala:42, flattened.
+ *  - device arithmetic is fp32, indices int32; host I/O is fp64 (as the reference) or
+ *    fp32 (the *_f32 entry points).
+ *  - one model/dataset lives on ONE GPU.  Data-parallel training runs one process per
+ *    GPU; the packed gradient is exposed (fmhip_grad_*) so the host all-reduces it
+ *    (RCCL) between fmhip_step_compute and fmhip_step_apply.
+ *  - a handle must not be used from two threads at once.
+ */
+#ifndef FMHIP_H
+#define FMHIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMHIP_VERSION 100 /* 0.1.0 */
+
+enum {
+    FMHIP_OK = 0,
+    FMHIP_ERR_INVALID = -1,      /* bad argument (NULL, negative size, unsorted row_ptr, index < 0 ...) */
+    FMHIP_ERR_HIP = -2,          /* a HIP runtime call failed; message has hipGetErrorString */
+    FMHIP_ERR_NOMEM = -3,        /* host or device allocation failed */
+    FMHIP_ERR_SHAPE = -4,        /* dataset has a feature index > model.num_attribute */
+    FMHIP_ERR_UNSUPPORTED = -5   /* num_factor > FMHIP_MAX_FACTORS, batch too large ... */
+};
+
+#define FMHIP_MAX_FACTORS 256
+/* CSC work split: every column of a batch is processed in pieces of this many entries */
+#define FMHIP_RANGE_LEN 64
+
+typedef struct fmhip_model *fmhip_model_t;
+typedef struct fmhip_dataset *fmhip_dataset_t;
+
+typedef struct fmhip_stats {
+    double sse;        /* sum over processed rows of e^2, e = yhat - y (S/fm/lib/ALS.scala:143) */
+    double sum_e;      /* sum of e */
+    int64_t rows;      /* rows processed */
+    int64_t nnz;       /* stored nonzeros processed */
+    int64_t nonfinite; /* rows whose prediction was NaN/Inf (never masked; cf. S/fm/lib/ALS.scala:190-192) */
+    int64_t steps;     /* mini-batch steps taken */
+} fmhip_stats;
+
+/* per-kernel device time, HIP events on the model's stream (fmhip_profile_*) */
+enum { FMHIP_K_FORWARD = 0, FMHIP_K_REDUCE = 1, FMHIP_K_BACKWARD = 2, FMHIP_K_FIXUP = 3, FMHIP_K_APPLY = 4, FMHIP_K_COUNT = 5 };
+typedef struct fmhip_profile {
+    double ms[FMHIP_K_COUNT];        /* summed elapsed per kernel kind */
+    int64_t launches[FMHIP_K_COUNT];
+    int64_t nnz[FMHIP_K_COUNT];      /* stored nonzeros those launches covered */
+    int64_t rows[FMHIP_K_COUNT];
+} fmhip_profile;
+
+/* ---- library ----------------------------------------------------------------- */
+int fmhip_version(void);
+const char *fmhip_last_error(void);
+int fmhip_device_count(int *count);
+
+/* ---- model: `new FMModel(num_attribute, num_factor)`  S/fm/FMModel.scala:9-22 -- */
+/* Parameters start at zero; the reference's unseeded N(0, 0.01) init (quirk Q2) is the
+ * caller's job: draw on the host, then fmhip_model_set_params.  `stream` is a
+ * hipStream_t (NULL = the library creates its own non-blocking stream). */
+int fmhip_model_create(int device, int64_t num_attribute, int32_t num_factor, void *stream, fmhip_model_t *out);
+int fmhip_model_destroy(fmhip_model_t m);
+int fmhip_model_info(fmhip_model_t m, int64_t *num_attribute, int32_t *num_factor, int32_t *padded_factors);
+/* w: n+1 doubles, v: k*(n+1) doubles at v[f + i*k]  (FMModel.w0 / .w / .v, S/fm/FMModel.scala:17-19) */
+int fmhip_model_set_params(fmhip_model_t m, double w0, const double *w, const double *v);
+int fmhip_model_get_params(fmhip_model_t m, double *w0, double *w, double *v);
+int fmhip_model_set_params_f32(fmhip_model_t m, float w0, const float *w, const float *v);
+int fmhip_model_get_params_f32(fmhip_model_t m, float *w0, float *w, float *v);
+int fmhip_synchronize(fmhip_model_t m);
+
+/* ---- dataset: DataSet(rdd).cache() + transposeInput  S/DataSet.scala:42-62,31-38 */
+/* Copies the rows to the GPU, cuts them into mini-batches of `batch_rows` consecutive
+ * rows (<= 0: one batch) and builds each batch's row->column transpose (the CSC the
+ * atomics-free backward walks).  Caller keeps ownership of the host arrays. */
+int fmhip_dataset_create(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col,
+                         const double *val, const double *y, int64_t batch_rows, fmhip_dataset_t *out);
+int fmhip_dataset_create_f32(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col,
+                             const float *val, const float *y, int64_t batch_rows, fmhip_dataset_t *out);
+int fmhip_dataset_destroy(fmhip_dataset_t d);
+/* size = rdd.count (S/DataSet.scala:23-25); dimension = max feature index (:27-29) */
+int fmhip_dataset_info(fmhip_dataset_t d, int64_t *n_rows, int64_t *nnz, int64_t *dimension,
+                       int64_t *batch_rows, int64_t *n_batches);
+int fmhip_dataset_batch_info(fmhip_dataset_t d, int64_t batch, int64_t *row0, int64_t *rows, int64_t *nnz,
+                             int64_t *n_columns);
+/* Reads one batch's device-resident transpose back (parity of the index gathers):
+ * feat[n_columns] ascending feature ids present in the batch, ptr[n_columns+1] offsets,
+ * rows[nnz] batch-local row index (ascending inside a column), vals[nnz]. */
+int fmhip_dataset_get_transpose(fmhip_dataset_t d, int64_t batch, int32_t *feat, int32_t *ptr, int32_t *rows,
+                                float *vals);
+
+/* ---- scoring ------------------------------------------------------------------ */
+/* FMModel.predict mapped over the rows (S/fm/FMModel.scala:34-63; dataset.rdd.mapValues(predict)) */
+int fmhip_predict(fmhip_model_t m, fmhip_dataset_t d, double *yhat /* n_rows */);
+/* Model.computeRMSE (S/Model.scala:13-19) */
+int fmhip_rmse(fmhip_model_t m, fmhip_dataset_t d, double *rmse, fmhip_stats *stats /* nullable */);
+/* ALS.precomputeTermE (S/fm/lib/ALS.scala:142-144): e_r = yhat_r - y_r */
+int fmhip_residual(fmhip_model_t m, fmhip_dataset_t d, double *e /* n_rows */);
+/* ALS.precomputeTermQ for every factor (S/fm/lib/ALS.scala:146-150): q[r*k + f] */
+int fmhip_term_q(fmhip_model_t m, fmhip_dataset_t d, double *q /* n_rows*k */);
+
+/* ---- training (build-defined mini-batch SGD; SparkFM itself only ships ALS) ---- */
+/*   g_theta = sum_{r in batch} e_r * h_r(theta),  h from S/fm/lib/ALS.scala:56-58 (V), :40 (w), :21 (w0)
+ *   theta  <- theta - eta * (g_theta / |batch| + reg_theta * theta)                                  */
+int fmhip_sgd_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double eta, double reg0, double regw,
+                   double regv, fmhip_stats *stats /* nullable: skips the host sync */);
+/* one pass over all batches; order[n_batches] = batch visiting order (NULL = ascending) */
+int fmhip_sgd_epoch(fmhip_model_t m, fmhip_dataset_t d, double eta, double reg0, double regw, double regv,
+                    const int64_t *order, fmhip_stats *stats /* nullable */);
+/* Gradient of one batch at the current parameters, host layout as the parameters
+ * (gv[f + i*k], gw[i]); does not update anything. */
+int fmhip_batch_grad(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double *gv, double *gw, double *gw0,
+                     fmhip_stats *stats);
+
+/* ---- data-parallel split step ---------------------------------------------------
+ * packed fp32 gradient: [ G_V (n1p*Kp) | G_w (n1p) | G_b (n1p) | scalars (8) ], n1p = n+1
+ * rounded up to 4, Kp = padded factors.  G_V holds sum e*x*q; G_b holds sum e*x^2 (the
+ * -x^2*v term of h is applied in fmhip_step_apply, so the packed buffer is a plain sum
+ * over rows and all-reduces with `sum`).  scalars = {sum e, sum e^2, rows, nonfinite}. */
+int fmhip_grad_floats(fmhip_model_t m, int64_t *n_floats);
+/* use caller-owned DEVICE memory (e.g. a torch tensor the host all-reduces); NULL = internal.
+ * The buffer must be zero-filled by the caller before the first step. */
+int fmhip_grad_bind(fmhip_model_t m, void *device_ptr);
+int fmhip_grad_ptr(fmhip_model_t m, void **device_ptr);
+int fmhip_step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t batch);
+/* applies the packed gradient (after the host's all-reduce, if any), then zeroes it */
+int fmhip_step_apply(fmhip_model_t m, double eta, double reg0, double regw, double regv);
+/* scalars of the packed gradient as last computed/all-reduced (synchronises) */
+int fmhip_step_stats(fmhip_model_t m, fmhip_stats *stats);
+
+/* ---- measurement ------------------------------------------------------------------ */
+int fmhip_profile_begin(fmhip_model_t m);                  /* start recording HIP events per kernel */
+int fmhip_profile_end(fmhip_model_t m, fmhip_profile *p);  /* synchronise, sum, stop recording */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMHIP_H */

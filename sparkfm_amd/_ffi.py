@@ -1,0 +1,123 @@
+"""ctypes binding of libfmhip.so — the same C ABI (include/fmhip.h) a JNI shim would bind.
+
+There is NO CPU fallback: if the HIP library is missing this module raises, loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfmhip.so")
+
+OK = 0
+K_FORWARD, K_REDUCE, K_BACKWARD, K_FIXUP, K_APPLY, K_COUNT = 0, 1, 2, 3, 4, 5
+KERNEL_NAMES = ("forward", "reduce", "backward", "fixup", "apply")
+RANGE_LEN = 64
+
+# every symbol include/fmhip.h declares (tests check the library exports all of them)
+SYMBOLS = (
+    "fmhip_version", "fmhip_last_error", "fmhip_device_count",
+    "fmhip_model_create", "fmhip_model_destroy", "fmhip_model_info",
+    "fmhip_model_set_params", "fmhip_model_get_params", "fmhip_model_set_params_f32", "fmhip_model_get_params_f32",
+    "fmhip_synchronize",
+    "fmhip_dataset_create", "fmhip_dataset_create_f32", "fmhip_dataset_destroy", "fmhip_dataset_info",
+    "fmhip_dataset_batch_info", "fmhip_dataset_get_transpose",
+    "fmhip_predict", "fmhip_rmse", "fmhip_residual", "fmhip_term_q",
+    "fmhip_sgd_step", "fmhip_sgd_epoch", "fmhip_batch_grad",
+    "fmhip_grad_floats", "fmhip_grad_bind", "fmhip_grad_ptr", "fmhip_step_compute", "fmhip_step_apply",
+    "fmhip_step_stats", "fmhip_profile_begin", "fmhip_profile_end",
+)
+
+
+class Stats(C.Structure):
+    _fields_ = [("sse", C.c_double), ("sum_e", C.c_double), ("rows", C.c_int64), ("nnz", C.c_int64),
+                ("nonfinite", C.c_int64), ("steps", C.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class Profile(C.Structure):
+    _fields_ = [("ms", C.c_double * K_COUNT), ("launches", C.c_int64 * K_COUNT), ("nnz", C.c_int64 * K_COUNT),
+                ("rows", C.c_int64 * K_COUNT)]
+
+    def as_dict(self):
+        return {KERNEL_NAMES[i]: dict(ms=self.ms[i], launches=self.launches[i], nnz=self.nnz[i], rows=self.rows[i])
+                for i in range(K_COUNT)}
+
+
+class FmhipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("fmhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Loads libfmhip.so; raises if it has not been built (no fallback of any kind)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libfmhip.so not found at %s — build it first: python -c 'import __graft_entry__ as g; g.build()' "
+            "(sparkfm_amd has no CPU fallback)" % LIB_PATH)
+    try:
+        # torch bundles its own HIP runtime (same soname); import it first so that one process
+        # never ends up with two runtimes when torch tensors/streams are shared with the library
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    P = C.POINTER
+    L.fmhip_version.restype = C.c_int
+    L.fmhip_last_error.restype = C.c_char_p
+    L.fmhip_device_count.argtypes = [P(C.c_int)]
+    L.fmhip_model_create.argtypes = [C.c_int, i64, i32, vp, P(vp)]
+    L.fmhip_model_destroy.argtypes = [vp]
+    L.fmhip_model_info.argtypes = [vp, P(i64), P(i32), P(i32)]
+    L.fmhip_model_set_params.argtypes = [vp, dbl, vp, vp]
+    L.fmhip_model_get_params.argtypes = [vp, P(dbl), vp, vp]
+    L.fmhip_model_set_params_f32.argtypes = [vp, C.c_float, vp, vp]
+    L.fmhip_model_get_params_f32.argtypes = [vp, P(C.c_float), vp, vp]
+    L.fmhip_synchronize.argtypes = [vp]
+    L.fmhip_dataset_create.argtypes = [C.c_int, i64, vp, vp, vp, vp, i64, P(vp)]
+    L.fmhip_dataset_create_f32.argtypes = [C.c_int, i64, vp, vp, vp, vp, i64, P(vp)]
+    L.fmhip_dataset_destroy.argtypes = [vp]
+    L.fmhip_dataset_info.argtypes = [vp, P(i64), P(i64), P(i64), P(i64), P(i64)]
+    L.fmhip_dataset_batch_info.argtypes = [vp, i64, P(i64), P(i64), P(i64), P(i64)]
+    L.fmhip_dataset_get_transpose.argtypes = [vp, i64, vp, vp, vp, vp]
+    L.fmhip_predict.argtypes = [vp, vp, vp]
+    L.fmhip_rmse.argtypes = [vp, vp, P(dbl), P(Stats)]
+    L.fmhip_residual.argtypes = [vp, vp, vp]
+    L.fmhip_term_q.argtypes = [vp, vp, vp]
+    L.fmhip_sgd_step.argtypes = [vp, vp, i64, dbl, dbl, dbl, dbl, P(Stats)]
+    L.fmhip_sgd_epoch.argtypes = [vp, vp, dbl, dbl, dbl, dbl, vp, P(Stats)]
+    L.fmhip_batch_grad.argtypes = [vp, vp, i64, vp, vp, P(dbl), P(Stats)]
+    L.fmhip_grad_floats.argtypes = [vp, P(i64)]
+    L.fmhip_grad_bind.argtypes = [vp, vp]
+    L.fmhip_grad_ptr.argtypes = [vp, P(vp)]
+    L.fmhip_step_compute.argtypes = [vp, vp, i64]
+    L.fmhip_step_apply.argtypes = [vp, dbl, dbl, dbl, dbl]
+    L.fmhip_step_stats.argtypes = [vp, P(Stats)]
+    L.fmhip_profile_begin.argtypes = [vp]
+    L.fmhip_profile_end.argtypes = [vp, P(Profile)]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ("fmhip_version", "fmhip_last_error"):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(code):
+    if code != OK:
+        raise FmhipError(code, load().fmhip_last_error().decode("utf-8", "replace"))
+    return code
+
+
+def ptr(a):
+    """numpy array (or None) -> void* for the C ABI."""
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

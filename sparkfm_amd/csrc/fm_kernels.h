@@ -1,0 +1,65 @@
+// fm_kernels.h — launchers of the gfx950 kernels (internal to libfmhip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fmhip {
+
+constexpr int kRangeLen = 64;      // == FMHIP_RANGE_LEN
+constexpr int kPartPad = 4;        // partial row = Kp floats + {sum e*x, sum e*x^2, pad, pad}
+constexpr int kScalars = 8;        // packed-gradient tail: {sum e, sum e^2, rows, nonfinite, ...}
+
+// padded factor count: 4 * LPN * J with LPN = lanes per row-slot (<= 16), J float4 per lane
+int padded_factors(int k);
+
+enum FwdMode { kFwdTrain = 0, kFwdResidual = 1, kFwdQ = 2 };
+
+struct FwdArgs {
+    const int64_t *row_ptr;  // global CSR offsets (device), indexed row0 + r
+    const int32_t *col;
+    const float *val;
+    const float *y;
+    const float *V;   // [(n+1)][Kp]
+    const float *w;   // [n+1]
+    const float *w0;  // [1]
+    int64_t row0;
+    int32_t n_rows;
+    float *P;     // train: [rows][Kp] = e*q ; q-mode: [rows][Kp] = q
+    float *e;     // [rows] e = yhat - y   (residual / train)
+    float *yhat;  // optional [rows]
+};
+
+struct BwdArgs {
+    const uint32_t *crow;      // batch CSC: bit31 = first entry of its column, low bits = batch-local row
+    const float *cval;
+    const int32_t *range_seg;  // [n_ranges] compressed column index holding entry rho*kRangeLen
+    const int32_t *cfeat;      // [n_cols] feature id of compressed column
+    const int32_t *cptr;       // [n_cols+1]
+    const int32_t *split_seg;  // [n_split] compressed columns that span >1 range
+    int32_t nnz;
+    int32_t n_ranges;
+    int32_t n_split;
+    const float *P;            // [rows][Kp]
+    const float *e;            // [rows]
+    float *GV;                 // [n1p][Kp]
+    float *Gw;                 // [n1p]
+    float *Gb;                 // [n1p]
+    float *part;               // [n_ranges][2][Kp + kPartPad]
+};
+
+struct ApplyArgs {
+    float *V, *w, *w0;
+    float *GV, *Gw, *Gb;
+    const float *scal;  // {sum e, sum e^2, rows, ...}
+    int64_t n1;         // n+1 (rows of V actually used)
+    float eta, reg0, regw, regv;
+};
+
+hipError_t launch_forward(int Kp, FwdMode mode, const FwdArgs &a, hipStream_t s);
+hipError_t launch_backward(int Kp, const BwdArgs &a, hipStream_t s);
+hipError_t launch_fixup(int Kp, const BwdArgs &a, hipStream_t s);
+hipError_t launch_apply(int Kp, const ApplyArgs &a, hipStream_t s);
+// scal[0..3] = {sum e, sum e^2, n, nonfinite}; acc (optional, 4 doubles) += the same
+hipError_t launch_reduce_e(const float *e, int32_t n, float *scal, double *acc, hipStream_t s);
+
+}  // namespace fmhip

@@ -1,0 +1,416 @@
+// fm_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the FM mini-batch SGD step.
+//
+// Work shapes (all HBM/L2-bound gather + stream; ~1 flop/B, so no MFMA):
+//   k_forward  CSR rows  : per stored nonzero gather one Kp-float row of V (128 B at Kp=32)
+//   k_backward CSC ranges: per stored nonzero gather one Kp-float row of P = e*q
+//   k_fixup    sums the partials of columns cut across ranges (fixed order -> deterministic)
+//   k_apply    dense SGD update fused with zeroing the packed gradient
+//
+// Lane geometry: a "slot" = LPN consecutive lanes owning one CSR row (forward) or one CSC
+// range (backward); lane l of a slot holds factors 4*(l + jj*LPN) .. +3 for jj < J, so one
+// wave-instruction moves 64/LPN whole rows of Kp = 4*LPN*J floats, each row a contiguous,
+// 16-B-per-lane coalesced segment.  Index/value streams are read LPN entries at a time (one
+// per lane, contiguous) and broadcast inside the slot with ds_bpermute (__shfl width LPN).
+//
+// Formulas restated from SparkFM (S/ = src/main/scala/io/edstud/spark/):
+//   forward   S/fm/FMModel.scala:34-63   yhat = w0 + sum w x + 0.5*sum_f[(sum v x)^2 - sum (v x)^2]
+//   residual  S/fm/lib/ALS.scala:142-144 e = yhat - y
+//   q         S/fm/lib/ALS.scala:146-150 q_f = sum_i v_fi x_i
+//   gradient  S/fm/lib/ALS.scala:56-58   h(v_fi) = x*q_f - x^2*v_fi ; :40 h(w_i) = x ; :21 h(w0) = 1
+#include "fm_kernels.h"
+
+namespace fmhip {
+
+int padded_factors(int k) {
+    int kp = 4;
+    while (kp < k) kp <<= 1;
+    return kp;
+}
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4mul(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ void f4fma(float4 &acc, float4 a, float s) {
+    acc.x = fmaf(a.x, s, acc.x); acc.y = fmaf(a.y, s, acc.y); acc.z = fmaf(a.z, s, acc.z); acc.w = fmaf(a.w, s, acc.w);
+}
+__device__ __forceinline__ void f4add(float4 &acc, float4 a) { acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+__device__ __forceinline__ void f4sqacc(float4 &acc, float4 a) {
+    acc.x = fmaf(a.x, a.x, acc.x); acc.y = fmaf(a.y, a.y, acc.y); acc.z = fmaf(a.z, a.z, acc.z); acc.w = fmaf(a.w, a.w, acc.w);
+}
+// (q*q - s) with the product rounded BEFORE the subtraction (no fma contraction): for a
+// single-nonzero row q = v*x and s = round((v*x)^2), so this is exactly 0 (quirk Q6).
+__device__ __forceinline__ float sq_minus(float q, float s) { return __fsub_rn(__fmul_rn(q, q), s); }
+__device__ __forceinline__ float f4sqminus(float4 q, float4 s) {
+    return (sq_minus(q.x, s.x) + sq_minus(q.y, s.y)) + (sq_minus(q.z, s.z) + sq_minus(q.w, s.w));
+}
+
+// ------------------------------------------------------------------ forward
+template <int LPN, int J, int MODE>
+__global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
+    constexpr int KP = 4 * LPN * J;
+    constexpr int SLOTS = kBlock / LPN;
+    constexpr int CH = (LPN * J > 16) ? (16 / J) : LPN;  // entries whose V rows are in flight together
+    const int l = threadIdx.x & (LPN - 1);
+    const int slot = threadIdx.x / LPN;
+    const float w0 = *a.w0;
+    for (int r = blockIdx.x * SLOTS + slot; r < a.n_rows; r += gridDim.x * SLOTS) {
+        const int64_t p0 = a.row_ptr[a.row0 + r], p1 = a.row_ptr[a.row0 + r + 1];
+        float4 q[J], s[J];
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) { q[jj] = f4zero(); s[jj] = f4zero(); }
+        float lin = 0.f;
+        for (int64_t base = p0; base < p1; base += LPN) {
+            const int64_t p = base + l;
+            int c = 0;
+            float x = 0.f;
+            if (p < p1) {
+                c = a.col[p];
+                x = a.val[p];
+                lin = fmaf(a.w[c], x, lin);
+            }
+            const int cnt = (int)((p1 - base) < (int64_t)LPN ? (p1 - base) : (int64_t)LPN);
+#pragma unroll
+            for (int c0 = 0; c0 < LPN; c0 += CH) {
+                float4 t[CH][J];
+                float xs[CH];
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int cj = __shfl(c, c0 + j, LPN);
+                    xs[j] = __shfl(x, c0 + j, LPN);
+                    const float4 *vr = reinterpret_cast<const float4 *>(a.V + (size_t)cj * KP) + l;
+#pragma unroll
+                    for (int jj = 0; jj < J; ++jj) t[j][jj] = vr[jj * LPN];
+                }
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const bool live = c0 + j < cnt;
+#pragma unroll
+                    for (int jj = 0; jj < J; ++jj) {
+                        float4 tv = f4mul(t[j][jj], xs[j]);
+                        if (!live) tv = f4zero();
+                        f4add(q[jj], tv);       // q_f accumulates in stored order (FMModel.scala:59)
+                        f4sqacc(s[jj], tv);     // sum_sqr_f (FMModel.scala:60)
+                    }
+                }
+            }
+        }
+        float u = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) u += f4sqminus(q[jj], s[jj]);
+        float tot = fmaf(0.5f, u, lin);
+#pragma unroll
+        for (int m = LPN >> 1; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, LPN);
+        const float yhat = w0 + tot;
+        const float e = yhat - a.y[a.row0 + r];
+        if (MODE == kFwdTrain) {
+            float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) pr[jj * LPN] = f4mul(q[jj], e);
+        } else if (MODE == kFwdQ) {
+            float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) pr[jj * LPN] = q[jj];
+        }
+        if (l == 0) {
+            if (a.e) a.e[r] = e;
+            if (a.yhat) a.yhat[r] = yhat;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ backward
+template <int LPN, int J>
+__device__ __forceinline__ void store_row(float *dst, int l, const float4 (&acc)[J], float sa, float sb, float *dsa, float *dsb) {
+    float4 *d4 = reinterpret_cast<float4 *>(dst) + l;
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) d4[jj * LPN] = acc[jj];
+    if (l == 0) { *dsa = sa; *dsb = sb; }
+}
+
+// One slot walks kRangeLen consecutive entries of the batch's CSC stream.  Column
+// boundaries inside the range are handled serially (flush + reset), so every slot does the
+// same amount of work whatever the column-length skew (power-law features), no atomics are
+// needed and the summation order is fixed.  Outputs per closed column piece:
+//   whole column inside the range            -> G rows directly
+//   piece of a column begun in an earlier range -> part[rho][0]  ("head")
+//   last piece, column continues past the range -> part[rho][1]  ("tail")
+template <int LPN, int J>
+__global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
+    constexpr int KP = 4 * LPN * J;
+    constexpr int SLOTS = kBlock / LPN;
+    constexpr int PR = KP + kPartPad;
+    constexpr int CH = (LPN * J > 16) ? (16 / J) : LPN;  // entries whose P rows are in flight together
+    const int l = threadIdx.x & (LPN - 1);
+    const int rho = blockIdx.x * SLOTS + threadIdx.x / LPN;
+    if (rho >= a.n_ranges) return;
+    const int beg = rho * kRangeLen;
+    const int end = (beg + kRangeLen < a.nnz) ? beg + kRangeLen : a.nnz;
+    int seg = a.range_seg[rho];
+    bool is_head = (a.crow[beg] >> 31) == 0u;
+    float4 acc[J];
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) acc[jj] = f4zero();
+    float sa = 0.f, sb = 0.f;
+    for (int base = beg; base < end; base += LPN) {
+        const int p = base + l;
+        uint32_t rf = 0u;
+        float x = 0.f, ee = 0.f;
+        if (p < end) {
+            rf = a.crow[p];
+            x = a.cval[p];
+            ee = a.e[rf & 0x7fffffffu];
+        }
+        const int cnt = (end - base) < LPN ? (end - base) : LPN;
+#pragma unroll
+        for (int c0 = 0; c0 < LPN; c0 += CH) {
+            float4 pv[CH][J];
+            uint32_t rj[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                rj[j] = __shfl(rf, c0 + j, LPN);
+                const float4 *pr = reinterpret_cast<const float4 *>(a.P + (size_t)(rj[j] & 0x7fffffffu) * KP) + l;
+#pragma unroll
+                for (int jj = 0; jj < J; ++jj) pv[j][jj] = pr[jj * LPN];
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const float xj = __shfl(x, c0 + j, LPN);
+                const float ej = __shfl(ee, c0 + j, LPN);
+                if (c0 + j < cnt) {
+                    if ((rj[j] >> 31) && (base + c0 + j != beg)) {
+                        // the open column ends here: flush it
+                        if (is_head) {
+                            float *pr = a.part + ((size_t)rho * 2) * PR;
+                            store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1);
+                        } else {
+                            const int i = a.cfeat[seg];
+                            store_row<LPN, J>(a.GV + (size_t)i * KP, l, acc, sa, sb, a.Gw + i, a.Gb + i);
+                        }
+                        is_head = false;
+                        ++seg;
+#pragma unroll
+                        for (int jj = 0; jj < J; ++jj) acc[jj] = f4zero();
+                        sa = 0.f;
+                        sb = 0.f;
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < J; ++jj) f4fma(acc[jj], pv[j][jj], xj);  // sum x * (e*q)
+                    const float ex = ej * xj;
+                    sa += ex;                 // sum e*x      -> G_w   (h(w_i) = x)
+                    sb = fmaf(ex, xj, sb);    // sum e*x^2    -> G_b   (the -x^2*v term of h(v))
+                }
+            }
+        }
+    }
+    const bool tail_open = (end < a.nnz) && ((a.crow[end] >> 31) == 0u);
+    if (is_head) {
+        float *pr = a.part + ((size_t)rho * 2) * PR;
+        store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1);
+    } else if (tail_open) {
+        float *pr = a.part + ((size_t)rho * 2 + 1) * PR;
+        store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1);
+    } else {
+        const int i = a.cfeat[seg];
+        store_row<LPN, J>(a.GV + (size_t)i * KP, l, acc, sa, sb, a.Gw + i, a.Gb + i);
+    }
+}
+
+// One wave per column that spans more than one range: column sum = tail(ra) + sum_{ra<rho<=rb} head(rho),
+// taken slot-strided then tree-reduced — a fixed order, so results are run-to-run identical.
+template <int LPN, int J>
+__global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
+    constexpr int KP = 4 * LPN * J;
+    constexpr int PR = KP + kPartPad;
+    constexpr int WSLOTS = 64 / LPN;
+    const int lane = threadIdx.x & 63;
+    const int l = lane & (LPN - 1);
+    const int ws = lane / LPN;
+    const int idx = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (idx >= a.n_split) return;
+    const int seg = a.split_seg[idx];
+    const int ca = a.cptr[seg], cb = a.cptr[seg + 1];
+    const int ra = ca / kRangeLen, rb = (cb - 1) / kRangeLen;
+    const int count = rb - ra + 1;
+    float4 acc[J];
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) acc[jj] = f4zero();
+    float sa = 0.f, sb = 0.f;
+    for (int t = ws; t < count; t += WSLOTS) {
+        const float *pr = a.part + ((size_t)(ra + t) * 2 + (t == 0 ? 1 : 0)) * PR;
+        const float4 *p4 = reinterpret_cast<const float4 *>(pr) + l;
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) f4add(acc[jj], p4[jj * LPN]);
+        sa += pr[KP];
+        sb += pr[KP + 1];
+    }
+#pragma unroll
+    for (int m = 32; m >= LPN; m >>= 1) {
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) {
+            acc[jj].x += __shfl_xor(acc[jj].x, m, 64);
+            acc[jj].y += __shfl_xor(acc[jj].y, m, 64);
+            acc[jj].z += __shfl_xor(acc[jj].z, m, 64);
+            acc[jj].w += __shfl_xor(acc[jj].w, m, 64);
+        }
+        sa += __shfl_xor(sa, m, 64);
+        sb += __shfl_xor(sb, m, 64);
+    }
+    if (ws == 0) {
+        const int i = a.cfeat[seg];
+        store_row<LPN, J>(a.GV + (size_t)i * KP, l, acc, sa, sb, a.Gw + i, a.Gb + i);
+    }
+}
+
+// ------------------------------------------------------------------ apply
+// theta <- theta - eta*(g/|B| + reg*theta) with g_V = G_V - v*G_b (S/fm/lib/ALS.scala:56-58:
+// sum e*(x*q - x^2*v)); the packed gradient is zeroed on the way out.
+template <int KP>
+__global__ __launch_bounds__(kBlock) void k_apply(ApplyArgs a) {
+    constexpr int LPR = KP / 4;  // lanes per feature row (<= 64, divides the wave)
+    const float invb = a.scal[2] > 0.f ? 1.0f / a.scal[2] : 0.f;
+    const int64_t total = a.n1 * LPR;
+    float4 *V4 = reinterpret_cast<float4 *>(a.V);
+    float4 *G4 = reinterpret_cast<float4 *>(a.GV);
+    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = idx / LPR;
+        const float b = a.Gb[i];
+        float4 g = G4[idx], v = V4[idx];
+        v.x -= a.eta * fmaf(a.regv, v.x, (g.x - v.x * b) * invb);
+        v.y -= a.eta * fmaf(a.regv, v.y, (g.y - v.y * b) * invb);
+        v.z -= a.eta * fmaf(a.regv, v.z, (g.z - v.z * b) * invb);
+        v.w -= a.eta * fmaf(a.regv, v.w, (g.w - v.w * b) * invb);
+        V4[idx] = v;
+        G4[idx] = f4zero();
+        if ((idx % LPR) == 0) {
+            const float wi = a.w[i];
+            a.w[i] = wi - a.eta * fmaf(a.regw, wi, a.Gw[i] * invb);
+            a.Gw[i] = 0.f;
+            a.Gb[i] = 0.f;  // same wave already holds its copy of b (all lanes of a row share a wave)
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float w0 = *a.w0;
+        *a.w0 = w0 - a.eta * fmaf(a.reg0, w0, a.scal[0] * invb);
+    }
+}
+
+// ------------------------------------------------------------------ reduce e
+// single block, fixed order, fp64 accumulation: {sum e, sum e^2, n, nonfinite}
+__global__ __launch_bounds__(1024) void k_reduce_e(const float *e, int32_t n, float *scal, double *acc) {
+    __shared__ double sh[3][16];
+    double s1 = 0.0, s2 = 0.0, bad = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float v = e[i];
+        if (!isfinite(v)) bad += 1.0;
+        s1 += (double)v;
+        s2 += (double)v * (double)v;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        s1 += __shfl_xor(s1, m, 64);
+        s2 += __shfl_xor(s2, m, 64);
+        bad += __shfl_xor(bad, m, 64);
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][wv] = s1; sh[1][wv] = s2; sh[2][wv] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t1 = 0.0, t2 = 0.0, tb = 0.0;
+        for (int i = 0; i < 16; ++i) { t1 += sh[0][i]; t2 += sh[1][i]; tb += sh[2][i]; }
+        if (scal) { scal[0] = (float)t1; scal[1] = (float)t2; scal[2] = (float)n; scal[3] = (float)tb; }
+        if (acc) { acc[0] += t1; acc[1] += t2; acc[2] += (double)n; acc[3] += tb; }
+    }
+}
+
+template <int LPN, int J>
+hipError_t fwd_dispatch(FwdMode mode, const FwdArgs &a, hipStream_t s) {
+    constexpr int SLOTS = kBlock / LPN;
+    int64_t blocks = ((int64_t)a.n_rows + SLOTS - 1) / SLOTS;
+    if (blocks > 65536) blocks = 65536;
+    if (blocks < 1) return hipSuccess;
+    dim3 g((unsigned)blocks), b(kBlock);
+    switch (mode) {
+        case kFwdTrain: hipLaunchKernelGGL((k_forward<LPN, J, kFwdTrain>), g, b, 0, s, a); break;
+        case kFwdResidual: hipLaunchKernelGGL((k_forward<LPN, J, kFwdResidual>), g, b, 0, s, a); break;
+        case kFwdQ: hipLaunchKernelGGL((k_forward<LPN, J, kFwdQ>), g, b, 0, s, a); break;
+    }
+    return hipGetLastError();
+}
+
+template <int LPN, int J>
+hipError_t bwd_dispatch(const BwdArgs &a, hipStream_t s) {
+    constexpr int SLOTS = kBlock / LPN;
+    if (a.n_ranges < 1) return hipSuccess;
+    dim3 g((unsigned)((a.n_ranges + SLOTS - 1) / SLOTS)), b(kBlock);
+    hipLaunchKernelGGL((k_backward<LPN, J>), g, b, 0, s, a);
+    return hipGetLastError();
+}
+
+template <int LPN, int J>
+hipError_t fix_dispatch(const BwdArgs &a, hipStream_t s) {
+    if (a.n_split < 1) return hipSuccess;
+    dim3 g((unsigned)((a.n_split + 3) / 4)), b(kBlock);
+    hipLaunchKernelGGL((k_fixup<LPN, J>), g, b, 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+#define FMHIP_KP_SWITCH(KPV, CALL)                       \
+    switch (KPV) {                                       \
+        case 4: return CALL(1, 1);                       \
+        case 8: return CALL(2, 1);                       \
+        case 16: return CALL(4, 1);                      \
+        case 32: return CALL(8, 1);                      \
+        case 64: return CALL(16, 1);                     \
+        case 128: return CALL(16, 2);                    \
+        case 256: return CALL(16, 4);                    \
+        default: return hipErrorInvalidValue;            \
+    }
+
+hipError_t launch_forward(int Kp, FwdMode mode, const FwdArgs &a, hipStream_t s) {
+#define CALL(L_, J_) fwd_dispatch<L_, J_>(mode, a, s)
+    FMHIP_KP_SWITCH(Kp, CALL)
+#undef CALL
+}
+
+hipError_t launch_backward(int Kp, const BwdArgs &a, hipStream_t s) {
+#define CALL(L_, J_) bwd_dispatch<L_, J_>(a, s)
+    FMHIP_KP_SWITCH(Kp, CALL)
+#undef CALL
+}
+
+hipError_t launch_fixup(int Kp, const BwdArgs &a, hipStream_t s) {
+#define CALL(L_, J_) fix_dispatch<L_, J_>(a, s)
+    FMHIP_KP_SWITCH(Kp, CALL)
+#undef CALL
+}
+
+hipError_t launch_apply(int Kp, const ApplyArgs &a, hipStream_t s) {
+    int64_t total = a.n1 * (Kp / 4);
+    int64_t blocks = (total + kBlock - 1) / kBlock;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    dim3 g((unsigned)blocks), b(kBlock);
+    switch (Kp) {
+        case 4: hipLaunchKernelGGL((k_apply<4>), g, b, 0, s, a); break;
+        case 8: hipLaunchKernelGGL((k_apply<8>), g, b, 0, s, a); break;
+        case 16: hipLaunchKernelGGL((k_apply<16>), g, b, 0, s, a); break;
+        case 32: hipLaunchKernelGGL((k_apply<32>), g, b, 0, s, a); break;
+        case 64: hipLaunchKernelGGL((k_apply<64>), g, b, 0, s, a); break;
+        case 128: hipLaunchKernelGGL((k_apply<128>), g, b, 0, s, a); break;
+        case 256: hipLaunchKernelGGL((k_apply<256>), g, b, 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_e(const float *e, int32_t n, float *scal, double *acc, hipStream_t s) {
+    hipLaunchKernelGGL(k_reduce_e, dim3(1), dim3(1024), 0, s, e, n, scal, acc);
+    return hipGetLastError();
+}
+
+}  // namespace fmhip

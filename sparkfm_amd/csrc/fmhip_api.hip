@@ -1,0 +1,857 @@
+// fmhip_api.hip — host side of libfmhip.so: the C ABI declared in include/fmhip.h.
+//
+// Owns device memory, the per-batch transposes and the launch sequence of one mini-batch
+// SGD step:   k_forward -> k_reduce_e -> k_backward -> k_fixup -> [host all-reduce] -> k_apply
+// Everything here is plumbing; the arithmetic lives in fm_kernels.hip.
+#include "../../include/fmhip.h"
+#include "fm_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace fmhip;
+
+static_assert(FMHIP_RANGE_LEN == kRangeLen, "header and kernels disagree on the CSC range length");
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return fail(_e == hipErrorOutOfMemory ? FMHIP_ERR_NOMEM : FMHIP_ERR_HIP,         \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define TRY(expr)               \
+    do {                        \
+        int _r = (expr);        \
+        if (_r != FMHIP_OK) return _r; \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count) {
+        release();
+        if (count == 0) return FMHIP_OK;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(FMHIP_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        }
+        n = count;
+        return FMHIP_OK;
+    }
+    int ensure(size_t count) { return count <= n ? FMHIP_OK : alloc(count); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+struct BatchMeta {
+    int64_t row0 = 0, rows = 0;
+    int64_t nnz0 = 0;   // offset of the batch in the global CSR/CSC entry arrays
+    int32_t nnz = 0;
+    int32_t n_cols = 0;     // compressed columns (features present in the batch)
+    int64_t col_off = 0;    // offset into cfeat; cptr offset is col_off + batch index
+    int32_t n_ranges = 0;
+    int64_t range_off = 0;
+    int32_t n_split = 0;
+    int64_t split_off = 0;
+};
+
+struct ProfRec {
+    int kind;
+    hipEvent_t a, b;
+    int64_t nnz, rows;
+};
+
+}  // namespace
+
+struct fmhip_dataset {
+    int device = 0;
+    int64_t n_rows = 0, nnz = 0, dimension = 0, batch_rows = 0;
+    int64_t max_rows = 0;
+    int32_t max_ranges = 0;
+    std::vector<BatchMeta> batches;
+    DevBuf<int64_t> row_ptr;
+    DevBuf<int32_t> col;
+    DevBuf<float> val, y;
+    DevBuf<uint32_t> crow;
+    DevBuf<float> cval;
+    DevBuf<int32_t> cfeat, cptr, range_seg, split_seg;
+};
+
+struct fmhip_model {
+    int device = 0;
+    int64_t n = 0, n1 = 0, n1p = 0;
+    int32_t k = 0, Kp = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DevBuf<float> V, w, w0;
+    DevBuf<float> grad_own;
+    float *grad = nullptr;        // packed gradient in use (own or bound)
+    bool grad_dirty = false;      // holds a gradient that has not been applied/zeroed
+    DevBuf<float> P, e, part;
+    DevBuf<double> acc;           // {sum e, sum e^2, rows, nonfinite}
+    int64_t last_nnz = 0, last_rows = 0;
+    bool profiling = false;
+    std::vector<ProfRec> prof;
+
+    float *GV() const { return grad; }
+    float *Gw() const { return grad + (size_t)n1p * Kp; }
+    float *Gb() const { return grad + (size_t)n1p * Kp + n1p; }
+    float *scal() const { return grad + (size_t)n1p * Kp + 2 * (size_t)n1p; }
+    size_t grad_floats() const { return (size_t)n1p * Kp + 2 * (size_t)n1p + kScalars; }
+};
+
+namespace {
+
+struct ProfScope {
+    fmhip_model *m;
+    ProfRec r{};
+    bool on;
+    ProfScope(fmhip_model *m_, int kind, int64_t nnz, int64_t rows) : m(m_), on(m_->profiling) {
+        if (!on) return;
+        r.kind = kind;
+        r.nnz = nnz;
+        r.rows = rows;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(r.a, m->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, m->stream);
+        m->prof.push_back(r);
+    }
+};
+
+int set_device(int device) {
+    HIP_TRY(hipSetDevice(device));
+    return FMHIP_OK;
+}
+
+// ---- dataset construction -------------------------------------------------------
+
+struct HostBatch {
+    std::vector<int32_t> cfeat, cptr, range_seg, split_seg;
+};
+
+// Row -> column transpose of one batch (S/DataSet.scala:31-38: zipWithIndex + flatMap
+// (featureId -> (rowIdx, value)) + groupByKey), as a stable counting sort: inside a column
+// the batch-local row indices ascend.  `cnt` is a per-thread scratch of dimension+1 zeros.
+void build_batch(const int64_t *row_ptr, const int32_t *col, const float *val, const BatchMeta &bm,
+                 std::vector<int32_t> &cnt, uint32_t *crow, float *cval, HostBatch &hb) {
+    const int64_t p0 = bm.nnz0, p1 = bm.nnz0 + bm.nnz;
+    std::vector<int32_t> &feat = hb.cfeat;
+    feat.clear();
+    for (int64_t p = p0; p < p1; ++p)
+        if (cnt[col[p]]++ == 0) feat.push_back(col[p]);
+    std::sort(feat.begin(), feat.end());
+    const size_t nc = feat.size();
+    hb.cptr.assign(nc + 1, 0);
+    for (size_t s = 0; s < nc; ++s) {
+        hb.cptr[s + 1] = hb.cptr[s] + cnt[feat[s]];
+        cnt[feat[s]] = hb.cptr[s];  // becomes the write cursor of the column
+    }
+    for (int64_t r = 0; r < bm.rows; ++r) {
+        const int64_t a = row_ptr[bm.row0 + r], b = row_ptr[bm.row0 + r + 1];
+        for (int64_t p = a; p < b; ++p) {
+            const int32_t d = cnt[col[p]]++;
+            crow[d] = (uint32_t)r;
+            cval[d] = val[p];
+        }
+    }
+    for (size_t s = 0; s < nc; ++s) {
+        crow[hb.cptr[s]] |= 0x80000000u;  // first entry of its column
+        cnt[feat[s]] = 0;                 // leave the scratch clean for the next batch
+    }
+    const int32_t n_ranges = (int32_t)((bm.nnz + kRangeLen - 1) / kRangeLen);
+    hb.range_seg.assign((size_t)n_ranges, 0);
+    size_t s = 0;
+    for (int32_t rho = 0; rho < n_ranges; ++rho) {
+        const int32_t pos = rho * kRangeLen;
+        while (s + 1 < nc && hb.cptr[s + 1] <= pos) ++s;
+        hb.range_seg[(size_t)rho] = (int32_t)s;
+    }
+    hb.split_seg.clear();
+    for (size_t c = 0; c < nc; ++c)
+        if (hb.cptr[c] / kRangeLen < (hb.cptr[c + 1] - 1) / kRangeLen) hb.split_seg.push_back((int32_t)c);
+}
+
+template <typename T>
+int upload(DevBuf<T> &dst, const T *src, size_t n) {
+    TRY(dst.alloc(n));
+    if (n) HIP_TRY(hipMemcpy(dst.p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return FMHIP_OK;
+}
+
+template <typename FT>
+int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const FT *val,
+                        const FT *y, int64_t batch_rows, fmhip_dataset_t *out) {
+    if (!out) return fail(FMHIP_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n_rows < 0) return fail(FMHIP_ERR_INVALID, "n_rows < 0");
+    if (!row_ptr) return fail(FMHIP_ERR_INVALID, "row_ptr is NULL");
+    if (row_ptr[0] != 0) return fail(FMHIP_ERR_INVALID, "row_ptr[0] must be 0");
+    for (int64_t r = 0; r < n_rows; ++r)
+        if (row_ptr[r + 1] < row_ptr[r]) return fail(FMHIP_ERR_INVALID, "row_ptr decreases at row %lld", (long long)r);
+    const int64_t nnz = row_ptr[n_rows];
+    if (nnz > 0 && (!col || !val)) return fail(FMHIP_ERR_INVALID, "col/val is NULL");
+    if (n_rows > 0 && !y) return fail(FMHIP_ERR_INVALID, "y is NULL");
+    int32_t dim = 0;
+    for (int64_t p = 0; p < nnz; ++p) {
+        if (col[p] < 0) return fail(FMHIP_ERR_INVALID, "negative feature index at entry %lld", (long long)p);
+        dim = std::max(dim, col[p]);
+    }
+    TRY(set_device(device));
+    fmhip_dataset *d = new (std::nothrow) fmhip_dataset();
+    if (!d) return fail(FMHIP_ERR_NOMEM, "out of host memory");
+    d->device = device;
+    d->n_rows = n_rows;
+    d->nnz = nnz;
+    d->dimension = dim;  // S/DataSet.scala:27-29
+    if (batch_rows <= 0 || batch_rows > n_rows) batch_rows = std::max<int64_t>(n_rows, 1);
+    d->batch_rows = batch_rows;
+    const int64_t nb = n_rows > 0 ? (n_rows + batch_rows - 1) / batch_rows : 0;
+    d->batches.resize((size_t)nb);
+    for (int64_t b = 0; b < nb; ++b) {
+        BatchMeta &bm = d->batches[(size_t)b];
+        bm.row0 = b * batch_rows;
+        bm.rows = std::min(batch_rows, n_rows - bm.row0);
+        bm.nnz0 = row_ptr[bm.row0];
+        const int64_t bn = row_ptr[bm.row0 + bm.rows] - bm.nnz0;
+        if (bn > (int64_t)0x7fffffff - 2 * kRangeLen || bm.rows > 0x7fffffff) {
+            delete d;
+            return fail(FMHIP_ERR_UNSUPPORTED, "batch %lld holds %lld nonzeros; the per-batch limit is 2^31", (long long)b,
+                        (long long)bn);
+        }
+        bm.nnz = (int32_t)bn;
+        d->max_rows = std::max(d->max_rows, bm.rows);
+    }
+    // fp32 copies of the streams (device arithmetic is fp32)
+    std::vector<float> valf((size_t)nnz), yf((size_t)n_rows);
+    for (int64_t p = 0; p < nnz; ++p) valf[(size_t)p] = (float)val[p];
+    for (int64_t r = 0; r < n_rows; ++r) yf[(size_t)r] = (float)y[r];
+    std::vector<uint32_t> crow((size_t)nnz);
+    std::vector<float> cval((size_t)nnz);
+    std::vector<HostBatch> hbs((size_t)nb);
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        int nt = (int)std::min<int64_t>(nb, hw ? hw : 1);
+        nt = std::max(nt, 1);
+        std::vector<std::thread> pool;
+        auto work = [&](int t) {
+            std::vector<int32_t> cnt((size_t)dim + 2, 0);
+            for (int64_t b = t; b < nb; b += nt) {
+                const BatchMeta &bm = d->batches[(size_t)b];
+                build_batch(row_ptr, col, valf.data(), bm, cnt, crow.data() + bm.nnz0, cval.data() + bm.nnz0,
+                            hbs[(size_t)b]);
+            }
+        };
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto &th : pool) th.join();
+    }
+    std::vector<int32_t> cfeat, cptr, range_seg, split_seg;
+    for (int64_t b = 0; b < nb; ++b) {
+        BatchMeta &bm = d->batches[(size_t)b];
+        HostBatch &hb = hbs[(size_t)b];
+        bm.n_cols = (int32_t)hb.cfeat.size();
+        bm.col_off = (int64_t)cfeat.size();
+        bm.n_ranges = (int32_t)hb.range_seg.size();
+        bm.range_off = (int64_t)range_seg.size();
+        bm.n_split = (int32_t)hb.split_seg.size();
+        bm.split_off = (int64_t)split_seg.size();
+        d->max_ranges = std::max(d->max_ranges, bm.n_ranges);
+        cfeat.insert(cfeat.end(), hb.cfeat.begin(), hb.cfeat.end());
+        cptr.insert(cptr.end(), hb.cptr.begin(), hb.cptr.end());
+        range_seg.insert(range_seg.end(), hb.range_seg.begin(), hb.range_seg.end());
+        split_seg.insert(split_seg.end(), hb.split_seg.begin(), hb.split_seg.end());
+        HostBatch().cfeat.swap(hb.cfeat);
+    }
+    int rc = FMHIP_OK;
+    if ((rc = upload(d->row_ptr, row_ptr, (size_t)n_rows + 1)) || (rc = upload(d->col, col, (size_t)nnz)) ||
+        (rc = upload(d->val, valf.data(), (size_t)nnz)) || (rc = upload(d->y, yf.data(), (size_t)n_rows)) ||
+        (rc = upload(d->crow, crow.data(), (size_t)nnz)) || (rc = upload(d->cval, cval.data(), (size_t)nnz)) ||
+        (rc = upload(d->cfeat, cfeat.data(), cfeat.size())) || (rc = upload(d->cptr, cptr.data(), cptr.size())) ||
+        (rc = upload(d->range_seg, range_seg.data(), range_seg.size())) ||
+        (rc = upload(d->split_seg, split_seg.data(), split_seg.size()))) {
+        delete d;
+        return rc;
+    }
+    *out = d;
+    return FMHIP_OK;
+}
+
+// ---- model helpers ----------------------------------------------------------------
+
+int check_pair(fmhip_model_t m, fmhip_dataset_t d) {
+    if (!m || !d) return fail(FMHIP_ERR_INVALID, "model or dataset is NULL");
+    if (m->device != d->device) return fail(FMHIP_ERR_INVALID, "model on device %d, dataset on device %d", m->device, d->device);
+    if (d->dimension > m->n)
+        return fail(FMHIP_ERR_SHAPE, "dataset has feature index %lld but the model has num_attribute = %lld",
+                    (long long)d->dimension, (long long)m->n);
+    return set_device(m->device);
+}
+
+int check_batch(fmhip_dataset_t d, int64_t batch) {
+    if (batch < 0 || batch >= (int64_t)d->batches.size())
+        return fail(FMHIP_ERR_INVALID, "batch %lld out of range [0, %zu)", (long long)batch, d->batches.size());
+    return FMHIP_OK;
+}
+
+int ensure_workspace(fmhip_model_t m, fmhip_dataset_t d) {
+    TRY(m->P.ensure((size_t)std::max<int64_t>(d->max_rows, 1) * m->Kp));
+    TRY(m->e.ensure((size_t)std::max<int64_t>(d->max_rows, 1)));
+    TRY(m->part.ensure((size_t)std::max<int32_t>(d->max_ranges, 1) * 2 * (m->Kp + kPartPad)));
+    return FMHIP_OK;
+}
+
+FwdArgs fwd_args(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm) {
+    FwdArgs a{};
+    a.row_ptr = d->row_ptr.p;
+    a.col = d->col.p;
+    a.val = d->val.p;
+    a.y = d->y.p;
+    a.V = m->V.p;
+    a.w = m->w.p;
+    a.w0 = m->w0.p;
+    a.row0 = bm.row0;
+    a.n_rows = (int32_t)bm.rows;
+    a.P = m->P.p;
+    a.e = m->e.p;
+    a.yhat = nullptr;
+    return a;
+}
+
+BwdArgs bwd_args(fmhip_model_t m, fmhip_dataset_t d, int64_t b) {
+    const BatchMeta &bm = d->batches[(size_t)b];
+    BwdArgs a{};
+    a.crow = d->crow.p + bm.nnz0;
+    a.cval = d->cval.p + bm.nnz0;
+    a.range_seg = d->range_seg.p + bm.range_off;
+    a.cfeat = d->cfeat.p + bm.col_off;
+    a.cptr = d->cptr.p + bm.col_off + b;
+    a.split_seg = d->split_seg.p + bm.split_off;
+    a.nnz = bm.nnz;
+    a.n_ranges = bm.n_ranges;
+    a.n_split = bm.n_split;
+    a.P = m->P.p;
+    a.e = m->e.p;
+    a.GV = m->GV();
+    a.Gw = m->Gw();
+    a.Gb = m->Gb();
+    a.part = m->part.p;
+    return a;
+}
+
+// forward + reduce + backward + fixup of one batch into the packed gradient
+int step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double *acc) {
+    const BatchMeta &bm = d->batches[(size_t)b];
+    TRY(ensure_workspace(m, d));
+    if (m->grad_dirty) {
+        HIP_TRY(hipMemsetAsync(m->grad, 0, m->grad_floats() * sizeof(float), m->stream));
+        m->grad_dirty = false;
+    }
+    {
+        ProfScope ps(m, FMHIP_K_FORWARD, bm.nnz, bm.rows);
+        HIP_TRY(launch_forward(m->Kp, kFwdTrain, fwd_args(m, d, bm), m->stream));
+    }
+    {
+        ProfScope ps(m, FMHIP_K_REDUCE, bm.nnz, bm.rows);
+        HIP_TRY(launch_reduce_e(m->e.p, (int32_t)bm.rows, m->scal(), acc, m->stream));
+    }
+    BwdArgs ba = bwd_args(m, d, b);
+    {
+        ProfScope ps(m, FMHIP_K_BACKWARD, bm.nnz, bm.rows);
+        HIP_TRY(launch_backward(m->Kp, ba, m->stream));
+    }
+    {
+        ProfScope ps(m, FMHIP_K_FIXUP, bm.nnz, bm.rows);
+        HIP_TRY(launch_fixup(m->Kp, ba, m->stream));
+    }
+    m->grad_dirty = true;
+    m->last_nnz = bm.nnz;
+    m->last_rows = bm.rows;
+    return FMHIP_OK;
+}
+
+int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double regv) {
+    ApplyArgs a{};
+    a.V = m->V.p;
+    a.w = m->w.p;
+    a.w0 = m->w0.p;
+    a.GV = m->GV();
+    a.Gw = m->Gw();
+    a.Gb = m->Gb();
+    a.scal = m->scal();
+    a.n1 = m->n1;
+    a.eta = (float)eta;
+    a.reg0 = (float)reg0;
+    a.regw = (float)regw;
+    a.regv = (float)regv;
+    {
+        ProfScope ps(m, FMHIP_K_APPLY, m->last_nnz, m->last_rows);
+        HIP_TRY(launch_apply(m->Kp, a, m->stream));
+    }
+    m->grad_dirty = false;
+    return FMHIP_OK;
+}
+
+int read_scal(fmhip_model_t m, fmhip_stats *st) {
+    float h[4];
+    HIP_TRY(hipMemcpyAsync(h, m->scal(), sizeof h, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    st->sum_e = h[0];
+    st->sse = h[1];
+    st->rows = (int64_t)llround(h[2]);
+    st->nonfinite = (int64_t)llround(h[3]);
+    return FMHIP_OK;
+}
+
+int read_acc(fmhip_model_t m, fmhip_stats *st) {
+    double h[4];
+    HIP_TRY(hipMemcpyAsync(h, m->acc.p, sizeof h, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    st->sum_e = h[0];
+    st->sse = h[1];
+    st->rows = (int64_t)llround(h[2]);
+    st->nonfinite = (int64_t)llround(h[3]);
+    return FMHIP_OK;
+}
+
+template <typename FT>
+int set_params_impl(fmhip_model_t m, FT w0, const FT *w, const FT *v) {
+    if (!m || !w || !v) return fail(FMHIP_ERR_INVALID, "NULL argument");
+    TRY(set_device(m->device));
+    std::vector<float> hV((size_t)m->n1p * m->Kp, 0.f), hw((size_t)m->n1p, 0.f);
+    for (int64_t i = 0; i < m->n1; ++i) {
+        hw[(size_t)i] = (float)w[i];
+        for (int f = 0; f < m->k; ++f) hV[(size_t)i * m->Kp + f] = (float)v[f + i * (int64_t)m->k];
+    }
+    const float hw0 = (float)w0;
+    HIP_TRY(hipMemcpyAsync(m->V.p, hV.data(), hV.size() * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(m->w.p, hw.data(), hw.size() * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(m->w0.p, &hw0, sizeof(float), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return FMHIP_OK;
+}
+
+template <typename FT>
+int get_params_impl(fmhip_model_t m, FT *w0, FT *w, FT *v) {
+    if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
+    TRY(set_device(m->device));
+    std::vector<float> hV((size_t)m->n1p * m->Kp), hw((size_t)m->n1p);
+    float hw0 = 0.f;
+    HIP_TRY(hipMemcpyAsync(hV.data(), m->V.p, hV.size() * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(hw.data(), m->w.p, hw.size() * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(&hw0, m->w0.p, sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (w0) *w0 = (FT)hw0;
+    for (int64_t i = 0; i < m->n1; ++i) {
+        if (w) w[i] = (FT)hw[(size_t)i];
+        if (v)
+            for (int f = 0; f < m->k; ++f) v[f + i * (int64_t)m->k] = (FT)hV[(size_t)i * m->Kp + f];
+    }
+    return FMHIP_OK;
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+
+extern "C" {
+
+int fmhip_version(void) { return FMHIP_VERSION; }
+
+const char *fmhip_last_error(void) { return g_err.c_str(); }
+
+int fmhip_device_count(int *count) {
+    if (!count) return fail(FMHIP_ERR_INVALID, "count is NULL");
+    *count = 0;
+    HIP_TRY(hipGetDeviceCount(count));
+    return FMHIP_OK;
+}
+
+int fmhip_model_create(int device, int64_t num_attribute, int32_t num_factor, void *stream, fmhip_model_t *out) {
+    if (!out) return fail(FMHIP_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (num_attribute < 0 || num_attribute >= ((int64_t)1 << 31) - 8)
+        return fail(FMHIP_ERR_INVALID, "num_attribute %lld out of range", (long long)num_attribute);
+    if (num_factor < 1) return fail(FMHIP_ERR_INVALID, "num_factor must be >= 1");
+    if (num_factor > FMHIP_MAX_FACTORS)
+        return fail(FMHIP_ERR_UNSUPPORTED, "num_factor %d > FMHIP_MAX_FACTORS (%d)", num_factor, FMHIP_MAX_FACTORS);
+    TRY(set_device(device));
+    fmhip_model *m = new (std::nothrow) fmhip_model();
+    if (!m) return fail(FMHIP_ERR_NOMEM, "out of host memory");
+    m->device = device;
+    m->n = num_attribute;
+    m->n1 = num_attribute + 1;
+    m->n1p = (m->n1 + 3) & ~(int64_t)3;
+    m->k = num_factor;
+    m->Kp = padded_factors(num_factor);
+    if (stream) {
+        m->stream = reinterpret_cast<hipStream_t>(stream);
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete m;
+            return fail(FMHIP_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+        }
+        m->own_stream = true;
+    }
+    int rc;
+    if ((rc = m->V.alloc((size_t)m->n1p * m->Kp)) || (rc = m->w.alloc((size_t)m->n1p)) || (rc = m->w0.alloc(1)) ||
+        (rc = m->grad_own.alloc(m->grad_floats())) || (rc = m->acc.alloc(4))) {
+        fmhip_model_destroy(m);
+        return rc;
+    }
+    m->grad = m->grad_own.p;
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipMemsetAsync(m->V.p, 0, m->V.n * sizeof(float), m->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(m->w.p, 0, m->w.n * sizeof(float), m->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(m->w0.p, 0, sizeof(float), m->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(m->grad, 0, m->grad_floats() * sizeof(float), m->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(m->acc.p, 0, 4 * sizeof(double), m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    if (e != hipSuccess) {
+        fmhip_model_destroy(m);
+        return fail(FMHIP_ERR_HIP, "zero-initialisation failed: %s", hipGetErrorString(e));
+    }
+    *out = m;
+    return FMHIP_OK;
+}
+
+int fmhip_model_destroy(fmhip_model_t m) {
+    if (!m) return FMHIP_OK;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    for (auto &r : m->prof) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+    return FMHIP_OK;
+}
+
+int fmhip_model_info(fmhip_model_t m, int64_t *num_attribute, int32_t *num_factor, int32_t *padded) {
+    if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
+    if (num_attribute) *num_attribute = m->n;
+    if (num_factor) *num_factor = m->k;
+    if (padded) *padded = m->Kp;
+    return FMHIP_OK;
+}
+
+int fmhip_model_set_params(fmhip_model_t m, double w0, const double *w, const double *v) { return set_params_impl<double>(m, w0, w, v); }
+int fmhip_model_get_params(fmhip_model_t m, double *w0, double *w, double *v) { return get_params_impl<double>(m, w0, w, v); }
+int fmhip_model_set_params_f32(fmhip_model_t m, float w0, const float *w, const float *v) { return set_params_impl<float>(m, w0, w, v); }
+int fmhip_model_get_params_f32(fmhip_model_t m, float *w0, float *w, float *v) { return get_params_impl<float>(m, w0, w, v); }
+
+int fmhip_synchronize(fmhip_model_t m) {
+    if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
+    TRY(set_device(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return FMHIP_OK;
+}
+
+int fmhip_dataset_create(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const double *val,
+                         const double *y, int64_t batch_rows, fmhip_dataset_t *out) {
+    return dataset_create_impl<double>(device, n_rows, row_ptr, col, val, y, batch_rows, out);
+}
+
+int fmhip_dataset_create_f32(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const float *val,
+                             const float *y, int64_t batch_rows, fmhip_dataset_t *out) {
+    return dataset_create_impl<float>(device, n_rows, row_ptr, col, val, y, batch_rows, out);
+}
+
+int fmhip_dataset_destroy(fmhip_dataset_t d) {
+    if (!d) return FMHIP_OK;
+    (void)hipSetDevice(d->device);
+    delete d;
+    return FMHIP_OK;
+}
+
+int fmhip_dataset_info(fmhip_dataset_t d, int64_t *n_rows, int64_t *nnz, int64_t *dimension, int64_t *batch_rows,
+                       int64_t *n_batches) {
+    if (!d) return fail(FMHIP_ERR_INVALID, "dataset is NULL");
+    if (n_rows) *n_rows = d->n_rows;
+    if (nnz) *nnz = d->nnz;
+    if (dimension) *dimension = d->dimension;
+    if (batch_rows) *batch_rows = d->batch_rows;
+    if (n_batches) *n_batches = (int64_t)d->batches.size();
+    return FMHIP_OK;
+}
+
+int fmhip_dataset_batch_info(fmhip_dataset_t d, int64_t batch, int64_t *row0, int64_t *rows, int64_t *nnz,
+                             int64_t *n_columns) {
+    if (!d) return fail(FMHIP_ERR_INVALID, "dataset is NULL");
+    TRY(check_batch(d, batch));
+    const BatchMeta &bm = d->batches[(size_t)batch];
+    if (row0) *row0 = bm.row0;
+    if (rows) *rows = bm.rows;
+    if (nnz) *nnz = bm.nnz;
+    if (n_columns) *n_columns = bm.n_cols;
+    return FMHIP_OK;
+}
+
+int fmhip_dataset_get_transpose(fmhip_dataset_t d, int64_t batch, int32_t *feat, int32_t *ptr, int32_t *rows,
+                                float *vals) {
+    if (!d) return fail(FMHIP_ERR_INVALID, "dataset is NULL");
+    TRY(check_batch(d, batch));
+    TRY(set_device(d->device));
+    const BatchMeta &bm = d->batches[(size_t)batch];
+    if (feat && bm.n_cols)
+        HIP_TRY(hipMemcpy(feat, d->cfeat.p + bm.col_off, (size_t)bm.n_cols * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (ptr)
+        HIP_TRY(hipMemcpy(ptr, d->cptr.p + bm.col_off + batch, ((size_t)bm.n_cols + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (rows && bm.nnz) {
+        HIP_TRY(hipMemcpy(rows, d->crow.p + bm.nnz0, (size_t)bm.nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int32_t p = 0; p < bm.nnz; ++p) rows[p] &= 0x7fffffff;
+    }
+    if (vals && bm.nnz)
+        HIP_TRY(hipMemcpy(vals, d->cval.p + bm.nnz0, (size_t)bm.nnz * sizeof(float), hipMemcpyDeviceToHost));
+    return FMHIP_OK;
+}
+
+// ---- scoring
+
+static int score_pass(fmhip_model_t m, fmhip_dataset_t d, double *yhat, double *e_out, double *q_out, fmhip_stats *st) {
+    TRY(check_pair(m, d));
+    TRY(ensure_workspace(m, d));
+    HIP_TRY(hipMemsetAsync(m->acc.p, 0, 4 * sizeof(double), m->stream));
+    DevBuf<float> dy;
+    if (yhat) TRY(dy.alloc((size_t)std::max<int64_t>(d->max_rows, 1)));
+    std::vector<float> hbuf;
+    for (size_t b = 0; b < d->batches.size(); ++b) {
+        const BatchMeta &bm = d->batches[b];
+        FwdArgs a = fwd_args(m, d, bm);
+        a.yhat = dy.p;
+        HIP_TRY(launch_forward(m->Kp, q_out ? kFwdQ : kFwdResidual, a, m->stream));
+        HIP_TRY(launch_reduce_e(m->e.p, (int32_t)bm.rows, nullptr, m->acc.p, m->stream));
+        if (yhat || e_out) {
+            hbuf.resize((size_t)bm.rows);
+            if (yhat) {
+                HIP_TRY(hipMemcpyAsync(hbuf.data(), dy.p, (size_t)bm.rows * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+                HIP_TRY(hipStreamSynchronize(m->stream));
+                for (int64_t r = 0; r < bm.rows; ++r) yhat[bm.row0 + r] = hbuf[(size_t)r];
+            }
+            if (e_out) {
+                HIP_TRY(hipMemcpyAsync(hbuf.data(), m->e.p, (size_t)bm.rows * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+                HIP_TRY(hipStreamSynchronize(m->stream));
+                for (int64_t r = 0; r < bm.rows; ++r) e_out[bm.row0 + r] = hbuf[(size_t)r];
+            }
+        }
+        if (q_out) {
+            hbuf.resize((size_t)bm.rows * m->Kp);
+            HIP_TRY(hipMemcpyAsync(hbuf.data(), m->P.p, hbuf.size() * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            for (int64_t r = 0; r < bm.rows; ++r)
+                for (int f = 0; f < m->k; ++f) q_out[(bm.row0 + r) * m->k + f] = hbuf[(size_t)r * m->Kp + f];
+        }
+    }
+    if (st) {
+        memset(st, 0, sizeof *st);
+        TRY(read_acc(m, st));
+        st->nnz = d->nnz;
+    }
+    return FMHIP_OK;
+}
+
+int fmhip_predict(fmhip_model_t m, fmhip_dataset_t d, double *yhat) {
+    if (!yhat) return fail(FMHIP_ERR_INVALID, "yhat is NULL");
+    return score_pass(m, d, yhat, nullptr, nullptr, nullptr);
+}
+
+int fmhip_residual(fmhip_model_t m, fmhip_dataset_t d, double *e) {
+    if (!e) return fail(FMHIP_ERR_INVALID, "e is NULL");
+    return score_pass(m, d, nullptr, e, nullptr, nullptr);
+}
+
+int fmhip_term_q(fmhip_model_t m, fmhip_dataset_t d, double *q) {
+    if (!q) return fail(FMHIP_ERR_INVALID, "q is NULL");
+    return score_pass(m, d, nullptr, nullptr, q, nullptr);
+}
+
+int fmhip_rmse(fmhip_model_t m, fmhip_dataset_t d, double *rmse, fmhip_stats *stats) {
+    if (!rmse) return fail(FMHIP_ERR_INVALID, "rmse is NULL");
+    fmhip_stats st;
+    TRY(score_pass(m, d, nullptr, nullptr, nullptr, &st));
+    // S/Model.scala:13-19: sqrt(sum (y - yhat)^2 / size); (y - yhat)^2 == e^2
+    *rmse = st.rows > 0 ? std::sqrt(st.sse / (double)st.rows) : 0.0;
+    if (stats) *stats = st;
+    return FMHIP_OK;
+}
+
+// ---- training
+
+int fmhip_sgd_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double eta, double reg0, double regw,
+                   double regv, fmhip_stats *stats) {
+    TRY(check_pair(m, d));
+    TRY(check_batch(d, batch));
+    TRY(step_compute(m, d, batch, nullptr));
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        TRY(read_scal(m, stats));
+        stats->nnz = d->batches[(size_t)batch].nnz;
+        stats->steps = 1;
+    }
+    return step_apply(m, eta, reg0, regw, regv);
+}
+
+int fmhip_sgd_epoch(fmhip_model_t m, fmhip_dataset_t d, double eta, double reg0, double regw, double regv,
+                    const int64_t *order, fmhip_stats *stats) {
+    TRY(check_pair(m, d));
+    const int64_t nb = (int64_t)d->batches.size();
+    if (order)
+        for (int64_t j = 0; j < nb; ++j) TRY(check_batch(d, order[j]));
+    HIP_TRY(hipMemsetAsync(m->acc.p, 0, 4 * sizeof(double), m->stream));
+    for (int64_t j = 0; j < nb; ++j) {
+        const int64_t b = order ? order[j] : j;
+        TRY(step_compute(m, d, b, m->acc.p));
+        TRY(step_apply(m, eta, reg0, regw, regv));
+    }
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        TRY(read_acc(m, stats));
+        stats->nnz = d->nnz;
+        stats->steps = nb;
+    }
+    return FMHIP_OK;
+}
+
+int fmhip_batch_grad(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double *gv, double *gw, double *gw0,
+                     fmhip_stats *stats) {
+    TRY(check_pair(m, d));
+    TRY(check_batch(d, batch));
+    TRY(step_compute(m, d, batch, nullptr));
+    std::vector<float> hG(m->grad_floats()), hV((size_t)m->n1p * m->Kp);
+    HIP_TRY(hipMemcpyAsync(hG.data(), m->grad, hG.size() * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(hV.data(), m->V.p, hV.size() * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemsetAsync(m->grad, 0, m->grad_floats() * sizeof(float), m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    m->grad_dirty = false;
+    const float *GV = hG.data(), *Gw = GV + (size_t)m->n1p * m->Kp, *Gb = Gw + m->n1p, *sc = Gb + m->n1p;
+    for (int64_t i = 0; i < m->n1; ++i) {
+        if (gw) gw[i] = Gw[i];
+        if (gv)
+            for (int f = 0; f < m->k; ++f)
+                gv[f + i * (int64_t)m->k] = (double)GV[(size_t)i * m->Kp + f] - (double)hV[(size_t)i * m->Kp + f] * (double)Gb[i];
+    }
+    if (gw0) *gw0 = sc[0];
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->sum_e = sc[0];
+        stats->sse = sc[1];
+        stats->rows = (int64_t)llround(sc[2]);
+        stats->nonfinite = (int64_t)llround(sc[3]);
+        stats->nnz = d->batches[(size_t)batch].nnz;
+    }
+    return FMHIP_OK;
+}
+
+// ---- data-parallel split step
+
+int fmhip_grad_floats(fmhip_model_t m, int64_t *n_floats) {
+    if (!m || !n_floats) return fail(FMHIP_ERR_INVALID, "NULL argument");
+    *n_floats = (int64_t)m->grad_floats();
+    return FMHIP_OK;
+}
+
+int fmhip_grad_bind(fmhip_model_t m, void *device_ptr) {
+    if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
+    if (device_ptr && (reinterpret_cast<uintptr_t>(device_ptr) & 15u))
+        return fail(FMHIP_ERR_INVALID, "gradient buffer must be 16-byte aligned");
+    m->grad = device_ptr ? static_cast<float *>(device_ptr) : m->grad_own.p;
+    m->grad_dirty = false;
+    return FMHIP_OK;
+}
+
+int fmhip_grad_ptr(fmhip_model_t m, void **device_ptr) {
+    if (!m || !device_ptr) return fail(FMHIP_ERR_INVALID, "NULL argument");
+    *device_ptr = m->grad;
+    return FMHIP_OK;
+}
+
+int fmhip_step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t batch) {
+    TRY(check_pair(m, d));
+    TRY(check_batch(d, batch));
+    return step_compute(m, d, batch, nullptr);
+}
+
+int fmhip_step_apply(fmhip_model_t m, double eta, double reg0, double regw, double regv) {
+    if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
+    TRY(set_device(m->device));
+    return step_apply(m, eta, reg0, regw, regv);
+}
+
+int fmhip_step_stats(fmhip_model_t m, fmhip_stats *stats) {
+    if (!m || !stats) return fail(FMHIP_ERR_INVALID, "NULL argument");
+    TRY(set_device(m->device));
+    memset(stats, 0, sizeof *stats);
+    TRY(read_scal(m, stats));
+    stats->nnz = m->last_nnz;
+    stats->steps = 1;
+    return FMHIP_OK;
+}
+
+// ---- measurement
+
+int fmhip_profile_begin(fmhip_model_t m) {
+    if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
+    for (auto &r : m->prof) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    m->prof.clear();
+    m->profiling = true;
+    return FMHIP_OK;
+}
+
+int fmhip_profile_end(fmhip_model_t m, fmhip_profile *p) {
+    if (!m || !p) return fail(FMHIP_ERR_INVALID, "NULL argument");
+    TRY(set_device(m->device));
+    m->profiling = false;
+    memset(p, 0, sizeof *p);
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    for (auto &r : m->prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            p->ms[r.kind] += ms;
+            p->launches[r.kind] += 1;
+            p->nnz[r.kind] += r.nnz;
+            p->rows[r.kind] += r.rows;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    m->prof.clear();
+    return FMHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,174 @@
+"""Model / FMModel — host mirror of S/Model.scala and S/fm/FMModel.scala.
+
+``FMModel`` keeps the reference's public, mutable fields (w0, w, v, reg0, regw, regv) as
+fp64 numpy arrays in the reference's layout — ``v`` is ``(num_factor, num_attribute+1)``
+Fortran-ordered, i.e. breeze's column-major DenseMatrix (S/fm/FMModel.scala:19) — and a
+device-resident fp32 twin behind the C ABI.  Host and device copies are synchronised lazily.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from .dataset import DataSet
+
+
+class Model:
+    """S/Model.scala:9-32."""
+
+    def predict(self, features):
+        raise NotImplementedError
+
+    def computeRMSE(self, dataset):
+        raise NotImplementedError
+
+
+class FMModel(Model):
+    def __init__(self, num_attribute, num_factor, init_mean=0.0, init_stdev=0.01, seed=0, device=0, stream=None):
+        self.num_attribute = int(num_attribute)  # S/fm/FMModel.scala:10
+        self.num_factor = int(num_factor)
+        self.init_mean, self.init_stdev, self.seed = init_mean, init_stdev, seed
+        n1 = self.num_attribute + 1
+        # S/fm/FMModel.scala:17-22: w0 = 0, w = 0, v ~ N(mean, stdev).  The reference ignores `seed`
+        # (quirk Q2: unseeded breeze Gaussian); here the seed IS honoured so runs are reproducible.
+        rng = np.random.Generator(np.random.PCG64(seed))
+        self._w0 = 0.0
+        self._w = np.zeros(n1)
+        self._v = np.asfortranarray(rng.normal(init_mean, init_stdev, size=(n1, self.num_factor)).T)
+        self.k0 = True  # S/fm/FMModel.scala:25-26
+        self.k1 = True
+        self.reg0, self.regw, self.regv = 0.0, 0.0, 10.0  # S/fm/FMModel.scala:29-31 (ALS ridge terms)
+        self.device = int(device)
+        self._stream = stream
+        self._h = None
+        self._host_fresh = True   # host arrays hold the current parameters
+        self._dev_fresh = False   # device holds the current parameters
+
+    # -- parameter access (lazy host<->device sync) --------------------------------------
+    def _pull(self):
+        if not self._host_fresh:
+            w0 = C.c_double()
+            flat = np.empty(self._v.size)
+            _ffi.check(_ffi.load().fmhip_model_get_params(self._h, C.byref(w0), _ffi.ptr(self._w), _ffi.ptr(flat)))
+            self._w0 = w0.value
+            self._v = flat.reshape((self.num_factor, self.num_attribute + 1), order="F")
+            self._host_fresh = True
+
+    @property
+    def w0(self):
+        self._pull()
+        return self._w0
+
+    @w0.setter
+    def w0(self, x):
+        self._pull()
+        self._w0 = float(x)
+        self._dev_fresh = False
+
+    @property
+    def w(self):
+        """Mutating the returned array in place requires a following ``touch()``."""
+        self._pull()
+        return self._w
+
+    @w.setter
+    def w(self, x):
+        self._pull()
+        self._w = np.array(x, np.float64).reshape(self.num_attribute + 1)
+        self._dev_fresh = False
+
+    @property
+    def v(self):
+        self._pull()
+        return self._v
+
+    @v.setter
+    def v(self, x):
+        self._pull()
+        x = np.asarray(x, np.float64)
+        if x.shape != (self.num_factor, self.num_attribute + 1):
+            raise ValueError("v must have shape (num_factor, num_attribute + 1)")
+        self._v = np.asfortranarray(x)
+        self._dev_fresh = False
+
+    def touch(self):
+        """Declare that the host arrays were modified in place."""
+        self._pull()
+        self._dev_fresh = False
+
+    @property
+    def handle(self):
+        """Device model with the current parameters uploaded."""
+        L = _ffi.load()
+        if self._h is None:
+            h = C.c_void_p()
+            _ffi.check(L.fmhip_model_create(self.device, self.num_attribute, self.num_factor, self._stream, C.byref(h)))
+            self._h = h
+        if not self._dev_fresh:
+            flat = np.ascontiguousarray(self._v.reshape(-1, order="F"))
+            _ffi.check(L.fmhip_model_set_params(self._h, self._w0, _ffi.ptr(self._w), _ffi.ptr(flat)))
+            self._dev_fresh = True
+        return self._h
+
+    def _device_updated(self):
+        self._host_fresh = False
+        self._dev_fresh = True
+
+    def close(self):
+        if self._h is not None:
+            self._pull()
+            _ffi.load().fmhip_model_destroy(self._h)
+            self._h = None
+            self._dev_fresh = False
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                _ffi.load().fmhip_model_destroy(self._h)
+        except Exception:
+            pass
+
+    # -- scoring -------------------------------------------------------------------------
+    def predict(self, features):
+        """FMModel.predict (S/fm/FMModel.scala:34-55).  `features` is one sparse row
+        ``(indices, values)`` -> float, or a DataSet -> array (the rdd.mapValues(predict) of
+        S/Model.scala:14)."""
+        if isinstance(features, DataSet):
+            out = np.empty(features.size)
+            _ffi.check(_ffi.load().fmhip_predict(self.handle, features.handle, _ffi.ptr(out)))
+            return out
+        idx, val = features
+        ds = DataSet.from_rows([(0.0, (idx, val))], device=self.device)
+        try:
+            return float(self.predict(ds)[0])
+        finally:
+            ds.unpersist()
+
+    def computeRMSE(self, dataset):
+        """Model.computeRMSE (S/Model.scala:13-19)."""
+        r = C.c_double()
+        _ffi.check(_ffi.load().fmhip_rmse(self.handle, dataset.handle, C.byref(r), None))
+        return r.value
+
+    def residual(self, dataset):
+        """ALS.precomputeTermE (S/fm/lib/ALS.scala:142-144): e = predict - target."""
+        out = np.empty(dataset.size)
+        _ffi.check(_ffi.load().fmhip_residual(self.handle, dataset.handle, _ffi.ptr(out)))
+        return out
+
+    def termQ(self, dataset):
+        """ALS.precomputeTermQ for all factors (S/fm/lib/ALS.scala:146-150): (rows, k)."""
+        out = np.empty((dataset.size, self.num_factor))
+        _ffi.check(_ffi.load().fmhip_term_q(self.handle, dataset.handle, _ffi.ptr(out)))
+        return out
+
+    def batchGradient(self, dataset, batch=0):
+        """sum over the batch of e*h (h: S/fm/lib/ALS.scala:56-58,40,21) -> (gv (k,n1), gw, g0, stats)."""
+        n1 = self.num_attribute + 1
+        gv = np.empty(self.num_factor * n1)
+        gw = np.empty(n1)
+        g0 = C.c_double()
+        st = _ffi.Stats()
+        _ffi.check(_ffi.load().fmhip_batch_grad(self.handle, dataset.handle, batch, _ffi.ptr(gv), _ffi.ptr(gw),
+                                                C.byref(g0), C.byref(st)))
+        return gv.reshape((self.num_factor, n1), order="F"), gw, g0.value, st.as_dict()

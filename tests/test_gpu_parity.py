@@ -1,0 +1,307 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the KATs.
+
+Tolerances (fp32 device arithmetic vs the fp64 oracle on identical inputs):
+  index gathers / transposes : bit-exact
+  yhat, e                    : |d| <= 1e-5 * (1 + sum|terms|)     (TOL_Y)
+  RMSE                       : rel 1e-5
+  one-step gradient          : per feature row, |d| <= 1e-4 * max(|G[i,:]|inf, scale)  (TOL_G)
+  parameters after T <= 20 steps: rel-L2 <= 1e-4 (measured ~1e-6; SURVEY proposed 1e-3)
+"""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import f, kat_arrays, random_problem
+
+pytestmark = pytest.mark.gpu
+
+TOL_Y = 1e-5
+TOL_G = 1e-4
+
+
+@pytest.fixture(scope="module")
+def fmhip():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import sparkfm_amd
+    return sparkfm_amd
+
+
+def make(fmhip, a, batch_rows=0):
+    ds = fmhip.DataSet(a["row_ptr"], a["col"], a["val"], a["y"], batch_rows=batch_rows).cache()
+    fm = fmhip.FMModel(a["n1"] - 1, a["k"])
+    fm.w0, fm.w, fm.v = a["w0"], a["w"], a["v"]
+    return ds, fm
+
+
+def term_scale(a):
+    """1 + sum of |terms| of the forward per row (for the yhat tolerance)."""
+    n_rows = len(a["y"])
+    out = np.ones(n_rows)
+    for r in range(n_rows):
+        s = slice(a["row_ptr"][r], a["row_ptr"][r + 1])
+        idx, x = a["col"][s], a["val"][s]
+        t = np.abs(a["v"][:, idx] * x)
+        out[r] += abs(a["w0"]) + np.abs(a["w"][idx] * x).sum() + 0.5 * ((t.sum(axis=1) ** 2).sum() + (t * t).sum())
+    return out
+
+
+def check_grad(gv, gw, ogv, ogw):
+    scale = max(np.abs(ogv).max(), 1e-6)
+    rowmax = np.maximum(np.abs(ogv).max(axis=0), 1e-3 * scale)
+    assert (np.abs(gv - ogv) <= TOL_G * rowmax[None, :]).all(), float((np.abs(gv - ogv) / rowmax[None, :]).max())
+    np.testing.assert_allclose(gw, ogw, rtol=TOL_G, atol=TOL_G * max(np.abs(ogw).max(), 1e-6))
+
+
+def test_kats_through_the_c_abi(fmhip, kats):
+    for c in kats:
+        a = kat_arrays(c)
+        ds, fm = make(fmhip, a)
+        sc = term_scale(a)
+        yh = fm.predict(ds)
+        assert (np.abs(yh - np.array(f(c["yhat"]))) <= TOL_Y * sc).all()
+        e = fm.residual(ds)
+        assert (np.abs(e - np.array(f(c["e"]))) <= TOL_Y * sc).all()
+        assert fm.computeRMSE(ds) == pytest.approx(math.sqrt(f(c["mse"])), rel=1e-5)
+        np.testing.assert_allclose(fm.termQ(ds), np.array(f(c["q"])), rtol=1e-5, atol=1e-6)
+        gv, gw, g0, st = fm.batchGradient(ds, 0)
+        check_grad(gv, gw, np.array(f(c["grad"]["gV"])), np.array(f(c["grad"]["gw"])))
+        assert g0 == pytest.approx(f(c["grad"]["g0"]), rel=1e-5, abs=1e-6)
+        assert st["sse"] == pytest.approx(f(c["sse"]), rel=1e-5)
+        s = c["sgd"]
+        sgd = fmhip.HipSGD(eta=f(s["eta"]), reg0=f(s["reg0"]), regw=f(s["regw"]), regv=f(s["regv"]))
+        sgd.step(fm, ds, 0)
+        np.testing.assert_allclose(fm.v, np.array(f(s["V"])), rtol=2e-6, atol=2e-7)
+        np.testing.assert_allclose(fm.w, f(s["w"]), rtol=2e-6, atol=2e-7)
+        assert fm.w0 == pytest.approx(f(s["w0"]), rel=2e-6, abs=2e-7)
+        ds.unpersist()
+        fm.close()
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 8, 16, 32, 33, 64, 100, 128])
+def test_forward_and_gradient_vs_oracle(fmhip, k):
+    # 4 ragged batches; empty rows; unsorted indices; a feature (id 0) present in every non-empty row
+    a = random_problem(100 + k, 1000, 257, k, 0, 40, empty_rows=(0, 17, 999))
+    for r in range(1000):
+        s = slice(a["row_ptr"][r], a["row_ptr"][r + 1])
+        if s.stop > s.start and not (a["col"][s] == 0).any():
+            a["col"][s.start] = 0
+    ds, fm = make(fmhip, a, batch_rows=300)
+    assert ds.info() == dict(n_rows=1000, nnz=int(a["row_ptr"][-1]), dimension=int(a["col"].max()), batch_rows=300,
+                             n_batches=4)
+    sc = term_scale(a)
+    yh = fm.predict(ds)
+    oyh = oracle.predict(a["w0"], a["w"], a["v"], a["row_ptr"], a["col"], a["val"])
+    assert (np.abs(yh - oyh) <= TOL_Y * sc).all(), float((np.abs(yh - oyh) / sc).max())
+    for r in (0, 17, 999):
+        assert yh[r] == np.float32(a["w0"])                       # empty row -> w0 exactly (quirk Q6)
+    assert fm.computeRMSE(ds) == pytest.approx(oracle.rmse(a["w0"], a["w"], a["v"], a["row_ptr"], a["col"], a["val"],
+                                                           a["y"]), rel=1e-5)
+    q = fm.termQ(ds)
+    cp, rows, cv = oracle.transpose(a["n1"], a["row_ptr"], a["col"], a["val"])
+    for ff in range(0, k, max(1, k // 3)):
+        np.testing.assert_allclose(q[:, ff], oracle.term_q(a["v"], ff, 1000, cp, rows, cv), rtol=1e-5, atol=1e-5)
+    for b in range(4):
+        r0, r1 = b * 300, min(1000, (b + 1) * 300)
+        gv, gw, g0, st = fm.batchGradient(ds, b)
+        ogv, ogw, og0, osse, oe = oracle.batch_grad(a["w0"], a["w"], a["v"], r0, r1, a["row_ptr"], a["col"], a["val"],
+                                                    a["y"])
+        check_grad(gv, gw, ogv, ogw)
+        assert g0 == pytest.approx(og0, rel=1e-5, abs=1e-4)
+        assert st["sse"] == pytest.approx(osse, rel=1e-5)
+        assert st["rows"] == r1 - r0 and st["nonfinite"] == 0
+    ds.unpersist()
+    fm.close()
+
+
+def test_transpose_is_bit_exact(fmhip):
+    """The device-resident per-batch transposes (S/DataSet.scala:31-38) against the oracle's:
+    feature ids, row ids and values must match exactly (index gathers are bit-exact)."""
+    a = random_problem(5, 700, 90, 4, 0, 25, empty_rows=(5,))
+    a["val"] = a["val"].astype(np.float32).astype(np.float64)       # exactly representable in fp32
+    ds, fm = make(fmhip, a, batch_rows=256)
+    for b in range(3):
+        r0, r1 = b * 256, min(700, (b + 1) * 256)
+        sub = a["row_ptr"][r0:r1 + 1] - a["row_ptr"][r0]
+        sl = slice(a["row_ptr"][r0], a["row_ptr"][r1])
+        cp, rows, cv = oracle.transpose(a["n1"], sub, a["col"][sl], a["val"][sl])
+        feat, ptr, drows, dvals = ds.transposeInput(b)
+        present = np.nonzero(np.diff(cp))[0]
+        np.testing.assert_array_equal(feat, present.astype(np.int32))
+        np.testing.assert_array_equal(ptr, cp[np.r_[present, a["n1"]]].astype(np.int32) if len(present) else [0])
+        np.testing.assert_array_equal(drows, rows)
+        np.testing.assert_array_equal(dvals.astype(np.float64), cv)
+    ds.unpersist()
+    fm.close()
+
+
+def test_single_nonzero_rows_have_exactly_zero_interaction(fmhip):
+    a = random_problem(9, 500, 64, 32, 1, 1)
+    ds, fm = make(fmhip, a)
+    yh = fm.predict(ds).astype(np.float32)
+    w32, x32 = a["w"].astype(np.float32), a["val"].astype(np.float32)
+    lin = np.float32(a["w0"]) + w32[a["col"]] * x32                 # one fp32 product + one add
+    np.testing.assert_array_equal(yh, lin.astype(np.float32))
+    gv, gw, g0, st = fm.batchGradient(ds, 0)
+    assert np.abs(gv).max() <= 1e-6 * np.abs(a["v"]).max()          # h(v) = x*(v x) - x^2 v = 0 (to fp32 rounding)
+    ds.unpersist()
+    fm.close()
+
+
+def test_hot_columns_split_over_many_ranges(fmhip):
+    """Power-law columns: 3 features present in every row (columns of 4000 entries = 63 ranges
+    each) next to a long tail of 1-2 entry columns."""
+    rng = np.random.default_rng(77)
+    n_rows, n1, k = 4000, 3000, 32
+    rows = []
+    for r in range(n_rows):
+        tail = rng.choice(np.arange(3, n1), size=int(rng.integers(0, 4)), replace=False)
+        idx = np.concatenate([rng.permutation(3), tail]).astype(np.int32)
+        rows.append(idx)
+    row_ptr = np.zeros(n_rows + 1, np.int64)
+    row_ptr[1:] = np.cumsum([len(r) for r in rows])
+    col = np.concatenate(rows)
+    val = rng.uniform(0.1, 1.0, len(col))
+    a = dict(k=k, n1=n1, w0=0.3, w=rng.normal(0, 0.1, n1), v=rng.normal(0, 0.1, (k, n1)), row_ptr=row_ptr, col=col,
+             val=val, y=rng.normal(0, 1, n_rows))
+    ds, fm = make(fmhip, a)
+    gv, gw, g0, st = fm.batchGradient(ds, 0)
+    ogv, ogw, og0, osse, _ = oracle.batch_grad(a["w0"], a["w"], a["v"], 0, n_rows, row_ptr, col, val, a["y"], threads=4)
+    check_grad(gv, gw, ogv, ogw)
+    gv2, gw2, _, _ = fm.batchGradient(ds, 0)
+    np.testing.assert_array_equal(gv, gv2)                          # atomics-free: run-to-run identical
+    np.testing.assert_array_equal(gw, gw2)
+    ds.unpersist()
+    fm.close()
+
+
+@pytest.mark.parametrize("k,batch_rows", [(8, 128), (32, 500), (64, 2000)])
+def test_sgd_epochs_track_the_oracle(fmhip, k, batch_rows):
+    a = random_problem(40 + k, 2000, 400, k, 1, 30)
+    rng = np.random.default_rng(1)
+    vt = rng.normal(0, 0.3, (2, 400))                               # learnable targets: a planted FM
+    a["y"] = oracle.predict(0.2, rng.normal(0, 0.3, 400), vt, a["row_ptr"], a["col"], a["val"]) + rng.normal(0, .05, 2000)
+    ds, fm = make(fmhip, a, batch_rows=batch_rows)
+    eta, regs = 0.05, (0.0, 1e-3, 1e-3)
+    sgd = fmhip.HipSGD(eta=eta, reg0=regs[0], regw=regs[1], regv=regs[2])
+    w0, w, v = a["w0"], a["w"], a["v"]
+    losses_gpu, losses_cpu = [], []
+    for _ in range(5):
+        fm = sgd.learn(fm, ds)
+        w0, w, v, sse = oracle.sgd_epoch(w0, w, v, batch_rows, a["row_ptr"], a["col"], a["val"], a["y"], eta, *regs)
+        losses_gpu.append(sgd.last_stats["sse"])
+        losses_cpu.append(sse)
+    assert sgd.last_stats["rows"] == 2000 and sgd.last_stats["steps"] == -(-2000 // batch_rows)
+    np.testing.assert_allclose(losses_gpu, losses_cpu, rtol=1e-5)
+    assert losses_cpu[-1] < losses_cpu[0]
+    assert np.linalg.norm(fm.v - v) <= 1e-4 * np.linalg.norm(v)
+    assert np.linalg.norm(fm.w - w) <= 1e-4 * np.linalg.norm(w)
+    assert fm.w0 == pytest.approx(w0, rel=1e-4, abs=1e-6)
+    ds.unpersist()
+    fm.close()
+
+
+def test_batch_order_and_determinism(fmhip):
+    a = random_problem(61, 1500, 300, 16, 1, 20)
+    outs = []
+    for rep in range(2):
+        ds, fm = make(fmhip, a, batch_rows=400)
+        sgd = fmhip.HipSGD(eta=0.03, regv=1e-3, shuffle_seed=5)
+        for _ in range(3):
+            fm = sgd.learn(fm, ds)
+        outs.append((fm.w0, fm.w.copy(), fm.v.copy()))
+        ds.unpersist()
+        fm.close()
+    assert outs[0][0] == outs[1][0]
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])            # bit-identical run to run
+    np.testing.assert_array_equal(outs[0][2], outs[1][2])
+    # the same permuted schedule on the oracle
+    sgd = fmhip.HipSGD(eta=0.03, regv=1e-3, shuffle_seed=5)
+    w0, w, v = a["w0"], a["w"], a["v"]
+    for _ in range(3):
+        order = sgd.batch_order(4)
+        sgd._epoch += 1
+        w0, w, v, _ = oracle.sgd_epoch(w0, w, v, 400, a["row_ptr"], a["col"], a["val"], a["y"], 0.03, 0, 0, 1e-3,
+                                       order=order)
+    assert np.linalg.norm(outs[0][2] - v) <= 1e-4 * np.linalg.norm(v)
+
+
+def test_split_step_equals_fused_step(fmhip):
+    """fmhip_step_compute + fmhip_step_apply with a caller-owned (torch) gradient buffer ==
+    fmhip_sgd_step; this is the path the data-parallel trainer uses."""
+    import torch
+    from sparkfm_amd.distributed import DataParallelSGD, HipEngine
+    a = random_problem(71, 900, 200, 32, 1, 20)
+    ds, fm = make(fmhip, a, batch_rows=300)
+    ref = fmhip.HipSGD(eta=0.04, regw=1e-3, regv=1e-3)
+    ref.learn(fm, ds)
+    want = (fm.w0, fm.w.copy(), fm.v.copy())
+    fm2 = fmhip.FMModel(a["n1"] - 1, a["k"])
+    fm2.w0, fm2.w, fm2.v = a["w0"], a["w"], a["v"]
+    dp = DataParallelSGD(eta=0.04, regw=1e-3, regv=1e-3)
+    dp.learn(fm2, ds)
+    torch.cuda.synchronize()
+    assert fm2.w0 == want[0]
+    np.testing.assert_array_equal(fm2.w, want[1])
+    np.testing.assert_array_equal(fm2.v, want[2])
+    assert float(dp.engine(fm2, ds).grad.abs().max()) == 0.0         # apply leaves the buffer zeroed
+    ds.unpersist()
+    fm.close()
+    fm2.close()
+
+
+def test_errors_are_reported_not_thrown(fmhip):
+    from sparkfm_amd import _ffi
+    a = random_problem(3, 50, 40, 4, 1, 5)
+    ds = fmhip.DataSet(a["row_ptr"], a["col"], a["val"], a["y"]).cache()
+    small = fmhip.FMModel(10, 4)                                     # fewer slots than the data's max index
+    with pytest.raises(_ffi.FmhipError) as ei:
+        small.computeRMSE(ds)
+    assert ei.value.code == -4 and "num_attribute" in str(ei.value)
+    with pytest.raises(_ffi.FmhipError):
+        fmhip.HipSGD().step(fmhip.FMModel(39, 4), ds, 7)             # batch out of range
+    bad = a["col"].copy()
+    bad[3] = -1
+    with pytest.raises(_ffi.FmhipError):
+        fmhip.DataSet(a["row_ptr"], bad, a["val"], a["y"]).cache()
+    with pytest.raises(_ffi.FmhipError):
+        fmhip.FMModel(10, 1000).handle                               # > FMHIP_MAX_FACTORS
+    ds.unpersist()
+
+
+def test_nonfinite_is_counted_not_masked(fmhip):
+    a = random_problem(4, 64, 30, 8, 2, 6)
+    a["v"][:, 3] = np.inf
+    ds, fm = make(fmhip, a)
+    from sparkfm_amd import _ffi
+    import ctypes as C
+    st = _ffi.Stats()
+    r = C.c_double()
+    _ffi.check(_ffi.load().fmhip_rmse(fm.handle, ds.handle, C.byref(r), C.byref(st)))
+    n_bad = sum(1 for rr in range(64) if (a["col"][a["row_ptr"][rr]:a["row_ptr"][rr + 1]] == 3).any())
+    assert st.nonfinite == n_bad and n_bad > 0
+    ds.unpersist()
+    fm.close()
+
+
+def test_fit_loop_like_the_reference(fmhip):
+    """FM(dataset, numFactor, maxIteration).learnWith(learner) — S/fm/impl/FactorizationMachines.scala:30-51."""
+    from sparkfm_amd import synth
+    d = synth.make_config("C1")                                      # 10k rows, 1k features, k=8 (BASELINE config 1)
+    ds = fmhip.DataSet.from_arrays(d, name="C1", batch_rows=1000)
+    trainer = fmhip.FM(ds, d["k"], maxIteration=6, seed=3)
+    fm = trainer.learnWith(fmhip.HipSGD.run(eta=0.1, regw=1e-4, regv=1e-4))
+    assert fm.num_attribute == ds.dimension and fm.v.shape == (8, ds.dimension + 1)
+    assert len(trainer.rmse_history) == 6
+    assert trainer.rmse_history[-1] < trainer.rmse_history[0]        # it learns
+    # the oracle follows the same trajectory from the same injected start
+    w0, w, v = 0.0, np.zeros(ds.dimension + 1), fmhip.FMModel(ds.dimension, 8, seed=3).v
+    val, y = d["val"].astype(np.float64), d["y"].astype(np.float64)
+    hist = []
+    for _ in range(6):
+        hist.append(oracle.rmse(w0, w, v, d["row_ptr"], d["col"], val, y))
+        w0, w, v, _ = oracle.sgd_epoch(w0, w, v, 1000, d["row_ptr"], d["col"], val, y, 0.1, 0.0, 1e-4, 1e-4, threads=4)
+    np.testing.assert_allclose(trainer.rmse_history, hist, rtol=1e-5)
+    assert np.linalg.norm(fm.v - v) <= 1e-4 * np.linalg.norm(v)

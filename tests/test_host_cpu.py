@@ -1,0 +1,153 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the
+header declares, argument validation that needs no GPU, the host mirrors of the reference
+classes, the synthetic generator, and the build entry point."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from sparkfm_amd import _ffi
+    hdr = open(os.path.join(ROOT, "include", "fmhip.h")).read()
+    declared = set(re.findall(r"\b(fmhip_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_ffi.SYMBOLS)
+    L = _ffi.load()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.fmhip_version() == 100
+    m = re.search(r"#define FMHIP_RANGE_LEN (\d+)", hdr)
+    assert int(m.group(1)) == _ffi.RANGE_LEN
+
+
+def test_argument_validation_without_a_gpu():
+    from sparkfm_amd import _ffi
+    L = _ffi.load()
+    h = C.c_void_p()
+    assert L.fmhip_model_create(0, 10, 4, None, None) == -1
+    assert L.fmhip_model_create(0, -1, 4, None, C.byref(h)) == -1
+    assert L.fmhip_model_create(0, 10, 0, None, C.byref(h)) == -1
+    assert L.fmhip_model_create(0, 10, 10_000, None, C.byref(h)) == -5
+    assert b"FMHIP_MAX_FACTORS" in L.fmhip_last_error()
+    rp = np.array([0, 2, 1], np.int64)
+    assert L.fmhip_dataset_create(0, 2, rp.ctypes.data, None, None, None, 0, C.byref(h)) == -1
+    assert b"row_ptr decreases" in L.fmhip_last_error()
+    assert L.fmhip_model_destroy(None) == 0 and L.fmhip_dataset_destroy(None) == 0
+    assert L.fmhip_predict(None, None, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from sparkfm_amd import _ffi
+    monkeypatch.setattr(_ffi, "_lib", None)
+    monkeypatch.setattr(_ffi, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _ffi.load()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "sparkfm_amd")
+    for dp, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".c", ".cpp")):
+                src = open(os.path.join(dp, fn)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, re.M), fn
+                assert "fm_oracle" not in src, fn
+
+
+def test_dataset_host_mirror():
+    from sparkfm_amd import DataSet
+    rows = [(1.0, ([0, 2, 3], [1.0, 2.0, 0.5])), (-1.0, ([1, 2], [1.0, 1.0])), (2.0, ([0], [3.0])), (0.5, ([], []))]
+    ds = DataSet.apply("toy", rows)
+    assert ds.size == 4 and ds.dimension == 3 and ds.nnz == 6 and not ds.isEmpty
+    assert list(ds.row_ptr) == [0, 3, 5, 6, 6]
+    back = list(ds.rows())
+    assert back[1][0] == -1.0 and list(back[1][1][0]) == [1, 2]
+    assert DataSet.from_rows([]).isEmpty and DataSet.from_rows([]).dimension == 0
+    with pytest.raises(ValueError):
+        DataSet([0, 2], [0], [1.0], [1.0])
+
+
+def test_model_host_layout_matches_breeze_column_major():
+    from sparkfm_amd import FMModel
+    fm = FMModel(5, 3, seed=1)
+    assert fm.w.shape == (6,) and fm.v.shape == (3, 6) and fm.w0 == 0.0
+    assert (fm.reg0, fm.regw, fm.regv) == (0.0, 0.0, 10.0)          # S/fm/FMModel.scala:29-31
+    flat = fm.v.reshape(-1, order="F")
+    assert flat[1 + 4 * 3] == fm.v[1, 4]                             # element (f, i) at f + i*k
+    assert abs(fm.v.std() - 0.01) < 0.01
+    fm2 = FMModel(5, 3, seed=1)
+    np.testing.assert_array_equal(fm.v, fm2.v)
+
+
+def test_batch_order_is_reproducible():
+    from sparkfm_amd import HipSGD
+    a, b = HipSGD(shuffle_seed=3), HipSGD(shuffle_seed=3)
+    assert list(a.batch_order(8)) == list(b.batch_order(8))
+    assert sorted(a.batch_order(8)) == list(range(8))
+    a._epoch = 1
+    assert list(a.batch_order(8)) != list(b.batch_order(8))
+    assert HipSGD().batch_order(8) is None
+
+
+def test_fit_loop_order(monkeypatch):
+    """computeRMSE is called BEFORE each learn (S/fm/impl/FactorizationMachines.scala:42-46)."""
+    import sparkfm_amd
+    from sparkfm_amd import fm as fm_mod
+    calls = []
+
+    class FakeModel:
+        def __init__(self, n, k, **kw):
+            calls.append(("new", n, k))
+
+        def computeRMSE(self, ds):
+            calls.append("rmse")
+            return 1.0
+
+    class FakeDS:
+        dimension, device, name = 7, 0, "x"
+
+        def cache(self):
+            calls.append("cache")
+            return self
+
+        def unpersist(self):
+            calls.append("unpersist")
+
+    class Learner(sparkfm_amd.FMLearn):
+        def learn(self, fm, ds):
+            calls.append("learn")
+            return fm
+
+    monkeypatch.setattr(fm_mod, "FMModel", FakeModel)
+    sparkfm_amd.FM(FakeDS(), 4, maxIteration=2).learnWith(Learner())
+    assert calls == ["cache", ("new", 7, 4), "rmse", "learn", "rmse", "learn", "unpersist"]
+
+
+def test_synth_is_seeded_and_shardable():
+    from sparkfm_amd import synth
+    a = synth.make_zipf(5, 300, 1000, 5, 15, 1.05)
+    b = synth.make_zipf(5, 300, 1000, 5, 15, 1.05)
+    for key in ("row_ptr", "col", "val", "y"):
+        np.testing.assert_array_equal(a[key], b[key])
+    part = synth.make_zipf(5, 100, 1000, 5, 15, 1.05, row_begin=100)
+    lo, hi = a["row_ptr"][100], a["row_ptr"][200]
+    np.testing.assert_array_equal(part["col"], a["col"][lo:hi])
+    np.testing.assert_array_equal(part["y"], a["y"][100:200])
+    nn = np.diff(a["row_ptr"])
+    assert nn.min() >= 5 and nn.max() <= 15
+    for r in range(300):                                            # distinct ids inside a row
+        s = a["col"][a["row_ptr"][r]:a["row_ptr"][r + 1]]
+        assert len(set(s.tolist())) == len(s)
+    assert a["col"].max() < 1000 and (a["val"] > 0).all() and (a["val"] <= 1).all()
+    assert (a["col"] == 0).mean() > (a["col"] == 500).mean()       # Zipf: low ids are hot
+
+
+def test_shard_rows_partition():
+    from sparkfm_amd.distributed import shard_rows
+    cuts = [shard_rows(1003, r, 8) for r in range(8)]
+    assert cuts[0][0] == 0 and cuts[-1][1] == 1003
+    assert all(cuts[i][1] == cuts[i + 1][0] for i in range(7))
