@@ -42,7 +42,13 @@ __device__ __forceinline__ void f4sqacc(float4 &acc, float4 a) {
 }
 // (q*q - s) with the product rounded BEFORE the subtraction (no fma contraction): for a
 // single-nonzero row q = v*x and s = round((v*x)^2), so this is exactly 0 (quirk Q6).
-__device__ __forceinline__ float sq_minus(float q, float s) { return __fsub_rn(__fmul_rn(q, q), s); }
+// (HIP's __fmul_rn/__fsub_rn are plain operators that hipcc would still contract into one fma,
+// hence the explicit contract(off).)
+__device__ __forceinline__ float sq_minus(float q, float s) {
+#pragma clang fp contract(off)
+    const float qq = q * q;
+    return qq - s;
+}
 __device__ __forceinline__ float f4sqminus(float4 q, float4 s) {
     return (sq_minus(q.x, s.x) + sq_minus(q.y, s.y)) + (sq_minus(q.z, s.z) + sq_minus(q.w, s.w));
 }

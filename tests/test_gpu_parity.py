@@ -48,8 +48,10 @@ def term_scale(a):
     return out
 
 
-def check_grad(gv, gw, ogv, ogw):
-    scale = max(np.abs(ogv).max(), 1e-6)
+def check_grad(gv, gw, ogv, ogw, vmax=1.0):
+    # the V gradient is a difference of two sums (sum e*x*q  -  v * sum e*x^2) that can cancel
+    # exactly (single-nonzero rows): the floor is set by the size of the cancelled terms
+    scale = max(np.abs(ogv).max(), np.abs(ogw).max() * vmax, 1e-6)
     rowmax = np.maximum(np.abs(ogv).max(axis=0), 1e-3 * scale)
     assert (np.abs(gv - ogv) <= TOL_G * rowmax[None, :]).all(), float((np.abs(gv - ogv) / rowmax[None, :]).max())
     np.testing.assert_allclose(gw, ogw, rtol=TOL_G, atol=TOL_G * max(np.abs(ogw).max(), 1e-6))
@@ -67,7 +69,7 @@ def test_kats_through_the_c_abi(fmhip, kats):
         assert fm.computeRMSE(ds) == pytest.approx(math.sqrt(f(c["mse"])), rel=1e-5)
         np.testing.assert_allclose(fm.termQ(ds), np.array(f(c["q"])), rtol=1e-5, atol=1e-6)
         gv, gw, g0, st = fm.batchGradient(ds, 0)
-        check_grad(gv, gw, np.array(f(c["grad"]["gV"])), np.array(f(c["grad"]["gw"])))
+        check_grad(gv, gw, np.array(f(c["grad"]["gV"])), np.array(f(c["grad"]["gw"])), np.abs(a["v"]).max())
         assert g0 == pytest.approx(f(c["grad"]["g0"]), rel=1e-5, abs=1e-6)
         assert st["sse"] == pytest.approx(f(c["sse"]), rel=1e-5)
         s = c["sgd"]
@@ -108,7 +110,7 @@ def test_forward_and_gradient_vs_oracle(fmhip, k):
         gv, gw, g0, st = fm.batchGradient(ds, b)
         ogv, ogw, og0, osse, oe = oracle.batch_grad(a["w0"], a["w"], a["v"], r0, r1, a["row_ptr"], a["col"], a["val"],
                                                     a["y"])
-        check_grad(gv, gw, ogv, ogw)
+        check_grad(gv, gw, ogv, ogw, np.abs(a["v"]).max())
         assert g0 == pytest.approx(og0, rel=1e-5, abs=1e-4)
         assert st["sse"] == pytest.approx(osse, rel=1e-5)
         assert st["rows"] == r1 - r0 and st["nonfinite"] == 0
@@ -145,7 +147,7 @@ def test_single_nonzero_rows_have_exactly_zero_interaction(fmhip):
     lin = np.float32(a["w0"]) + w32[a["col"]] * x32                 # one fp32 product + one add
     np.testing.assert_array_equal(yh, lin.astype(np.float32))
     gv, gw, g0, st = fm.batchGradient(ds, 0)
-    assert np.abs(gv).max() <= 1e-6 * np.abs(a["v"]).max()          # h(v) = x*(v x) - x^2 v = 0 (to fp32 rounding)
+    assert np.abs(gv).max() <= 1e-6 * np.abs(a["v"]).max() * np.abs(gw).max()   # h(v) = x*(v x) - x^2 v = 0 (to fp32 rounding)
     ds.unpersist()
     fm.close()
 
@@ -169,7 +171,7 @@ def test_hot_columns_split_over_many_ranges(fmhip):
     ds, fm = make(fmhip, a)
     gv, gw, g0, st = fm.batchGradient(ds, 0)
     ogv, ogw, og0, osse, _ = oracle.batch_grad(a["w0"], a["w"], a["v"], 0, n_rows, row_ptr, col, val, a["y"], threads=4)
-    check_grad(gv, gw, ogv, ogw)
+    check_grad(gv, gw, ogv, ogw, np.abs(a["v"]).max())
     gv2, gw2, _, _ = fm.batchGradient(ds, 0)
     np.testing.assert_array_equal(gv, gv2)                          # atomics-free: run-to-run identical
     np.testing.assert_array_equal(gw, gw2)
@@ -246,7 +248,9 @@ def test_split_step_equals_fused_step(fmhip):
     assert fm2.w0 == want[0]
     np.testing.assert_array_equal(fm2.w, want[1])
     np.testing.assert_array_equal(fm2.v, want[2])
-    assert float(dp.engine(fm2, ds).grad.abs().max()) == 0.0         # apply leaves the buffer zeroed
+    g = dp.engine(fm2, ds).grad
+    assert float(g[:-8].abs().max()) == 0.0                          # apply leaves G_V/G_w/G_b zeroed
+    assert float(g[-6]) == 300.0                                     # scalars keep the last step's {.., rows, ..}
     ds.unpersist()
     fm.close()
     fm2.close()
