@@ -6,11 +6,15 @@
 namespace fmhip {
 
 constexpr int kRangeLen = 64;      // == FMHIP_RANGE_LEN
+constexpr int kExtend = 16;        // a slot finishes a column that ends this close behind its range
 constexpr int kPartPad = 4;        // partial row = Kp floats + {sum e*x, sum e*x^2, pad, pad}
 constexpr int kScalars = 8;        // packed-gradient tail: {sum e, sum e^2, rows, nonfinite, ...}
 
 // padded factor count: 4 * LPN * J with LPN = lanes per row-slot (<= 16), J float4 per lane
 int padded_factors(int k);
+// grid of k_forward for a batch (also the number of per-block statistic partials it writes)
+constexpr int kMaxFwdBlocks = 16384;
+int forward_blocks(int Kp, int64_t n_rows);
 
 enum FwdMode { kFwdTrain = 0, kFwdResidual = 1, kFwdQ = 2 };
 
@@ -27,6 +31,7 @@ struct FwdArgs {
     float *P;     // train: [rows][Kp] = e*q ; q-mode: [rows][Kp] = q
     float *e;     // [rows] e = yhat - y   (residual / train)
     float *yhat;  // optional [rows]
+    double *bsum; // optional [forward_blocks][4] per-block {sum e, sum e^2, nonfinite, 0}
 };
 
 struct BwdArgs {
@@ -59,7 +64,8 @@ hipError_t launch_forward(int Kp, FwdMode mode, const FwdArgs &a, hipStream_t s)
 hipError_t launch_backward(int Kp, const BwdArgs &a, hipStream_t s);
 hipError_t launch_fixup(int Kp, const BwdArgs &a, hipStream_t s);
 hipError_t launch_apply(int Kp, const ApplyArgs &a, hipStream_t s);
-// scal[0..3] = {sum e, sum e^2, n, nonfinite}; acc (optional, 4 doubles) += the same
-hipError_t launch_reduce_e(const float *e, int32_t n, float *scal, double *acc, hipStream_t s);
+// scal[0..3] = {sum e, sum e^2, n_rows, nonfinite} (optional); acc (optional, 4 doubles) += the same
+hipError_t launch_reduce_blocks(const double *bsum, int32_t nblocks, int32_t n_rows, float *scal, double *acc,
+                                hipStream_t s);
 
 }  // namespace fmhip

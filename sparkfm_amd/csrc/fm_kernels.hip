@@ -27,6 +27,15 @@ int padded_factors(int k) {
     return kp;
 }
 
+int forward_blocks(int Kp, int64_t n_rows) {
+    const int lpn = Kp / 4 > 16 ? 16 : Kp / 4;
+    const int slots = 256 / lpn;
+    int64_t blocks = (n_rows + slots - 1) / slots;
+    if (blocks > kMaxFwdBlocks) blocks = kMaxFwdBlocks;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -62,6 +71,7 @@ __global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
     const int l = threadIdx.x & (LPN - 1);
     const int slot = threadIdx.x / LPN;
     const float w0 = *a.w0;
+    float st1 = 0.f, st2 = 0.f, stbad = 0.f;   // this thread's share of {sum e, sum e^2, nonfinite}
     for (int r = blockIdx.x * SLOTS + slot; r < a.n_rows; r += gridDim.x * SLOTS) {
         const int64_t p0 = a.row_ptr[a.row0 + r], p1 = a.row_ptr[a.row0 + r + 1];
         float4 q[J], s[J];
@@ -123,6 +133,30 @@ __global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
         if (l == 0) {
             if (a.e) a.e[r] = e;
             if (a.yhat) a.yhat[r] = yhat;
+            st1 += e;
+            st2 = fmaf(e, e, st2);
+            if (!isfinite(e)) stbad += 1.f;
+        }
+    }
+    // block partial of the residual statistics (fixed order; k_reduce_blocks finishes the sum)
+    if (a.bsum) {
+        __shared__ double sh[3][kBlock / 64];
+        double d1 = st1, d2 = st2, db = stbad;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            d1 += __shfl_xor(d1, m, 64);
+            d2 += __shfl_xor(d2, m, 64);
+            db += __shfl_xor(db, m, 64);
+        }
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { sh[0][wv] = d1; sh[1][wv] = d2; sh[2][wv] = db; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t1 = 0.0, t2 = 0.0, tb = 0.0;
+#pragma unroll
+            for (int i = 0; i < kBlock / 64; ++i) { t1 += sh[0][i]; t2 += sh[1][i]; tb += sh[2][i]; }
+            double *o = a.bsum + (size_t)blockIdx.x * 4;
+            o[0] = t1; o[1] = t2; o[2] = tb; o[3] = 0.0;
         }
     }
 }
@@ -136,17 +170,41 @@ __device__ __forceinline__ void store_row(float *dst, int l, const float4 (&acc)
     if (l == 0) { *dsa = sa; *dsb = sb; }
 }
 
+template <int LPN, int J>
+__device__ __forceinline__ void slots_reduce(float4 (&acc)[J], float &sa, float &sb) {
+#pragma unroll
+    for (int m = 32; m >= LPN; m >>= 1) {
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) {
+            acc[jj].x += __shfl_xor(acc[jj].x, m, 64);
+            acc[jj].y += __shfl_xor(acc[jj].y, m, 64);
+            acc[jj].z += __shfl_xor(acc[jj].z, m, 64);
+            acc[jj].w += __shfl_xor(acc[jj].w, m, 64);
+        }
+        sa += __shfl_xor(sa, m, 64);
+        sb += __shfl_xor(sb, m, 64);
+    }
+}
+
 // One slot walks kRangeLen consecutive entries of the batch's CSC stream.  Column
 // boundaries inside the range are handled serially (flush + reset), so every slot does the
 // same amount of work whatever the column-length skew (power-law features), no atomics are
 // needed and the summation order is fixed.  Outputs per closed column piece:
-//   whole column inside the range            -> G rows directly
+//   whole column inside the slot's walk         -> G rows directly
 //   piece of a column begun in an earlier range -> part[rho][0]  ("head")
 //   last piece, column continues past the range -> part[rho][1]  ("tail")
+// Two rules keep the number of partials (and the fixup pass) small:
+//   extension  a column that starts in range rho and ends within kExtend entries of the next
+//              range is finished by slot rho (slot rho+1 skips those entries): short columns
+//              straddling a range boundary produce no partial at all;
+//   wave sum   when the whole wave's span (64/LPN ranges) lies inside ONE column the slots are
+//              tree-summed in registers and a single partial is written for the wave.
+// k_fixup and the host-side split list (fmhip_api.hip) apply the same two predicates.
 template <int LPN, int J>
 __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
     constexpr int KP = 4 * LPN * J;
     constexpr int SLOTS = kBlock / LPN;
+    constexpr int WS = 64 / LPN;                        // slots (ranges) per wave
     constexpr int PR = KP + kPartPad;
     constexpr int CH = (LPN * J > 16) ? (16 / J) : LPN;  // entries whose P rows are in flight together
     const int l = threadIdx.x & (LPN - 1);
@@ -155,21 +213,41 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
     const int beg = rho * kRangeLen;
     const int end = (beg + kRangeLen < a.nnz) ? beg + kRangeLen : a.nnz;
     int seg = a.range_seg[rho];
-    bool is_head = (a.crow[beg] >> 31) == 0u;
+    const int ca = a.cptr[seg], cb = a.cptr[seg + 1];   // the column open at `beg`
+    const int wbeg = (rho - (int)((threadIdx.x & 63) / LPN)) * kRangeLen;
+    const bool clean = (ca <= wbeg) && (cb >= wbeg + WS * kRangeLen);   // wave-uniform by construction
+    bool is_head = ca < beg;
+    int p0 = beg, stop = end;
+    bool tail_partial = false;
+    if (!clean) {
+        if (is_head && ca >= beg - kRangeLen && cb - beg <= kExtend) {
+            p0 = cb;            // slot rho-1 finishes that column
+            ++seg;
+            is_head = false;
+        }
+        if (end < a.nnz) {
+            const int sn = a.range_seg[rho + 1];
+            const int ca2 = a.cptr[sn], cb2 = a.cptr[sn + 1];   // the column open at `end`
+            if (ca2 < end) {
+                if (ca2 >= beg && cb2 - end <= kExtend) stop = cb2;   // finish it here
+                else tail_partial = true;
+            }
+        }
+    }
     float4 acc[J];
 #pragma unroll
     for (int jj = 0; jj < J; ++jj) acc[jj] = f4zero();
     float sa = 0.f, sb = 0.f;
-    for (int base = beg; base < end; base += LPN) {
+    for (int base = p0; base < stop; base += LPN) {
         const int p = base + l;
         uint32_t rf = 0u;
         float x = 0.f, ee = 0.f;
-        if (p < end) {
+        if (p < stop) {
             rf = a.crow[p];
             x = a.cval[p];
             ee = a.e[rf & 0x7fffffffu];
         }
-        const int cnt = (end - base) < LPN ? (end - base) : LPN;
+        const int cnt = (stop - base) < LPN ? (stop - base) : LPN;
 #pragma unroll
         for (int c0 = 0; c0 < LPN; c0 += CH) {
             float4 pv[CH][J];
@@ -186,7 +264,7 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
                 const float xj = __shfl(x, c0 + j, LPN);
                 const float ej = __shfl(ee, c0 + j, LPN);
                 if (c0 + j < cnt) {
-                    if ((rj[j] >> 31) && (base + c0 + j != beg)) {
+                    if ((rj[j] >> 31) && (base + c0 + j != p0)) {
                         // the open column ends here: flush it
                         if (is_head) {
                             float *pr = a.part + ((size_t)rho * 2) * PR;
@@ -211,11 +289,19 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
             }
         }
     }
-    const bool tail_open = (end < a.nnz) && ((a.crow[end] >> 31) == 0u);
+    if (clean) {
+        slots_reduce<LPN, J>(acc, sa, sb);
+        if (beg == wbeg) {
+            float *pr = a.part + ((size_t)rho * 2 + (ca == wbeg ? 1 : 0)) * PR;
+            store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1);
+        }
+        return;
+    }
+    if (p0 >= stop) return;   // everything in this range belonged to the previous slot
     if (is_head) {
         float *pr = a.part + ((size_t)rho * 2) * PR;
         store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1);
-    } else if (tail_open) {
+    } else if (tail_partial) {
         float *pr = a.part + ((size_t)rho * 2 + 1) * PR;
         store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1);
     } else {
@@ -224,13 +310,17 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
     }
 }
 
-// One wave per column that spans more than one range: column sum = tail(ra) + sum_{ra<rho<=rb} head(rho),
-// taken slot-strided then tree-reduced — a fixed order, so results are run-to-run identical.
+// One wave per column whose entries were cut into several partials.  The column [ca, cb)
+// spans ranges ra..rb; its units are, in order: the ranges before the first wave-aligned
+// range, one wave-sum per wave lying wholly inside the column, the ranges after the last such
+// wave.  Units are taken slot-strided (4 in flight per slot) and tree-summed: a fixed order,
+// so results are run-to-run identical.
 template <int LPN, int J>
 __global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
     constexpr int KP = 4 * LPN * J;
     constexpr int PR = KP + kPartPad;
-    constexpr int WSLOTS = 64 / LPN;
+    constexpr int WS = 64 / LPN;
+    constexpr int WSPAN = WS * kRangeLen;
     const int lane = threadIdx.x & 63;
     const int l = lane & (LPN - 1);
     const int ws = lane / LPN;
@@ -239,31 +329,50 @@ __global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
     const int seg = a.split_seg[idx];
     const int ca = a.cptr[seg], cb = a.cptr[seg + 1];
     const int ra = ca / kRangeLen, rb = (cb - 1) / kRangeLen;
-    const int count = rb - ra + 1;
+    const int w_lo = (ca + WSPAN - 1) / WSPAN, w_hi = cb / WSPAN;   // clean waves [w_lo, w_hi)
+    const int nw = w_hi > w_lo ? w_hi - w_lo : 0;
+    const int nl = nw ? w_lo * WS - ra : rb - ra + 1;               // leading single ranges
+    const int r2 = w_hi * WS;                                       // first trailing range
+    const int count = nw ? nl + nw + (rb - r2 + 1) : nl;
     float4 acc[J];
 #pragma unroll
     for (int jj = 0; jj < J; ++jj) acc[jj] = f4zero();
     float sa = 0.f, sb = 0.f;
-    for (int t = ws; t < count; t += WSLOTS) {
-        const float *pr = a.part + ((size_t)(ra + t) * 2 + (t == 0 ? 1 : 0)) * PR;
+    auto unit_row = [&](int t) -> const float * {
+        const int rho = t < nl ? ra + t : (t < nl + nw ? (w_lo + (t - nl)) * WS : r2 + (t - nl - nw));
+        return a.part + ((size_t)rho * 2 + (ca >= rho * kRangeLen ? 1 : 0)) * PR;
+    };
+    int t = ws;
+    for (; t + 3 * WS < count; t += 4 * WS) {
+        const float *pr[4];
+        float4 v[4][J];
+        float va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pr[u] = unit_row(t + u * WS);
+            const float4 *p4 = reinterpret_cast<const float4 *>(pr[u]) + l;
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) v[u][jj] = p4[jj * LPN];
+            va[u] = pr[u][KP];
+            vb[u] = pr[u][KP + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) f4add(acc[jj], v[u][jj]);
+            sa += va[u];
+            sb += vb[u];
+        }
+    }
+    for (; t < count; t += WS) {
+        const float *pr = unit_row(t);
         const float4 *p4 = reinterpret_cast<const float4 *>(pr) + l;
 #pragma unroll
         for (int jj = 0; jj < J; ++jj) f4add(acc[jj], p4[jj * LPN]);
         sa += pr[KP];
         sb += pr[KP + 1];
     }
-#pragma unroll
-    for (int m = 32; m >= LPN; m >>= 1) {
-#pragma unroll
-        for (int jj = 0; jj < J; ++jj) {
-            acc[jj].x += __shfl_xor(acc[jj].x, m, 64);
-            acc[jj].y += __shfl_xor(acc[jj].y, m, 64);
-            acc[jj].z += __shfl_xor(acc[jj].z, m, 64);
-            acc[jj].w += __shfl_xor(acc[jj].w, m, 64);
-        }
-        sa += __shfl_xor(sa, m, 64);
-        sb += __shfl_xor(sb, m, 64);
-    }
+    slots_reduce<LPN, J>(acc, sa, sb);
     if (ws == 0) {
         const int i = a.cfeat[seg];
         store_row<LPN, J>(a.GV + (size_t)i * KP, l, acc, sa, sb, a.Gw + i, a.Gb + i);
@@ -303,16 +412,18 @@ __global__ __launch_bounds__(kBlock) void k_apply(ApplyArgs a) {
     }
 }
 
-// ------------------------------------------------------------------ reduce e
-// single block, fixed order, fp64 accumulation: {sum e, sum e^2, n, nonfinite}
-__global__ __launch_bounds__(1024) void k_reduce_e(const float *e, int32_t n, float *scal, double *acc) {
-    __shared__ double sh[3][16];
+// ------------------------------------------------------------------ reduce
+// single block, fixed order: sums the forward's per-block partials into
+// scal = {sum e, sum e^2, rows, nonfinite} (fp32, part of the packed gradient) and acc (fp64, +=)
+__global__ __launch_bounds__(kBlock) void k_reduce_blocks(const double *bsum, int32_t nblocks, int32_t n_rows, float *scal,
+                                                         double *acc) {
+    __shared__ double sh[3][kBlock / 64];
     double s1 = 0.0, s2 = 0.0, bad = 0.0;
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        const float v = e[i];
-        if (!isfinite(v)) bad += 1.0;
-        s1 += (double)v;
-        s2 += (double)v * (double)v;
+    for (int i = threadIdx.x; i < nblocks; i += kBlock) {
+        const double *b = bsum + (size_t)i * 4;
+        s1 += b[0];
+        s2 += b[1];
+        bad += b[2];
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -325,18 +436,15 @@ __global__ __launch_bounds__(1024) void k_reduce_e(const float *e, int32_t n, fl
     __syncthreads();
     if (threadIdx.x == 0) {
         double t1 = 0.0, t2 = 0.0, tb = 0.0;
-        for (int i = 0; i < 16; ++i) { t1 += sh[0][i]; t2 += sh[1][i]; tb += sh[2][i]; }
-        if (scal) { scal[0] = (float)t1; scal[1] = (float)t2; scal[2] = (float)n; scal[3] = (float)tb; }
-        if (acc) { acc[0] += t1; acc[1] += t2; acc[2] += (double)n; acc[3] += tb; }
+        for (int i = 0; i < kBlock / 64; ++i) { t1 += sh[0][i]; t2 += sh[1][i]; tb += sh[2][i]; }
+        if (scal) { scal[0] = (float)t1; scal[1] = (float)t2; scal[2] = (float)n_rows; scal[3] = (float)tb; }
+        if (acc) { acc[0] += t1; acc[1] += t2; acc[2] += (double)n_rows; acc[3] += tb; }
     }
 }
 
 template <int LPN, int J>
 hipError_t fwd_dispatch(FwdMode mode, const FwdArgs &a, hipStream_t s) {
-    constexpr int SLOTS = kBlock / LPN;
-    int64_t blocks = ((int64_t)a.n_rows + SLOTS - 1) / SLOTS;
-    if (blocks > 65536) blocks = 65536;
-    if (blocks < 1) return hipSuccess;
+    int64_t blocks = forward_blocks(4 * LPN * J, a.n_rows);
     dim3 g((unsigned)blocks), b(kBlock);
     switch (mode) {
         case kFwdTrain: hipLaunchKernelGGL((k_forward<LPN, J, kFwdTrain>), g, b, 0, s, a); break;
@@ -414,8 +522,9 @@ hipError_t launch_apply(int Kp, const ApplyArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_reduce_e(const float *e, int32_t n, float *scal, double *acc, hipStream_t s) {
-    hipLaunchKernelGGL(k_reduce_e, dim3(1), dim3(1024), 0, s, e, n, scal, acc);
+hipError_t launch_reduce_blocks(const double *bsum, int32_t nblocks, int32_t n_rows, float *scal, double *acc,
+                                hipStream_t s) {
+    hipLaunchKernelGGL(k_reduce_blocks, dim3(1), dim3(kBlock), 0, s, bsum, nblocks, n_rows, scal, acc);
     return hipGetLastError();
 }
 

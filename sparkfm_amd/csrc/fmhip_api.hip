@@ -118,6 +118,7 @@ struct fmhip_model {
     bool grad_dirty = false;      // holds a gradient that has not been applied/zeroed
     DevBuf<float> P, e, part;
     DevBuf<double> acc;           // {sum e, sum e^2, rows, nonfinite}
+    DevBuf<double> bsum;          // k_forward's per-block statistic partials
     int64_t last_nnz = 0, last_rows = 0;
     bool profiling = false;
     std::vector<ProfRec> prof;
@@ -199,8 +200,13 @@ void build_batch(const int64_t *row_ptr, const int32_t *col, const float *val, c
         hb.range_seg[(size_t)rho] = (int32_t)s;
     }
     hb.split_seg.clear();
-    for (size_t c = 0; c < nc; ++c)
-        if (hb.cptr[c] / kRangeLen < (hb.cptr[c + 1] - 1) / kRangeLen) hb.split_seg.push_back((int32_t)c);
+    // columns whose sum is assembled by k_fixup — the same predicates k_backward applies: a
+    // column spanning two ranges whose remainder in the second is <= kExtend is finished by the
+    // first range's slot and needs no fixup
+    for (size_t c = 0; c < nc; ++c) {
+        const int32_t ra = hb.cptr[c] / kRangeLen, rb = (hb.cptr[c + 1] - 1) / kRangeLen;
+        if (rb > ra && !(rb == ra + 1 && hb.cptr[c + 1] - rb * kRangeLen <= kExtend)) hb.split_seg.push_back((int32_t)c);
+    }
 }
 
 template <typename T>
@@ -329,6 +335,7 @@ int ensure_workspace(fmhip_model_t m, fmhip_dataset_t d) {
     TRY(m->P.ensure((size_t)std::max<int64_t>(d->max_rows, 1) * m->Kp));
     TRY(m->e.ensure((size_t)std::max<int64_t>(d->max_rows, 1)));
     TRY(m->part.ensure((size_t)std::max<int32_t>(d->max_ranges, 1) * 2 * (m->Kp + kPartPad)));
+    TRY(m->bsum.ensure((size_t)kMaxFwdBlocks * 4));
     return FMHIP_OK;
 }
 
@@ -346,6 +353,7 @@ FwdArgs fwd_args(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm) {
     a.P = m->P.p;
     a.e = m->e.p;
     a.yhat = nullptr;
+    a.bsum = m->bsum.p;
     return a;
 }
 
@@ -384,7 +392,7 @@ int step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double *acc) {
     }
     {
         ProfScope ps(m, FMHIP_K_REDUCE, bm.nnz, bm.rows);
-        HIP_TRY(launch_reduce_e(m->e.p, (int32_t)bm.rows, m->scal(), acc, m->stream));
+        HIP_TRY(launch_reduce_blocks(m->bsum.p, forward_blocks(m->Kp, bm.rows), (int32_t)bm.rows, m->scal(), acc, m->stream));
     }
     BwdArgs ba = bwd_args(m, d, b);
     {
@@ -653,7 +661,7 @@ static int score_pass(fmhip_model_t m, fmhip_dataset_t d, double *yhat, double *
         FwdArgs a = fwd_args(m, d, bm);
         a.yhat = dy.p;
         HIP_TRY(launch_forward(m->Kp, q_out ? kFwdQ : kFwdResidual, a, m->stream));
-        HIP_TRY(launch_reduce_e(m->e.p, (int32_t)bm.rows, nullptr, m->acc.p, m->stream));
+        HIP_TRY(launch_reduce_blocks(m->bsum.p, forward_blocks(m->Kp, bm.rows), (int32_t)bm.rows, nullptr, m->acc.p, m->stream));
         if (yhat || e_out) {
             hbuf.resize((size_t)bm.rows);
             if (yhat) {

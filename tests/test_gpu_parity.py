@@ -179,6 +179,36 @@ def test_hot_columns_split_over_many_ranges(fmhip):
     fm.close()
 
 
+@pytest.mark.parametrize("k", [4, 16, 32, 64])
+def test_column_lengths_around_the_range_and_wave_boundaries(fmhip, k):
+    """Columns of every length 1..700 (ranges are 64 entries, a slot finishes a column that ends
+    <= 16 entries behind its range, a wave sums 64/LPN ranges when they lie in one column): every
+    combination of direct store / head / tail / wave partial occurs."""
+    rng = np.random.default_rng(5 + k)
+    n_rows, lens = 800, list(range(1, 701, 3)) + [64, 65, 80, 81, 128, 512, 513, 640, 800]
+    rng.shuffle(lens)
+    n1 = len(lens)
+    cols = [np.sort(rng.choice(n_rows, size=ln, replace=False)) for ln in lens]
+    rr = np.concatenate(cols)
+    cc = np.concatenate([np.full(len(c), j, np.int32) for j, c in enumerate(cols)])
+    order = np.lexsort((rng.random(len(rr)), rr))                    # by row, random order inside a row
+    rr, cc = rr[order], cc[order]
+    row_ptr = np.zeros(n_rows + 1, np.int64)
+    np.add.at(row_ptr, rr + 1, 1)
+    row_ptr = np.cumsum(row_ptr)
+    a = dict(k=k, n1=n1, w0=-0.2, w=rng.normal(0, 0.1, n1), v=rng.normal(0, 0.05, (k, n1)), row_ptr=row_ptr,
+             col=cc.astype(np.int32), val=rng.uniform(0.1, 1.0, len(cc)), y=rng.normal(0, 1, n_rows))
+    ds, fm = make(fmhip, a)
+    gv, gw, g0, st = fm.batchGradient(ds, 0)
+    ogv, ogw, og0, osse, _ = oracle.batch_grad(a["w0"], a["w"], a["v"], 0, n_rows, row_ptr, a["col"], a["val"], a["y"],
+                                               threads=4)
+    check_grad(gv, gw, ogv, ogw, np.abs(a["v"]).max())
+    gv2, gw2, _, _ = fm.batchGradient(ds, 0)
+    np.testing.assert_array_equal(gv, gv2)
+    ds.unpersist()
+    fm.close()
+
+
 @pytest.mark.parametrize("k,batch_rows", [(8, 128), (32, 500), (64, 2000)])
 def test_sgd_epochs_track_the_oracle(fmhip, k, batch_rows):
     a = random_problem(40 + k, 2000, 400, k, 1, 30)
