@@ -36,13 +36,26 @@ def alg_bytes(k):
     return {"forward": 4 * k + 12, "backward": 4 * k + 4, "step": 8 * k + 16}
 
 
+def host_cores():
+    """Host cores this job may use: the affinity mask, the cgroup CPU quota, and the GPU box's
+    per-GPU share (16) — whichever is smallest."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(d, k, n1, batch_rows, eta, regs, w0, w, v, budget_s=15.0):
     """fp64 CPU oracle (kind "port"), all host cores, on a bounded sample: the first m
     mini-batches of the same rows with the same schedule; m sized for ~budget_s of CPU work."""
     import oracle
     from oracle import capi
     L = capi.lib()
-    threads = oracle.max_threads()
+    threads = host_cores()
     n_rows = len(d["row_ptr"]) - 1
     nb = -(-n_rows // batch_rows)
     rp = np.ascontiguousarray(d["row_ptr"], np.int64)

@@ -156,29 +156,38 @@ void fmo_term_q(int k, int f, const double *v, int64_t n_rows, int64_t n1,
 }
 
 /* ---- mini-batch gradient ------------------------------------------------ */
+#define FMO_MAX_K_STACK 256
 
 /* per-row forward that also returns q_f = sum_i v_fi x_i (the quantity
  * S/fm/lib/ALS.scala:146-150 calls q) so the gradient h of :56-58 can be formed. */
 static double row_forward_q(int k, double w0, const double *w, const double *v,
                             int64_t nnz, const int32_t *idx, const double *val, double *q) {
+    /* Same arithmetic as fmo_predict_row with the two loops interchanged (nonzeros outer,
+     * factors inner, so the inner loop is contiguous and vectorises).  Every factor's sums
+     * still accumulate over the nonzeros in stored order and the factors are still added to
+     * the result in the order 0..k-1, so the value is bit-identical to fmo_predict_row
+     * (tests/test_oracle_kat.py checks that). */
+    double sq[FMO_MAX_K_STACK];
+    double *s = k <= FMO_MAX_K_STACK ? sq : (double *)malloc((size_t)k * sizeof(double));
     double result = w0;
-    for (int f = 0; f < k; ++f) q[f] = 0.0;
+    for (int f = 0; f < k; ++f) { q[f] = 0.0; s[f] = 0.0; }
     if (nnz > 0) {
         double lin = w[idx[0]] * val[0];
         for (int64_t a = 1; a < nnz; ++a) lin += w[idx[a]] * val[a];
         result += lin;
-        for (int f = 0; f < k; ++f) {
-            double t = v[f + (int64_t)idx[0] * k] * val[0];
-            double sum_f = t, sum_sqr_f = t * t;
-            for (int64_t a = 1; a < nnz; ++a) {
-                t = v[f + (int64_t)idx[a] * k] * val[a];
-                sum_f += t;
-                sum_sqr_f += t * t;
-            }
-            q[f] = sum_f;
-            result += 0.5 * (sum_f * sum_f - sum_sqr_f);
+        {
+            const double *vi = v + (int64_t)idx[0] * k;
+            const double x = val[0];
+            for (int f = 0; f < k; ++f) { double t = vi[f] * x; q[f] = t; s[f] = t * t; }
         }
+        for (int64_t a = 1; a < nnz; ++a) {
+            const double *vi = v + (int64_t)idx[a] * k;
+            const double x = val[a];
+            for (int f = 0; f < k; ++f) { double t = vi[f] * x; q[f] += t; s[f] += t * t; }
+        }
+        for (int f = 0; f < k; ++f) result += 0.5 * (q[f] * q[f] - s[f]);
     }
+    if (s != sq) free(s);
     return result;
 }
 
@@ -283,16 +292,21 @@ static void batch_grad_ws(grad_ws *ws, int k, int64_t n1, double w0, const doubl
     }
     double g0 = 0.0, s2 = 0.0;
     for (int t = 0; t < threads; ++t) { g0 += ws->tg0[t]; s2 += ws->tsse[t]; }
-    for (int t = 1; t < threads; ++t) {
-        double *tv = ws->tgv[t], *tw = ws->tgw[t];
-        for (int64_t j = 0; j < ws->nt[t]; ++j) {
-            int64_t i = ws->tl[t][j];
-            gw[i] += tw[i];
-            tw[i] = 0.0;
-            double *gi = gv + i * k;
-            double *ti = tv + i * k;
-            for (int f = 0; f < k; ++f) { gi[f] += ti[f]; ti[f] = 0.0; }
-            ws->seen[t][i] = 0;
+    /* cross-thread reduction, parallel over features; for every feature the thread buffers
+     * are added in thread order (deterministic), and touched slots are re-zeroed */
+    if (threads > 1) {
+#pragma omp parallel for num_threads(threads) schedule(static)
+        for (int64_t i = 0; i < n1; ++i) {
+            for (int t = 1; t < threads; ++t) {
+                if (!ws->seen[t][i]) continue;
+                double *tv = ws->tgv[t], *tw = ws->tgw[t];
+                gw[i] += tw[i];
+                tw[i] = 0.0;
+                double *gi = gv + i * k;
+                double *ti = tv + i * k;
+                for (int f = 0; f < k; ++f) { gi[f] += ti[f]; ti[f] = 0.0; }
+                ws->seen[t][i] = 0;
+            }
         }
     }
     *gw0 = g0;

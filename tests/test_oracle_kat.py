@@ -138,6 +138,15 @@ def test_c_oracle_vs_numpy_twin_random():
         assert sse == pytest.approx(sse2, rel=1e-10)
 
 
+def test_training_forward_is_bit_identical_to_predict():
+    """The vectorisable loop order of the training path (nonzeros outer) gives the same bits as
+    the reference-order predict (factors outer): e from batch_grad == residual."""
+    a = random_problem(77, 400, 120, 32, 0, 40, empty_rows=(9,))
+    e1 = oracle.residual(a["w0"], a["w"], a["v"], a["row_ptr"], a["col"], a["val"], a["y"])
+    _, _, _, _, e2 = oracle.batch_grad(a["w0"], a["w"], a["v"], 0, 400, a["row_ptr"], a["col"], a["val"], a["y"])
+    np.testing.assert_array_equal(e1, e2)
+
+
 def test_single_nnz_rows_have_zero_interaction():
     a = random_problem(9, 40, 20, 5, 1, 1)
     yh = oracle.predict(a["w0"], a["w"], a["v"], a["row_ptr"], a["col"], a["val"])
