@@ -154,7 +154,8 @@ def main():
     if world > 1:
         dist.barrier()
     if not os.environ.get("FMHIP_BENCH_NO_EVENTS"):
-        _ffi.check(L.fmhip_profile_begin(hm))
+        # one kernel kind per step, rotating: the event records barely perturb the timed region
+        _ffi.check(L.fmhip_profile_begin_rotating(hm))
     sync()
     t0 = time.perf_counter()
     for j in range(args.warmup, args.warmup + args.steps):

@@ -151,7 +151,11 @@ int fmhip_step_apply(fmhip_model_t m, double eta, double reg0, double regw, doub
 int fmhip_step_stats(fmhip_model_t m, fmhip_stats *stats);
 
 /* ---- measurement ------------------------------------------------------------------ */
-int fmhip_profile_begin(fmhip_model_t m);                  /* start recording HIP events per kernel */
+int fmhip_profile_begin(fmhip_model_t m);                  /* start recording HIP events around every kernel */
+/* same, but each SGD step times only ONE kernel kind, rotating forward -> reduce -> backward ->
+ * fixup -> apply from step to step: 2 event records per step instead of 10, so the timed region
+ * is barely perturbed (event records cost ~4 us each on the stream) */
+int fmhip_profile_begin_rotating(fmhip_model_t m);
 int fmhip_profile_end(fmhip_model_t m, fmhip_profile *p);  /* synchronise, sum, stop recording */
 
 #ifdef __cplusplus

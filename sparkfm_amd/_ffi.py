@@ -24,7 +24,7 @@ SYMBOLS = (
     "fmhip_predict", "fmhip_rmse", "fmhip_residual", "fmhip_term_q",
     "fmhip_sgd_step", "fmhip_sgd_epoch", "fmhip_batch_grad",
     "fmhip_grad_floats", "fmhip_grad_bind", "fmhip_grad_ptr", "fmhip_step_compute", "fmhip_step_apply",
-    "fmhip_step_stats", "fmhip_profile_begin", "fmhip_profile_end",
+    "fmhip_step_stats", "fmhip_profile_begin", "fmhip_profile_begin_rotating", "fmhip_profile_end",
 )
 
 
@@ -103,6 +103,7 @@ def load():
     L.fmhip_step_apply.argtypes = [vp, dbl, dbl, dbl, dbl]
     L.fmhip_step_stats.argtypes = [vp, P(Stats)]
     L.fmhip_profile_begin.argtypes = [vp]
+    L.fmhip_profile_begin_rotating.argtypes = [vp]
     L.fmhip_profile_end.argtypes = [vp, P(Profile)]
     for name in SYMBOLS:
         fn = getattr(L, name)

@@ -121,6 +121,8 @@ struct fmhip_model {
     DevBuf<double> bsum;          // k_forward's per-block statistic partials
     int64_t last_nnz = 0, last_rows = 0;
     bool profiling = false;
+    bool prof_rotate = false;     // time one kernel kind per step, rotating
+    int64_t prof_step = 0;
     std::vector<ProfRec> prof;
 
     float *GV() const { return grad; }
@@ -137,6 +139,7 @@ struct ProfScope {
     ProfRec r{};
     bool on;
     ProfScope(fmhip_model *m_, int kind, int64_t nnz, int64_t rows) : m(m_), on(m_->profiling) {
+        if (on && m->prof_rotate && (int)(m->prof_step % FMHIP_K_COUNT) != kind) on = false;
         if (!on) return;
         r.kind = kind;
         r.nnz = nnz;
@@ -428,6 +431,7 @@ int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double reg
         HIP_TRY(launch_apply(m->Kp, a, m->stream));
     }
     m->grad_dirty = false;
+    ++m->prof_step;
     return FMHIP_OK;
 }
 
@@ -838,7 +842,15 @@ int fmhip_profile_begin(fmhip_model_t m) {
     }
     m->prof.clear();
     m->profiling = true;
+    m->prof_rotate = false;
+    m->prof_step = 0;
     return FMHIP_OK;
+}
+
+int fmhip_profile_begin_rotating(fmhip_model_t m) {
+    int rc = fmhip_profile_begin(m);
+    if (rc == FMHIP_OK) m->prof_rotate = true;
+    return rc;
 }
 
 int fmhip_profile_end(fmhip_model_t m, fmhip_profile *p) {
