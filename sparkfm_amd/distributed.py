@@ -28,6 +28,7 @@ class HipEngine:
         n = C.c_int64()
         _ffi.check(self.L.fmhip_grad_floats(fm.handle, C.byref(n)))
         self.grad = torch.zeros(int(n.value), dtype=torch.float32, device="cuda:%d" % fm.device)
+        torch.cuda.synchronize(fm.device)   # the zero-fill must land before the library's stream uses the buffer
         _ffi.check(self.L.fmhip_grad_bind(fm.handle, C.c_void_p(self.grad.data_ptr())))
         self.n_batches = dataset.n_batches
 
@@ -51,20 +52,34 @@ class HipEngine:
         _ffi.check(self.L.fmhip_grad_bind(self.fm.handle, None))
 
 
+_streams = {}
+
+
 def torch_stream_handle(device=0):
-    """hipStream_t of torch's current stream: kernels launched by the library then order
-    naturally with torch.distributed collectives."""
+    """Makes a dedicated torch stream the CURRENT stream of `device` and returns its hipStream_t.
+
+    Kernels the library launches on it then order naturally with torch.distributed collectives
+    (ProcessGroupNCCL waits for, and is waited on by, the current stream) — no host syncs.  A
+    dedicated stream is used because the default stream's handle is NULL, which the C ABI reads
+    as "create your own stream"."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    if device not in _streams:
+        _streams[device] = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(_streams[device])
+    h = _streams[device].cuda_stream
+    assert h != 0
+    return C.c_void_p(h)
 
 
 class DataParallelSGD(FMLearn):
     """FMLearn whose `learn` runs one data-parallel epoch over this rank's row shard."""
 
-    def __init__(self, eta=0.05, reg0=0.0, regw=0.0, regv=0.0, group=None, engine_factory=HipEngine):
+    def __init__(self, eta=0.05, reg0=0.0, regw=0.0, regv=0.0, group=None, engine_factory=HipEngine,
+                 always_reduce=False):
         self.eta, self.reg0, self.regw, self.regv = float(eta), float(reg0), float(regw), float(regv)
         self.group = group
         self.engine_factory = engine_factory
+        self.always_reduce = always_reduce   # run the collective even in a 1-rank group (self-test)
         self._engine = None
         self._key = None
 
@@ -91,7 +106,7 @@ class DataParallelSGD(FMLearn):
             eng.compute(j)
         else:
             eng.compute_empty()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.always_reduce):
             dist.all_reduce(eng.grad, op=dist.ReduceOp.SUM, group=self.group)
         eng.apply(self.eta, self.reg0, self.regw, self.regv)
 
