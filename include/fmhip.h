@@ -76,6 +76,12 @@ typedef struct fmhip_profile {
 int fmhip_version(void);
 const char *fmhip_last_error(void);
 int fmhip_device_count(int *count);
+/* tuning knobs (process-wide; results are identical across variants up to fp32 rounding):
+ *   key 0  forward kernel : 0 = global-memory gathers (default), 20 = LDS V-tile (rows of the hottest,
+ *                           i.e. lowest-id, features staged in LDS; ids must be frequency-ranked to benefit)
+ *   key 1  backward kernel: 1 = pipelined buffer-load walk (default), 0 = plain walk
+ *   key 2  LDS V-tile rows: 0 = auto (as many rows as fit 128 KiB) */
+int fmhip_tune(int key, int value);
 
 /* ---- model: `new FMModel(num_attribute, num_factor)`  S/fm/FMModel.scala:9-22 -- */
 /* Parameters start at zero; the reference's unseeded N(0, 0.01) init (quirk Q2) is the

@@ -15,7 +15,7 @@ RANGE_LEN = 64
 
 # every symbol include/fmhip.h declares (tests check the library exports all of them)
 SYMBOLS = (
-    "fmhip_version", "fmhip_last_error", "fmhip_device_count",
+    "fmhip_version", "fmhip_last_error", "fmhip_device_count", "fmhip_tune",
     "fmhip_model_create", "fmhip_model_destroy", "fmhip_model_info",
     "fmhip_model_set_params", "fmhip_model_get_params", "fmhip_model_set_params_f32", "fmhip_model_get_params_f32",
     "fmhip_synchronize",
@@ -75,6 +75,7 @@ def load():
     L.fmhip_version.restype = C.c_int
     L.fmhip_last_error.restype = C.c_char_p
     L.fmhip_device_count.argtypes = [P(C.c_int)]
+    L.fmhip_tune.argtypes = [C.c_int, C.c_int]
     L.fmhip_model_create.argtypes = [C.c_int, i64, i32, vp, P(vp)]
     L.fmhip_model_destroy.argtypes = [vp]
     L.fmhip_model_info.argtypes = [vp, P(i64), P(i32), P(i32)]

@@ -10,11 +10,17 @@ constexpr int kExtend = 16;        // a slot finishes a column that ends this cl
 constexpr int kPartPad = 4;        // partial row = Kp floats + {sum e*x, sum e*x^2, pad, pad}
 constexpr int kScalars = 8;        // packed-gradient tail: {sum e, sum e^2, rows, nonfinite, ...}
 
+// runtime kernel-variant knobs (diagnostics / A-B benchmarking; fmhip_tune)
+enum { kTuneFwd = 0, kTuneBwd = 1, kTuneTile = 2, kTuneCount = 3 };
+extern int g_tune[kTuneCount];
+
 // padded factor count: 4 * LPN * J with LPN = lanes per row-slot (<= 16), J float4 per lane
 int padded_factors(int k);
 // grid of k_forward for a batch (also the number of per-block statistic partials it writes)
 constexpr int kMaxFwdBlocks = 16384;
 int forward_blocks(int Kp, int64_t n_rows);
+int forward_blocks_lds(int64_t n_rows);
+int forward_blocks_r(int Kp, int64_t n_rows, int rows_per_slot);   // grid of the rolling-prefetch forward   // grid of the LDS V-tile forward
 
 enum FwdMode { kFwdTrain = 0, kFwdResidual = 1, kFwdQ = 2 };
 
@@ -24,6 +30,7 @@ struct FwdArgs {
     const float *val;
     const float *y;
     const float *V;   // [(n+1)][Kp]
+    uint32_t v_bytes; // size of V in bytes, or 0 if it does not fit a 32-bit buffer descriptor
     const float *w;   // [n+1]
     const float *w0;  // [1]
     int64_t row0;
@@ -32,6 +39,7 @@ struct FwdArgs {
     float *e;     // [rows] e = yhat - y   (residual / train)
     float *yhat;  // optional [rows]
     double *bsum; // optional [forward_blocks][4] per-block {sum e, sum e^2, nonfinite, 0}
+    int32_t tile_rows; // LDS V-tile: rows of V (feature ids < tile_rows) staged in LDS; 0 = off
 };
 
 struct BwdArgs {
@@ -45,6 +53,7 @@ struct BwdArgs {
     int32_t n_ranges;
     int32_t n_split;
     const float *P;            // [rows][Kp]
+    uint32_t p_bytes;          // size of P in bytes, or 0 if it does not fit a 32-bit buffer descriptor
     const float *e;            // [rows]
     float *GV;                 // [n1p][Kp]
     float *Gw;                 // [n1p]

@@ -342,6 +342,13 @@ int ensure_workspace(fmhip_model_t m, fmhip_dataset_t d) {
     return FMHIP_OK;
 }
 
+// number of per-block statistic partials the forward launch writes (depends on the variant)
+int fwd_partials(fmhip_model_t m, int64_t rows) {
+    const uint64_t vb = (uint64_t)m->n1p * m->Kp * sizeof(float);
+    if (g_tune[kTuneFwd] == 20 && vb < 0xffffffffull) return forward_blocks_lds(rows);
+    return forward_blocks(m->Kp, rows);
+}
+
 FwdArgs fwd_args(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm) {
     FwdArgs a{};
     a.row_ptr = d->row_ptr.p;
@@ -349,6 +356,10 @@ FwdArgs fwd_args(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm) {
     a.val = d->val.p;
     a.y = d->y.p;
     a.V = m->V.p;
+    {
+        const uint64_t vb = (uint64_t)m->n1p * m->Kp * sizeof(float);
+        a.v_bytes = vb < 0xffffffffull ? (uint32_t)vb : 0u;
+    }
     a.w = m->w.p;
     a.w0 = m->w0.p;
     a.row0 = bm.row0;
@@ -357,6 +368,12 @@ FwdArgs fwd_args(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm) {
     a.e = m->e.p;
     a.yhat = nullptr;
     a.bsum = m->bsum.p;
+    {
+        // LDS V-tile size: as many hot rows as fit 128 KiB (+ their w), capped by the model
+        int64_t t = (128 * 1024) / ((int64_t)m->Kp * 4);
+        if (g_tune[kTuneTile] > 0) t = g_tune[kTuneTile];
+        a.tile_rows = (int32_t)std::min<int64_t>(t, m->n1);
+    }
     return a;
 }
 
@@ -373,6 +390,10 @@ BwdArgs bwd_args(fmhip_model_t m, fmhip_dataset_t d, int64_t b) {
     a.n_ranges = bm.n_ranges;
     a.n_split = bm.n_split;
     a.P = m->P.p;
+    {
+        const uint64_t pb = (uint64_t)bm.rows * m->Kp * sizeof(float);
+        a.p_bytes = pb < 0xffffffffull ? (uint32_t)pb : 0u;
+    }
     a.e = m->e.p;
     a.GV = m->GV();
     a.Gw = m->Gw();
@@ -395,7 +416,7 @@ int step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double *acc) {
     }
     {
         ProfScope ps(m, FMHIP_K_REDUCE, bm.nnz, bm.rows);
-        HIP_TRY(launch_reduce_blocks(m->bsum.p, forward_blocks(m->Kp, bm.rows), (int32_t)bm.rows, m->scal(), acc, m->stream));
+        HIP_TRY(launch_reduce_blocks(m->bsum.p, fwd_partials(m, bm.rows), (int32_t)bm.rows, m->scal(), acc, m->stream));
     }
     BwdArgs ba = bwd_args(m, d, b);
     {
@@ -502,6 +523,12 @@ extern "C" {
 int fmhip_version(void) { return FMHIP_VERSION; }
 
 const char *fmhip_last_error(void) { return g_err.c_str(); }
+
+int fmhip_tune(int key, int value) {
+    if (key < 0 || key >= kTuneCount) return fail(FMHIP_ERR_INVALID, "unknown tuning key %d", key);
+    g_tune[key] = value;
+    return FMHIP_OK;
+}
 
 int fmhip_device_count(int *count) {
     if (!count) return fail(FMHIP_ERR_INVALID, "count is NULL");
@@ -665,7 +692,7 @@ static int score_pass(fmhip_model_t m, fmhip_dataset_t d, double *yhat, double *
         FwdArgs a = fwd_args(m, d, bm);
         a.yhat = dy.p;
         HIP_TRY(launch_forward(m->Kp, q_out ? kFwdQ : kFwdResidual, a, m->stream));
-        HIP_TRY(launch_reduce_blocks(m->bsum.p, forward_blocks(m->Kp, bm.rows), (int32_t)bm.rows, nullptr, m->acc.p, m->stream));
+        HIP_TRY(launch_reduce_blocks(m->bsum.p, fwd_partials(m, bm.rows), (int32_t)bm.rows, nullptr, m->acc.p, m->stream));
         if (yhat || e_out) {
             hbuf.resize((size_t)bm.rows);
             if (yhat) {

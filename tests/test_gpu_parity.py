@@ -118,6 +118,38 @@ def test_forward_and_gradient_vs_oracle(fmhip, k):
     fm.close()
 
 
+@pytest.mark.parametrize("fwd,bwd,tile", [(20, 1, 0), (20, 1, 16), (0, 0, 0)])
+def test_kernel_variants_agree_with_the_oracle(fmhip, fwd, bwd, tile):
+    """fmhip_tune: the LDS V-tile forward (ids < tile rows come from LDS, the rest from global
+    memory) and the plain backward walk give the same results as the default kernels."""
+    from sparkfm_amd import _ffi
+    L = _ffi.load()
+    try:
+        L.fmhip_tune(0, fwd), L.fmhip_tune(1, bwd), L.fmhip_tune(2, tile)
+        for k in (8, 32, 64, 128):
+            a = random_problem(300 + k, 700, 300, k, 0, 30, empty_rows=(1, 699))
+            ds, fm = make(fmhip, a, batch_rows=256)
+            sc = term_scale(a)
+            yh = fm.predict(ds)
+            oyh = oracle.predict(a["w0"], a["w"], a["v"], a["row_ptr"], a["col"], a["val"])
+            assert (np.abs(yh - oyh) <= TOL_Y * sc).all()
+            gv, gw, g0, st = fm.batchGradient(ds, 1)
+            ogv, ogw, og0, osse, _ = oracle.batch_grad(a["w0"], a["w"], a["v"], 256, 512, a["row_ptr"], a["col"],
+                                                       a["val"], a["y"])
+            check_grad(gv, gw, ogv, ogw, np.abs(a["v"]).max())
+            assert st["sse"] == pytest.approx(osse, rel=1e-5)
+            sgd = fmhip.HipSGD(eta=0.03, regv=1e-3)
+            sgd.learn(fm, ds)
+            w0, w, v, sse = oracle.sgd_epoch(a["w0"], a["w"], a["v"], 256, a["row_ptr"], a["col"], a["val"], a["y"],
+                                             0.03, 0.0, 0.0, 1e-3)
+            assert np.linalg.norm(fm.v - v) <= 1e-5 * np.linalg.norm(v)
+            assert sgd.last_stats["sse"] == pytest.approx(sse, rel=1e-5)
+            ds.unpersist()
+            fm.close()
+    finally:
+        L.fmhip_tune(0, 0), L.fmhip_tune(1, 1), L.fmhip_tune(2, 0)
+
+
 def test_transpose_is_bit_exact(fmhip):
     """The device-resident per-batch transposes (S/DataSet.scala:31-38) against the oracle's:
     feature ids, row ids and values must match exactly (index gathers are bit-exact)."""
