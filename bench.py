@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the config's row count, capped at 1.25M)")
-    ap.add_argument("--batch-rows", type=int, default=131072, help="mini-batch rows per GPU")
+    ap.add_argument("--batch-rows", type=int, default=250000, help="mini-batch rows per GPU")
     ap.add_argument("--eta", type=float, default=0.02)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dp", action="store_true",

@@ -63,7 +63,8 @@ typedef struct fmhip_stats {
     int64_t steps;     /* mini-batch steps taken */
 } fmhip_stats;
 
-/* per-kernel device time, HIP events on the model's stream (fmhip_profile_*) */
+/* per-kernel device time, HIP events on the model's stream (fmhip_profile_*).  FMHIP_K_REDUCE is
+ * kept for ABI stability: the statistics reduction now runs inside the fixup launch. */
 enum { FMHIP_K_FORWARD = 0, FMHIP_K_REDUCE = 1, FMHIP_K_BACKWARD = 2, FMHIP_K_FIXUP = 3, FMHIP_K_APPLY = 4, FMHIP_K_COUNT = 5 };
 typedef struct fmhip_profile {
     double ms[FMHIP_K_COUNT];        /* summed elapsed per kernel kind */
@@ -158,8 +159,8 @@ int fmhip_step_stats(fmhip_model_t m, fmhip_stats *stats);
 
 /* ---- measurement ------------------------------------------------------------------ */
 int fmhip_profile_begin(fmhip_model_t m);                  /* start recording HIP events around every kernel */
-/* same, but each SGD step times only ONE kernel kind, rotating forward -> reduce -> backward ->
- * fixup -> apply from step to step: 2 event records per step instead of 10, so the timed region
+/* same, but each SGD step times only ONE kernel kind, rotating forward -> backward -> fixup ->
+ * apply from step to step: 2 event records per step instead of 8, so the timed region
  * is barely perturbed (event records cost ~4 us each on the stream) */
 int fmhip_profile_begin_rotating(fmhip_model_t m);
 int fmhip_profile_end(fmhip_model_t m, fmhip_profile *p);  /* synchronise, sum, stop recording */

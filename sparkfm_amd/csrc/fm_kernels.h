@@ -59,6 +59,11 @@ struct BwdArgs {
     float *Gw;                 // [n1p]
     float *Gb;                 // [n1p]
     float *part;               // [n_ranges][2][Kp + kPartPad]
+    // optional: k_fixup's extra last block also sums the forward's per-block statistics
+    const double *red_bsum;
+    int32_t red_nblocks, red_rows;
+    float *red_scal;
+    double *red_acc;
 };
 
 struct ApplyArgs {

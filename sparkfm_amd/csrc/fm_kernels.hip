@@ -301,6 +301,41 @@ __global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ reduce
+// one block, fixed order: sums the forward's per-block partials into
+// scal = {sum e, sum e^2, rows, nonfinite} (fp32, part of the packed gradient) and acc (fp64, +=)
+__device__ __forceinline__ void reduce_blocks_body(const double *bsum, int32_t nblocks, int32_t n_rows, float *scal,
+                                                   double *acc, double (*sh)[kBlock / 64]) {
+    double s1 = 0.0, s2 = 0.0, bad = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += kBlock) {
+        const double4 b = reinterpret_cast<const double4 *>(bsum)[i];
+        s1 += b.x;
+        s2 += b.y;
+        bad += b.z;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        s1 += __shfl_xor(s1, m, 64);
+        s2 += __shfl_xor(s2, m, 64);
+        bad += __shfl_xor(bad, m, 64);
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][wv] = s1; sh[1][wv] = s2; sh[2][wv] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t1 = 0.0, t2 = 0.0, tb = 0.0;
+        for (int i = 0; i < kBlock / 64; ++i) { t1 += sh[0][i]; t2 += sh[1][i]; tb += sh[2][i]; }
+        if (scal) { scal[0] = (float)t1; scal[1] = (float)t2; scal[2] = (float)n_rows; scal[3] = (float)tb; }
+        if (acc) { acc[0] += t1; acc[1] += t2; acc[2] += (double)n_rows; acc[3] += tb; }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_reduce_blocks(const double *bsum, int32_t nblocks, int32_t n_rows, float *scal,
+                                                         double *acc) {
+    __shared__ double sh[3][kBlock / 64];
+    reduce_blocks_body(bsum, nblocks, n_rows, scal, acc, sh);
+}
+
 // ------------------------------------------------------------------ backward
 template <int LPN, int J>
 __device__ __forceinline__ void store_row(float *dst, int l, const float4 (&acc)[J], float sa, float sb, float *dsa, float *dsb) {
@@ -620,6 +655,12 @@ __global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int l = lane & (LPN - 1);
     const int ws = lane / LPN;
+    if (a.red_bsum && blockIdx.x == gridDim.x - 1) {
+        // the extra last block finishes the residual statistics of this step (saves a launch)
+        __shared__ double sh[3][kBlock / 64];
+        reduce_blocks_body(a.red_bsum, a.red_nblocks, a.red_rows, a.red_scal, a.red_acc, sh);
+        return;
+    }
     const int idx = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (idx >= a.n_split) return;
     const int seg = a.split_seg[idx];
@@ -708,36 +749,6 @@ __global__ __launch_bounds__(kBlock) void k_apply(ApplyArgs a) {
     }
 }
 
-// ------------------------------------------------------------------ reduce
-// single block, fixed order: sums the forward's per-block partials into
-// scal = {sum e, sum e^2, rows, nonfinite} (fp32, part of the packed gradient) and acc (fp64, +=)
-__global__ __launch_bounds__(kBlock) void k_reduce_blocks(const double *bsum, int32_t nblocks, int32_t n_rows, float *scal,
-                                                         double *acc) {
-    __shared__ double sh[3][kBlock / 64];
-    double s1 = 0.0, s2 = 0.0, bad = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += kBlock) {
-        const double *b = bsum + (size_t)i * 4;
-        s1 += b[0];
-        s2 += b[1];
-        bad += b[2];
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        s1 += __shfl_xor(s1, m, 64);
-        s2 += __shfl_xor(s2, m, 64);
-        bad += __shfl_xor(bad, m, 64);
-    }
-    const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { sh[0][wv] = s1; sh[1][wv] = s2; sh[2][wv] = bad; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t1 = 0.0, t2 = 0.0, tb = 0.0;
-        for (int i = 0; i < kBlock / 64; ++i) { t1 += sh[0][i]; t2 += sh[1][i]; tb += sh[2][i]; }
-        if (scal) { scal[0] = (float)t1; scal[1] = (float)t2; scal[2] = (float)n_rows; scal[3] = (float)tb; }
-        if (acc) { acc[0] += t1; acc[1] += t2; acc[2] += (double)n_rows; acc[3] += tb; }
-    }
-}
-
 template <int LPN, int J>
 hipError_t fwd_dispatch(FwdMode mode, const FwdArgs &a, hipStream_t s) {
     int64_t blocks = forward_blocks(4 * LPN * J, a.n_rows);
@@ -784,8 +795,9 @@ hipError_t bwd_dispatch(const BwdArgs &a, hipStream_t s) {
 
 template <int LPN, int J>
 hipError_t fix_dispatch(const BwdArgs &a, hipStream_t s) {
-    if (a.n_split < 1) return hipSuccess;
-    dim3 g((unsigned)((a.n_split + 3) / 4)), b(kBlock);
+    const int extra = a.red_bsum ? 1 : 0;
+    if (a.n_split < 1 && !extra) return hipSuccess;
+    dim3 g((unsigned)((a.n_split + 3) / 4 + extra)), b(kBlock);
     hipLaunchKernelGGL((k_fixup<LPN, J>), g, b, 0, s, a);
     return hipGetLastError();
 }

@@ -1,7 +1,7 @@
 // fmhip_api.hip — host side of libfmhip.so: the C ABI declared in include/fmhip.h.
 //
 // Owns device memory, the per-batch transposes and the launch sequence of one mini-batch
-// SGD step:   k_forward -> k_reduce_e -> k_backward -> k_fixup -> [host all-reduce] -> k_apply
+// SGD step:   k_forward -> k_backward -> k_fixup (+ statistics) -> [host all-reduce] -> k_apply
 // Everything here is plumbing; the arithmetic lives in fm_kernels.hip.
 #include "../../include/fmhip.h"
 #include "fm_kernels.h"
@@ -139,7 +139,10 @@ struct ProfScope {
     ProfRec r{};
     bool on;
     ProfScope(fmhip_model *m_, int kind, int64_t nnz, int64_t rows) : m(m_), on(m_->profiling) {
-        if (on && m->prof_rotate && (int)(m->prof_step % FMHIP_K_COUNT) != kind) on = false;
+        if (on && m->prof_rotate) {
+            static const int live[4] = {FMHIP_K_FORWARD, FMHIP_K_BACKWARD, FMHIP_K_FIXUP, FMHIP_K_APPLY};
+            if (live[m->prof_step % 4] != kind) on = false;
+        }
         if (!on) return;
         r.kind = kind;
         r.nnz = nnz;
@@ -414,11 +417,13 @@ int step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double *acc) {
         ProfScope ps(m, FMHIP_K_FORWARD, bm.nnz, bm.rows);
         HIP_TRY(launch_forward(m->Kp, kFwdTrain, fwd_args(m, d, bm), m->stream));
     }
-    {
-        ProfScope ps(m, FMHIP_K_REDUCE, bm.nnz, bm.rows);
-        HIP_TRY(launch_reduce_blocks(m->bsum.p, fwd_partials(m, bm.rows), (int32_t)bm.rows, m->scal(), acc, m->stream));
-    }
     BwdArgs ba = bwd_args(m, d, b);
+    // the residual statistics {sum e, sum e^2, rows, nonfinite} are finished by k_fixup's extra block
+    ba.red_bsum = m->bsum.p;
+    ba.red_nblocks = fwd_partials(m, bm.rows);
+    ba.red_rows = (int32_t)bm.rows;
+    ba.red_scal = m->scal();
+    ba.red_acc = acc;
     {
         ProfScope ps(m, FMHIP_K_BACKWARD, bm.nnz, bm.rows);
         HIP_TRY(launch_backward(m->Kp, ba, m->stream));
