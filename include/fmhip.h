@@ -152,6 +152,19 @@ int fmhip_grad_floats(fmhip_model_t m, int64_t *n_floats);
 int fmhip_grad_bind(fmhip_model_t m, void *device_ptr);
 int fmhip_grad_ptr(fmhip_model_t m, void **device_ptr);
 int fmhip_step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t batch);
+/* The same work in pieces, so the host can overlap the all-reduce with the backward:
+ *   fmhip_step_forward                       forward of the batch
+ *   fmhip_step_backward(.., lo, hi, finish)  gradient rows of the features lo <= id < hi; call it for
+ *                                            disjoint intervals covering [0, n+1) in DESCENDING order
+ *                                            (the cold, high-id features first: most of the gradient
+ *                                            volume, least of the work), finish = 1 on the last one
+ * After a call returns, floats [lo*row_floats, hi*row_floats) of the packed buffer are final and can
+ * be all-reduced while the next interval computes; floats [gv_floats, end) (G_w | G_b | scalars) are
+ * final after the call with finish = 1. */
+int fmhip_step_forward(fmhip_model_t m, fmhip_dataset_t d, int64_t batch);
+int fmhip_step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, int64_t feat_lo, int64_t feat_hi,
+                        int finish);
+int fmhip_grad_layout(fmhip_model_t m, int64_t *row_floats, int64_t *gv_floats);
 /* applies the packed gradient (after the host's all-reduce, if any), then zeroes it */
 int fmhip_step_apply(fmhip_model_t m, double eta, double reg0, double regw, double regv);
 /* scalars of the packed gradient as last computed/all-reduced (synchronises) */

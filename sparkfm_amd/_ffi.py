@@ -23,7 +23,8 @@ SYMBOLS = (
     "fmhip_dataset_batch_info", "fmhip_dataset_get_transpose",
     "fmhip_predict", "fmhip_rmse", "fmhip_residual", "fmhip_term_q",
     "fmhip_sgd_step", "fmhip_sgd_epoch", "fmhip_batch_grad",
-    "fmhip_grad_floats", "fmhip_grad_bind", "fmhip_grad_ptr", "fmhip_step_compute", "fmhip_step_apply",
+    "fmhip_grad_floats", "fmhip_grad_bind", "fmhip_grad_ptr", "fmhip_grad_layout", "fmhip_step_compute",
+    "fmhip_step_forward", "fmhip_step_backward", "fmhip_step_apply",
     "fmhip_step_stats", "fmhip_profile_begin", "fmhip_profile_begin_rotating", "fmhip_profile_end",
 )
 
@@ -101,6 +102,9 @@ def load():
     L.fmhip_grad_bind.argtypes = [vp, vp]
     L.fmhip_grad_ptr.argtypes = [vp, P(vp)]
     L.fmhip_step_compute.argtypes = [vp, vp, i64]
+    L.fmhip_step_forward.argtypes = [vp, vp, i64]
+    L.fmhip_step_backward.argtypes = [vp, vp, i64, i64, i64, C.c_int]
+    L.fmhip_grad_layout.argtypes = [vp, P(i64), P(i64)]
     L.fmhip_step_apply.argtypes = [vp, dbl, dbl, dbl, dbl]
     L.fmhip_step_stats.argtypes = [vp, P(Stats)]
     L.fmhip_profile_begin.argtypes = [vp]

@@ -51,6 +51,7 @@ struct BwdArgs {
     const int32_t *split_seg;  // [n_split] compressed columns that span >1 range
     int32_t nnz;
     int32_t n_ranges;
+    int32_t rho_lo, rho_hi;    // ranges this launch walks (whole batch: 0, n_ranges)
     int32_t n_split;
     const float *P;            // [rows][Kp]
     uint32_t p_bytes;          // size of P in bytes, or 0 if it does not fit a 32-bit buffer descriptor

@@ -345,6 +345,15 @@ __device__ __forceinline__ void store_row(float *dst, int l, const float4 (&acc)
     if (l == 0) { *dsa = sa; *dsb = sb; }
 }
 
+// sa += e*x (-> G_w, h(w_i) = x); sb += e*x^2 (-> G_b, the -x^2*v term of h(v)).  Written with
+// explicit fma's so that every code path (plain-chunk fast path, flush path, both kernels) rounds
+// identically whatever the compiler's contraction choices: results do not depend on which path a
+// wave happened to take.
+__device__ __forceinline__ void accum_scalars(float &sa, float &sb, float e, float x) {
+    sa = fmaf(e, x, sa);
+    sb = fmaf(__fmul_rn(e, x), x, sb);
+}
+
 template <int LPN, int J>
 __device__ __forceinline__ void slots_reduce(float4 (&acc)[J], float &sa, float &sb) {
 #pragma unroll
@@ -383,8 +392,10 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
     constexpr int PR = KP + kPartPad;
     constexpr int CH = (LPN * J > 16) ? (16 / J) : LPN;  // entries whose P rows are in flight together
     const int l = threadIdx.x & (LPN - 1);
-    const int rho = blockIdx.x * SLOTS + threadIdx.x / LPN;
-    if (rho >= a.n_ranges) return;
+    // a launch may cover only the ranges [rho_lo, rho_hi) (feature-chunked backward); block
+    // numbering stays aligned to the global range numbering so the wave-sum predicate is unchanged
+    const int rho = (a.rho_lo / SLOTS + blockIdx.x) * SLOTS + threadIdx.x / LPN;
+    if (rho < a.rho_lo || rho >= a.rho_hi) return;
     const int beg = rho * kRangeLen;
     const int end = (beg + kRangeLen < a.nnz) ? beg + kRangeLen : a.nnz;
     int seg = a.range_seg[rho];
@@ -457,9 +468,7 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
                     }
 #pragma unroll
                     for (int jj = 0; jj < J; ++jj) f4fma(acc[jj], pv[j][jj], xj);  // sum x * (e*q)
-                    const float ex = ej * xj;
-                    sa += ex;                 // sum e*x      -> G_w   (h(w_i) = x)
-                    sb = fmaf(ex, xj, sb);    // sum e*x^2    -> G_b   (the -x^2*v term of h(v))
+                    accum_scalars(sa, sb, ej, xj);
                 }
             }
         }
@@ -499,8 +508,10 @@ __global__ __launch_bounds__(kBlock) void k_backward_p(BwdArgs a) {
     constexpr int CHB = (LPN * J > 8) ? ((8 / J) > 0 ? (8 / J) : 1) : LPN;   // entries per gather chunk
     constexpr int NCH = SG * LPN / CHB;                                       // chunks per super-group
     const int l = threadIdx.x & (LPN - 1);
-    const int rho = blockIdx.x * SLOTS + threadIdx.x / LPN;
-    if (rho >= a.n_ranges) return;
+    // a launch may cover only the ranges [rho_lo, rho_hi) (feature-chunked backward); block
+    // numbering stays aligned to the global range numbering so the wave-sum predicate is unchanged
+    const int rho = (a.rho_lo / SLOTS + blockIdx.x) * SLOTS + threadIdx.x / LPN;
+    if (rho < a.rho_lo || rho >= a.rho_hi) return;
     const __amdgpu_buffer_rsrc_t prs = make_rsrc(a.P, a.p_bytes);
     const int beg = rho * kRangeLen;
     const int end = (beg + kRangeLen < a.nnz) ? beg + kRangeLen : a.nnz;
@@ -583,9 +594,7 @@ __global__ __launch_bounds__(kBlock) void k_backward_p(BwdArgs a) {
                     const float ej = __shfl(ee[g], jl, LPN);
 #pragma unroll
                     for (int jj = 0; jj < J; ++jj) f4fma(acc[jj], pv[buf][j][jj], xj);
-                    const float ex = ej * xj;
-                    sa += ex;
-                    sb = fmaf(ex, xj, sb);
+                    accum_scalars(sa, sb, ej, xj);
                 }
                 continue;
             }
@@ -613,9 +622,7 @@ __global__ __launch_bounds__(kBlock) void k_backward_p(BwdArgs a) {
                     }
 #pragma unroll
                     for (int jj = 0; jj < J; ++jj) f4fma(acc[jj], pv[buf][j][jj], xj);
-                    const float ex = ej * xj;
-                    sa += ex;
-                    sb = fmaf(ex, xj, sb);
+                    accum_scalars(sa, sb, ej, xj);
                 }
             }
         }
@@ -785,8 +792,9 @@ hipError_t fwd_dispatch(FwdMode mode, const FwdArgs &a, hipStream_t s) {
 template <int LPN, int J>
 hipError_t bwd_dispatch(const BwdArgs &a, hipStream_t s) {
     constexpr int SLOTS = kBlock / LPN;
-    if (a.n_ranges < 1) return hipSuccess;
-    dim3 g((unsigned)((a.n_ranges + SLOTS - 1) / SLOTS)), b(kBlock);
+    if (a.rho_hi <= a.rho_lo) return hipSuccess;
+    const int first_block = a.rho_lo / SLOTS, last_block = (a.rho_hi - 1) / SLOTS;
+    dim3 g((unsigned)(last_block - first_block + 1)), b(kBlock);
     // the pipelined kernel needs P to fit a 32-bit buffer view (< 4 GiB per batch)
     if (a.p_bytes && g_tune[kTuneBwd] == 1) hipLaunchKernelGGL((k_backward_p<LPN, J>), g, b, 0, s, a);
     else hipLaunchKernelGGL((k_backward<LPN, J>), g, b, 0, s, a);

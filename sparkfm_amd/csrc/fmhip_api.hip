@@ -104,6 +104,7 @@ struct fmhip_dataset {
     DevBuf<uint32_t> crow;
     DevBuf<float> cval;
     DevBuf<int32_t> cfeat, cptr, range_seg, split_seg;
+    std::vector<int32_t> h_cfeat, h_cptr, h_split;   // host copies (feature-chunked backward needs them)
 };
 
 struct fmhip_model {
@@ -120,6 +121,7 @@ struct fmhip_model {
     DevBuf<double> acc;           // {sum e, sum e^2, rows, nonfinite}
     DevBuf<double> bsum;          // k_forward's per-block statistic partials
     int64_t last_nnz = 0, last_rows = 0;
+    int64_t bw_next_hi = -1;      // feature-chunked backward: the next interval must end here (-1: none pending)
     bool profiling = false;
     bool prof_rotate = false;     // time one kernel kind per step, rotating
     int64_t prof_step = 0;
@@ -306,6 +308,9 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
         split_seg.insert(split_seg.end(), hb.split_seg.begin(), hb.split_seg.end());
         HostBatch().cfeat.swap(hb.cfeat);
     }
+    d->h_cfeat = cfeat;
+    d->h_cptr = cptr;
+    d->h_split = split_seg;
     int rc = FMHIP_OK;
     if ((rc = upload(d->row_ptr, row_ptr, (size_t)n_rows + 1)) || (rc = upload(d->col, col, (size_t)nnz)) ||
         (rc = upload(d->val, valf.data(), (size_t)nnz)) || (rc = upload(d->y, yf.data(), (size_t)n_rows)) ||
@@ -391,6 +396,8 @@ BwdArgs bwd_args(fmhip_model_t m, fmhip_dataset_t d, int64_t b) {
     a.split_seg = d->split_seg.p + bm.split_off;
     a.nnz = bm.nnz;
     a.n_ranges = bm.n_ranges;
+    a.rho_lo = 0;
+    a.rho_hi = bm.n_ranges;
     a.n_split = bm.n_split;
     a.P = m->P.p;
     {
@@ -405,8 +412,8 @@ BwdArgs bwd_args(fmhip_model_t m, fmhip_dataset_t d, int64_t b) {
     return a;
 }
 
-// forward + reduce + backward + fixup of one batch into the packed gradient
-int step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double *acc) {
+// forward of one batch: P = e*q, e, per-block statistics partials
+int step_forward(fmhip_model_t m, fmhip_dataset_t d, int64_t b) {
     const BatchMeta &bm = d->batches[(size_t)b];
     TRY(ensure_workspace(m, d));
     if (m->grad_dirty) {
@@ -417,25 +424,57 @@ int step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double *acc) {
         ProfScope ps(m, FMHIP_K_FORWARD, bm.nnz, bm.rows);
         HIP_TRY(launch_forward(m->Kp, kFwdTrain, fwd_args(m, d, bm), m->stream));
     }
-    BwdArgs ba = bwd_args(m, d, b);
-    // the residual statistics {sum e, sum e^2, rows, nonfinite} are finished by k_fixup's extra block
-    ba.red_bsum = m->bsum.p;
-    ba.red_nblocks = fwd_partials(m, bm.rows);
-    ba.red_rows = (int32_t)bm.rows;
-    ba.red_scal = m->scal();
-    ba.red_acc = acc;
-    {
-        ProfScope ps(m, FMHIP_K_BACKWARD, bm.nnz, bm.rows);
-        HIP_TRY(launch_backward(m->Kp, ba, m->stream));
-    }
-    {
-        ProfScope ps(m, FMHIP_K_FIXUP, bm.nnz, bm.rows);
-        HIP_TRY(launch_fixup(m->Kp, ba, m->stream));
-    }
     m->grad_dirty = true;
     m->last_nnz = bm.nnz;
     m->last_rows = bm.rows;
+    m->bw_next_hi = INT64_MAX;
     return FMHIP_OK;
+}
+
+// backward + fixup of the columns whose feature id lies in [feat_lo, feat_hi) into the packed
+// gradient.  The CSC stream is sorted by feature, so the interval is a contiguous run of entries;
+// the range holding its first entry is walked by THIS call in full (the entries of lower features
+// in it produce G rows / head partials that the call covering them consumes later), the range
+// holding the first entry of feat_hi is left to the call that covers feat_hi.  `finish` adds the
+// residual-statistics reduction (once per step, with the last interval).
+int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo, int64_t feat_hi, bool finish,
+                  double *acc) {
+    const BatchMeta &bm = d->batches[(size_t)b];
+    BwdArgs ba = bwd_args(m, d, b);
+    const int32_t *hf = d->h_cfeat.data() + bm.col_off, *hp = d->h_cptr.data() + bm.col_off + b;
+    const int32_t *hs = d->h_split.data() + bm.split_off;
+    const int32_t s_lo = (int32_t)(std::lower_bound(hf, hf + bm.n_cols, (int32_t)std::min<int64_t>(feat_lo, INT32_MAX)) - hf);
+    const int32_t s_hi = (int32_t)(std::lower_bound(hf, hf + bm.n_cols, (int32_t)std::min<int64_t>(feat_hi, INT32_MAX)) - hf);
+    const int32_t e_lo = hp[s_lo], e_hi = hp[s_hi];            // entry interval of the columns
+    ba.rho_lo = e_lo / kRangeLen;
+    ba.rho_hi = s_hi >= bm.n_cols ? bm.n_ranges : e_hi / kRangeLen;   // the straddling range goes to the next interval
+    const int32_t sp_lo = (int32_t)(std::lower_bound(hs, hs + bm.n_split, s_lo) - hs);
+    const int32_t sp_hi = (int32_t)(std::lower_bound(hs, hs + bm.n_split, s_hi) - hs);
+    ba.split_seg += sp_lo;
+    ba.n_split = sp_hi - sp_lo;
+    if (finish) {
+        ba.red_bsum = m->bsum.p;
+        ba.red_nblocks = fwd_partials(m, bm.rows);
+        ba.red_rows = (int32_t)bm.rows;
+        ba.red_scal = m->scal();
+        ba.red_acc = acc;
+    }
+    const int64_t nnz_part = (int64_t)e_hi - e_lo;
+    {
+        ProfScope ps(m, FMHIP_K_BACKWARD, nnz_part, bm.rows);
+        HIP_TRY(launch_backward(m->Kp, ba, m->stream));
+    }
+    {
+        ProfScope ps(m, FMHIP_K_FIXUP, nnz_part, bm.rows);
+        HIP_TRY(launch_fixup(m->Kp, ba, m->stream));
+    }
+    return FMHIP_OK;
+}
+
+// forward + backward + fixup of one batch into the packed gradient
+int step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double *acc) {
+    TRY(step_forward(m, d, b));
+    return step_backward(m, d, b, 0, INT64_MAX, true, acc);
 }
 
 int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double regv) {
@@ -846,6 +885,35 @@ int fmhip_step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t batch) {
     TRY(check_pair(m, d));
     TRY(check_batch(d, batch));
     return step_compute(m, d, batch, nullptr);
+}
+
+int fmhip_step_forward(fmhip_model_t m, fmhip_dataset_t d, int64_t batch) {
+    TRY(check_pair(m, d));
+    TRY(check_batch(d, batch));
+    return step_forward(m, d, batch);
+}
+
+int fmhip_step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, int64_t feat_lo, int64_t feat_hi, int finish) {
+    TRY(check_pair(m, d));
+    TRY(check_batch(d, batch));
+    if (feat_lo < 0 || feat_hi < feat_lo) return fail(FMHIP_ERR_INVALID, "bad feature interval [%lld, %lld)", (long long)feat_lo, (long long)feat_hi);
+    // intervals must come in DESCENDING order and tile [0, n+1): a range straddling two intervals is
+    // walked with the upper one, whose partials the lower one's fixup then reads
+    if (m->bw_next_hi < 0) return fail(FMHIP_ERR_INVALID, "fmhip_step_backward without fmhip_step_forward");
+    if (m->bw_next_hi == INT64_MAX ? feat_hi < m->n1 : feat_hi != m->bw_next_hi)
+        return fail(FMHIP_ERR_INVALID, "feature intervals must tile [0, n+1) in descending order (expected hi = %lld, got %lld)",
+                    (long long)(m->bw_next_hi == INT64_MAX ? m->n1 : m->bw_next_hi), (long long)feat_hi);
+    if (finish && feat_lo != 0) return fail(FMHIP_ERR_INVALID, "finish = 1 belongs to the interval that starts at feature 0");
+    TRY(step_backward(m, d, batch, feat_lo, feat_hi, finish != 0, nullptr));
+    m->bw_next_hi = feat_lo == 0 ? -1 : feat_lo;
+    return FMHIP_OK;
+}
+
+int fmhip_grad_layout(fmhip_model_t m, int64_t *row_floats, int64_t *gv_floats) {
+    if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
+    if (row_floats) *row_floats = m->Kp;
+    if (gv_floats) *gv_floats = (int64_t)m->n1p * m->Kp;
+    return FMHIP_OK;
 }
 
 int fmhip_step_apply(fmhip_model_t m, double eta, double reg0, double regw, double regv) {

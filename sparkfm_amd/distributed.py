@@ -31,6 +31,25 @@ class HipEngine:
         torch.cuda.synchronize(fm.device)   # the zero-fill must land before the library's stream uses the buffer
         _ffi.check(self.L.fmhip_grad_bind(fm.handle, C.c_void_p(self.grad.data_ptr())))
         self.n_batches = dataset.n_batches
+        rf, gv = C.c_int64(), C.c_int64()
+        _ffi.check(self.L.fmhip_grad_layout(fm.handle, C.byref(rf), C.byref(gv)))
+        self.row_floats, self.gv_floats = int(rf.value), int(gv.value)
+        self.n1 = fm.num_attribute + 1
+
+    def forward(self, batch):
+        _ffi.check(self.L.fmhip_step_forward(self.fm.handle, self.dataset.handle, batch))
+
+    def backward(self, batch, lo, hi, finish):
+        """Gradient rows of features lo <= id < hi (intervals in descending order, finish on the last)."""
+        _ffi.check(self.L.fmhip_step_backward(self.fm.handle, self.dataset.handle, batch, lo, hi, 1 if finish else 0))
+
+    def gv_slice(self, lo, hi):
+        """The part of the packed buffer that holds G_V of features lo <= id < hi."""
+        return self.grad[lo * self.row_floats:min(hi, self.n1) * self.row_floats]
+
+    def tail_slice(self):
+        """G_w | G_b | scalars."""
+        return self.grad[self.gv_floats:]
 
     def compute(self, batch):
         _ffi.check(self.L.fmhip_step_compute(self.fm.handle, self.dataset.handle, batch))
@@ -75,11 +94,15 @@ class DataParallelSGD(FMLearn):
     """FMLearn whose `learn` runs one data-parallel epoch over this rank's row shard."""
 
     def __init__(self, eta=0.05, reg0=0.0, regw=0.0, regv=0.0, group=None, engine_factory=HipEngine,
-                 always_reduce=False):
+                 always_reduce=False, overlap=True, cuts=None):
         self.eta, self.reg0, self.regw, self.regv = float(eta), float(reg0), float(regw), float(regv)
         self.group = group
         self.engine_factory = engine_factory
         self.always_reduce = always_reduce   # run the collective even in a 1-rank group (self-test)
+        # overlap: backward runs per feature interval (cold, high-id features first) and each
+        # interval's slice of the gradient is all-reduced while the next interval computes
+        self.overlap = overlap
+        self.cuts = cuts                     # ascending feature ids [0, c1, ..., n+1]; None = planned from the data
         self._engine = None
         self._key = None
 
@@ -100,14 +123,59 @@ class DataParallelSGD(FMLearn):
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
 
+    def _collective(self):
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.always_reduce)
+
+    def plan_cuts(self, eng, fractions=(0.45,)):
+        """Feature-id cut points shared by all ranks: the interval above the last cut holds about
+        `fractions[-1]` of the stored nonzeros (rank 0's shard decides; ids are assumed to be roughly
+        frequency-ranked — if they are not, the cuts are still valid, just less useful)."""
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        n1 = eng.n1
+        cuts = torch.zeros(len(fractions), dtype=torch.int64, device=eng.grad.device)
+        if not self._collective() or dist.get_rank(self.group) == 0:
+            col = eng.dataset.col
+            cnt = np.bincount(col, minlength=n1)[:n1] if len(col) else np.zeros(n1, np.int64)
+            above = np.cumsum(cnt[::-1])[::-1]                      # nonzeros with id >= f
+            total = max(int(above[0]) if n1 else 0, 1)
+            vals = [int(np.searchsorted(-above, -f * total)) for f in sorted(fractions, reverse=True)]
+            cuts = torch.tensor(vals, dtype=torch.int64, device=eng.grad.device)
+        if self._collective():
+            dist.broadcast(cuts, src=0, group=self.group)
+        inner = sorted({int(c) for c in cuts.tolist() if 0 < int(c) < n1})
+        self.cuts = [0] + inner + [n1]
+        return self.cuts
+
     def step(self, eng, j):
         import torch.distributed as dist
-        if j < eng.n_batches:
-            eng.compute(j)
+        live = j < eng.n_batches
+        if not (self._collective() and self.overlap and hasattr(eng, "backward")):
+            if live:
+                eng.compute(j)
+            else:
+                eng.compute_empty()
+            if self._collective():
+                dist.all_reduce(eng.grad, op=dist.ReduceOp.SUM, group=self.group)
+            eng.apply(self.eta, self.reg0, self.regw, self.regv)
+            return
+        if self.cuts is None:
+            self.plan_cuts(eng)
+        works = []
+        if live:
+            eng.forward(j)
         else:
             eng.compute_empty()
-        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.always_reduce):
-            dist.all_reduce(eng.grad, op=dist.ReduceOp.SUM, group=self.group)
+        for i in range(len(self.cuts) - 1, 0, -1):                  # descending: cold features first
+            lo, hi = self.cuts[i - 1], self.cuts[i]
+            if live:
+                eng.backward(j, lo, hi, finish=(i == 1))
+            works.append(dist.all_reduce(eng.gv_slice(lo, hi), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        works.append(dist.all_reduce(eng.tail_slice(), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
         eng.apply(self.eta, self.reg0, self.regw, self.regv)
 
     def learn(self, fm, dataset):

@@ -306,6 +306,7 @@ def test_split_step_equals_fused_step(fmhip):
     fm2.w0, fm2.w, fm2.v = a["w0"], a["w"], a["v"]
     dp = DataParallelSGD(eta=0.04, regw=1e-3, regv=1e-3)
     dp.learn(fm2, ds)
+    assert dp.plan_cuts(dp.engine(fm2, ds))[0] == 0 and dp.cuts[-1] == a["n1"]
     torch.cuda.synchronize()
     assert fm2.w0 == want[0]
     np.testing.assert_array_equal(fm2.w, want[1])
@@ -316,6 +317,47 @@ def test_split_step_equals_fused_step(fmhip):
     ds.unpersist()
     fm.close()
     fm2.close()
+
+
+def test_feature_chunked_backward_equals_whole_backward(fmhip):
+    """fmhip_step_forward + fmhip_step_backward over descending feature intervals fills the packed
+    gradient exactly like fmhip_step_compute (bit for bit): the overlap path of the data-parallel
+    trainer.  Cuts are placed inside ranges, at range boundaries, and around empty intervals."""
+    import ctypes as C
+    import torch
+    from sparkfm_amd import _ffi
+    from sparkfm_amd.distributed import HipEngine
+    L = _ffi.load()
+    a = random_problem(81, 3000, 400, 32, 1, 30)
+    for r in range(3000):                                            # two hot columns -> wave sums + long fixups
+        s = slice(a["row_ptr"][r], a["row_ptr"][r + 1])
+        a["col"][s.start] = 0 if not (a["col"][s] == 0).any() else a["col"][s.start]
+    ds, fm = make(fmhip, a, batch_rows=1500)
+    eng = HipEngine(fm, ds)
+    for batch in (0, 1):
+        eng.compute(batch)
+        torch.cuda.synchronize()
+        want = eng.grad.clone()
+        eng.grad.zero_()
+        torch.cuda.synchronize()
+        fm_h = fm.handle
+        _ffi.check(L.fmhip_grad_bind(fm_h, C.c_void_p(eng.grad.data_ptr())))   # marks the zeroed buffer clean
+        for cuts in ([0, 400], [0, 1, 400], [0, 7, 50, 51, 399, 400], [0, 200, 200, 400]):
+            eng.forward(batch)
+            for i in range(len(cuts) - 1, 0, -1):
+                eng.backward(batch, cuts[i - 1], cuts[i], finish=(i == 1))
+            torch.cuda.synchronize()
+            assert torch.equal(eng.grad, want), cuts
+            eng.grad.zero_()
+            torch.cuda.synchronize()
+            _ffi.check(L.fmhip_grad_bind(fm_h, C.c_void_p(eng.grad.data_ptr())))
+    # order is enforced
+    eng.forward(0)
+    assert L.fmhip_step_backward(fm.handle, ds.handle, 0, 0, 100, 0) == -1
+    assert b"descending" in L.fmhip_last_error()
+    eng.close()
+    ds.unpersist()
+    fm.close()
 
 
 def test_errors_are_reported_not_thrown(fmhip):
