@@ -22,6 +22,24 @@ class Model:
     def computeRMSE(self, dataset):
         raise NotImplementedError
 
+    # The remaining metrics of S/Model.scala are off the training path and buggy in the reference
+    # (quirk Q4): computeMAE there is a SIGNED mean error (no abs, :21-26) and computeAccuracy does
+    # an integer division that yields 0 or 1 (:28-30).  Here they are what their names say; the
+    # reference's signed quantity is available as computeMeanError.
+    def computeMeanError(self, dataset):
+        """mean of (target - prediction): what the reference's `computeMAE` actually returns."""
+        return float((dataset.y - self.predict(dataset)).mean()) if dataset.size else 0.0
+
+    def computeMAE(self, dataset):
+        return float(abs(dataset.y - self.predict(dataset)).mean()) if dataset.size else 0.0
+
+    def computeAccuracy(self, dataset):
+        """fraction of rows whose prediction has the target's sign (>= 0 vs < 0), S/Model.scala:29."""
+        if not dataset.size:
+            return 0.0
+        yh = self.predict(dataset)
+        return float((((dataset.y >= 0) & (yh >= 0)) | ((dataset.y < 0) & (yh < 0))).mean())
+
 
 class FMModel(Model):
     def __init__(self, num_attribute, num_factor, init_mean=0.0, init_stdev=0.01, seed=0, device=0, stream=None):

@@ -151,3 +151,42 @@ def test_shard_rows_partition():
     cuts = [shard_rows(1003, r, 8) for r in range(8)]
     assert cuts[0][0] == 0 and cuts[-1][1] == 1003
     assert all(cuts[i][1] == cuts[i + 1][0] for i in range(7))
+
+
+def test_libfm_io_follows_the_reference(tmp_path):
+    """S/fm/FMUtils.scala:23-69 incl. quirk Q9 (the saver writes i+1, the loader keeps indices as written)."""
+    from sparkfm_amd import DataSet, FMUtils
+    src = tmp_path / "in.libfm"
+    src.write_text("# comment\n\n  1 0:1 3:0.5  7:2.25\n-1.5 2:1\n0\n3 5:0.1234 1:1e-3\n")
+    ds = FMUtils.loadLibFMFile(str(src))
+    assert ds.size == 4 and ds.dimension == 7 and list(ds.row_ptr) == [0, 3, 4, 4, 6]
+    assert list(ds.col) == [0, 3, 7, 2, 5, 1] and list(ds.y) == [1.0, -1.5, 0.0, 3.0]   # stored order kept
+    out = tmp_path / "out.libfm"
+    FMUtils.saveAsLibFMFile(ds, str(out))
+    assert out.read_text().splitlines() == ["1 1:1 4:.5 8:2.25", "-1.5 3:1", "0", "3 6:.123 2:.001"]
+    FMUtils.saveAsLibFMFile(ds, str(out), index_offset=0)
+    back = FMUtils.loadLibFMFile(str(out))
+    assert list(back.col) == list(ds.col) and list(back.row_ptr) == list(ds.row_ptr)
+    for v, s in [(1.0, "1"), (-2.0, "-2"), (0.5, ".5"), (-0.25, "-.25"), (0.0005, "0"), (0.0015, ".002"),
+                 (0.0025, ".002"), (12.3456, "12.346"), (1e-9, "0")]:
+        assert FMUtils.minimizeString(v) == s, (v, FMUtils.minimizeString(v))
+    with pytest.raises(ValueError):
+        FMUtils.loadLibFMFile(str(src), numFeatures=3)
+
+
+def test_split_by_random():
+    from sparkfm_amd import DataCollection, DataSet
+    rng = np.random.default_rng(0)
+    rows = [(float(i), (rng.choice(50, 3, replace=False), rng.random(3))) for i in range(2000)]
+    ds = DataSet.from_rows(rows)
+    c = DataCollection.splitByRandom(ds, 0.8, 0.2, seed=4)
+    assert c.trainingSet.size + c.testSet.size == 2000 and c.validationSet.size == 0
+    assert 0.75 < c.trainingSet.size / 2000 < 0.85
+    assert sorted(np.concatenate([c.trainingSet.y, c.testSet.y]).tolist()) == [float(i) for i in range(2000)]
+    r0 = int(c.testSet.y[0])
+    np.testing.assert_array_equal(c.testSet.col[:3], ds.col[3 * r0:3 * r0 + 3])
+    assert c.dimension == max(c.trainingSet.dimension, c.testSet.dimension)
+    c3 = DataCollection.splitByRandom(ds, 0.6, 0.2, 0.2, seed=4)
+    assert c3.validationSet.size > 0 and c3.trainingSet.size + c3.testSet.size + c3.validationSet.size == 2000
+    with pytest.raises(Exception, match="required"):
+        DataCollection.splitByRandom(ds, 0.0, 1.0)
