@@ -141,6 +141,14 @@ int fmhip_sgd_epoch(fmhip_model_t m, fmhip_dataset_t d, double eta, double reg0,
 int fmhip_batch_grad(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double *gv, double *gw, double *gw0,
                      fmhip_stats *stats);
 
+/* ---- ALS: SparkFM's own learner -----------------------------------------------------
+ * One ALS.learn pass (S/fm/lib/ALS.scala:15-75, closed-form steps :152-198) in fp64 on the GPU,
+ * including the reference's quirk that slot `num_attribute` is never trained (:38,:52).  Needs a
+ * single-batch dataset (batch_rows <= 0).  The parameters live in an fp64 master copy, so
+ * fmhip_model_get_params returns the fp64 result exactly; the fp32 device copy used by the scoring
+ * calls is refreshed from it. */
+int fmhip_als_epoch(fmhip_model_t m, fmhip_dataset_t d, double reg0, double regw, double regv);
+
 /* ---- data-parallel split step ---------------------------------------------------
  * packed fp32 gradient: [ G_V (n1p*Kp) | G_w (n1p) | G_b (n1p) | scalars (8) ], n1p = n+1
  * rounded up to 4, Kp = padded factors.  G_V holds sum e*x*q; G_b holds sum e*x^2 (the

@@ -6,10 +6,10 @@ The arithmetic runs in hand-written HIP kernels (csrc/) behind a plain C ABI
 """
 from .dataset import DataSet, Features  # noqa: F401
 from .model import FMModel, Model  # noqa: F401
-from .learn import FMLearn, HipSGD  # noqa: F401
+from .learn import FMLearn, HipALS, HipSGD  # noqa: F401
 from .fm import FM, FactorizationMachines, Task  # noqa: F401
 from .datacollection import DataCollection  # noqa: F401
 from . import fmutils as FMUtils  # noqa: F401
 
-__all__ = ["DataSet", "Features", "FMModel", "Model", "FMLearn", "HipSGD", "FM", "FactorizationMachines", "Task",
+__all__ = ["DataSet", "Features", "FMModel", "Model", "FMLearn", "HipSGD", "HipALS", "FM", "FactorizationMachines", "Task",
            "DataCollection", "FMUtils"]

@@ -22,7 +22,7 @@ SYMBOLS = (
     "fmhip_dataset_create", "fmhip_dataset_create_f32", "fmhip_dataset_destroy", "fmhip_dataset_info",
     "fmhip_dataset_batch_info", "fmhip_dataset_get_transpose",
     "fmhip_predict", "fmhip_rmse", "fmhip_residual", "fmhip_term_q",
-    "fmhip_sgd_step", "fmhip_sgd_epoch", "fmhip_batch_grad",
+    "fmhip_sgd_step", "fmhip_sgd_epoch", "fmhip_batch_grad", "fmhip_als_epoch",
     "fmhip_grad_floats", "fmhip_grad_bind", "fmhip_grad_ptr", "fmhip_grad_layout", "fmhip_step_compute",
     "fmhip_step_forward", "fmhip_step_backward", "fmhip_step_apply",
     "fmhip_step_stats", "fmhip_profile_begin", "fmhip_profile_begin_rotating", "fmhip_profile_end",
@@ -98,6 +98,7 @@ def load():
     L.fmhip_sgd_step.argtypes = [vp, vp, i64, dbl, dbl, dbl, dbl, P(Stats)]
     L.fmhip_sgd_epoch.argtypes = [vp, vp, dbl, dbl, dbl, dbl, vp, P(Stats)]
     L.fmhip_batch_grad.argtypes = [vp, vp, i64, vp, vp, P(dbl), P(Stats)]
+    L.fmhip_als_epoch.argtypes = [vp, vp, dbl, dbl, dbl]
     L.fmhip_grad_floats.argtypes = [vp, P(i64)]
     L.fmhip_grad_bind.argtypes = [vp, vp]
     L.fmhip_grad_ptr.argtypes = [vp, P(vp)]

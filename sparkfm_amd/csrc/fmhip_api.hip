@@ -5,6 +5,7 @@
 // Everything here is plumbing; the arithmetic lives in fm_kernels.hip.
 #include "../../include/fmhip.h"
 #include "fm_kernels.h"
+#include "als_kernels.h"
 
 #include <algorithm>
 #include <cmath>
@@ -72,6 +73,8 @@ struct DevBuf {
     ~DevBuf() { release(); }
 };
 
+constexpr int64_t kAlsMaxNnz = (int64_t)1 << 27;
+
 struct BatchMeta {
     int64_t row0 = 0, rows = 0;
     int64_t nnz0 = 0;   // offset of the batch in the global CSR/CSC entry arrays
@@ -105,6 +108,9 @@ struct fmhip_dataset {
     DevBuf<float> cval;
     DevBuf<int32_t> cfeat, cptr, range_seg, split_seg;
     std::vector<int32_t> h_cfeat, h_cptr, h_split;   // host copies (feature-chunked backward needs them)
+    // fp64 copies of the values (CSR order, CSC order) and labels for the fp64 ALS learner; kept only
+    // for single-batch datasets of at most kAlsMaxNnz stored nonzeros
+    DevBuf<double> val64, cval64, y64;
 };
 
 struct fmhip_model {
@@ -122,6 +128,12 @@ struct fmhip_model {
     DevBuf<double> bsum;          // k_forward's per-block statistic partials
     int64_t last_nnz = 0, last_rows = 0;
     int64_t bw_next_hi = -1;      // feature-chunked backward: the next interval must end here (-1: none pending)
+    // fp64 master copy of the parameters (reference layout): exact round trip of what the caller set,
+    // and the state the fp64 ALS learner trains; stale once an fp32 SGD step has run
+    std::vector<double> h_w, h_v;
+    double h_w0 = 0.0;
+    bool host64_fresh = false;
+    DevBuf<double> als_w0, als_w, als_v, als_e, als_q;
     bool profiling = false;
     bool prof_rotate = false;     // time one kernel kind per step, rotating
     int64_t prof_step = 0;
@@ -174,7 +186,8 @@ struct HostBatch {
 // (featureId -> (rowIdx, value)) + groupByKey), as a stable counting sort: inside a column
 // the batch-local row indices ascend.  `cnt` is a per-thread scratch of dimension+1 zeros.
 void build_batch(const int64_t *row_ptr, const int32_t *col, const float *val, const BatchMeta &bm,
-                 std::vector<int32_t> &cnt, uint32_t *crow, float *cval, HostBatch &hb) {
+                 std::vector<int32_t> &cnt, uint32_t *crow, float *cval, HostBatch &hb,
+                 const double *val64 = nullptr, double *cval64 = nullptr) {
     const int64_t p0 = bm.nnz0, p1 = bm.nnz0 + bm.nnz;
     std::vector<int32_t> &feat = hb.cfeat;
     feat.clear();
@@ -193,6 +206,7 @@ void build_batch(const int64_t *row_ptr, const int32_t *col, const float *val, c
             const int32_t d = cnt[col[p]]++;
             crow[d] = (uint32_t)r;
             cval[d] = val[p];
+            if (cval64) cval64[d] = val64[p];
         }
     }
     for (size_t s = 0; s < nc; ++s) {
@@ -274,6 +288,15 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     std::vector<uint32_t> crow((size_t)nnz);
     std::vector<float> cval((size_t)nnz);
     std::vector<HostBatch> hbs((size_t)nb);
+    const bool keep64 = nb == 1 && nnz <= kAlsMaxNnz;
+    std::vector<double> val64, cval64, y64;
+    if (keep64) {
+        val64.resize((size_t)nnz);
+        cval64.resize((size_t)nnz);
+        y64.resize((size_t)n_rows);
+        for (int64_t p = 0; p < nnz; ++p) val64[(size_t)p] = (double)val[p];
+        for (int64_t r = 0; r < n_rows; ++r) y64[(size_t)r] = (double)y[r];
+    }
     {
         unsigned hw = std::thread::hardware_concurrency();
         int nt = (int)std::min<int64_t>(nb, hw ? hw : 1);
@@ -284,7 +307,7 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
             for (int64_t b = t; b < nb; b += nt) {
                 const BatchMeta &bm = d->batches[(size_t)b];
                 build_batch(row_ptr, col, valf.data(), bm, cnt, crow.data() + bm.nnz0, cval.data() + bm.nnz0,
-                            hbs[(size_t)b]);
+                            hbs[(size_t)b], keep64 ? val64.data() : nullptr, keep64 ? cval64.data() : nullptr);
             }
         };
         for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
@@ -317,7 +340,9 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
         (rc = upload(d->crow, crow.data(), (size_t)nnz)) || (rc = upload(d->cval, cval.data(), (size_t)nnz)) ||
         (rc = upload(d->cfeat, cfeat.data(), cfeat.size())) || (rc = upload(d->cptr, cptr.data(), cptr.size())) ||
         (rc = upload(d->range_seg, range_seg.data(), range_seg.size())) ||
-        (rc = upload(d->split_seg, split_seg.data(), split_seg.size()))) {
+        (rc = upload(d->split_seg, split_seg.data(), split_seg.size())) ||
+        (keep64 && ((rc = upload(d->val64, val64.data(), val64.size())) || (rc = upload(d->cval64, cval64.data(), cval64.size())) ||
+                    (rc = upload(d->y64, y64.data(), y64.size()))))) {
         delete d;
         return rc;
     }
@@ -496,6 +521,7 @@ int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double reg
         HIP_TRY(launch_apply(m->Kp, a, m->stream));
     }
     m->grad_dirty = false;
+    m->host64_fresh = false;
     ++m->prof_step;
     return FMHIP_OK;
 }
@@ -532,6 +558,12 @@ int set_params_impl(fmhip_model_t m, FT w0, const FT *w, const FT *v) {
         for (int f = 0; f < m->k; ++f) hV[(size_t)i * m->Kp + f] = (float)v[f + i * (int64_t)m->k];
     }
     const float hw0 = (float)w0;
+    m->h_w0 = (double)w0;
+    m->h_w.assign((size_t)m->n1, 0.0);
+    m->h_v.assign((size_t)m->n1 * m->k, 0.0);
+    for (int64_t i = 0; i < m->n1; ++i) m->h_w[(size_t)i] = (double)w[i];
+    for (int64_t j = 0; j < m->n1 * m->k; ++j) m->h_v[(size_t)j] = (double)v[j];
+    m->host64_fresh = true;
     HIP_TRY(hipMemcpyAsync(m->V.p, hV.data(), hV.size() * sizeof(float), hipMemcpyHostToDevice, m->stream));
     HIP_TRY(hipMemcpyAsync(m->w.p, hw.data(), hw.size() * sizeof(float), hipMemcpyHostToDevice, m->stream));
     HIP_TRY(hipMemcpyAsync(m->w0.p, &hw0, sizeof(float), hipMemcpyHostToDevice, m->stream));
@@ -543,6 +575,12 @@ template <typename FT>
 int get_params_impl(fmhip_model_t m, FT *w0, FT *w, FT *v) {
     if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
     TRY(set_device(m->device));
+    if (m->host64_fresh) {   // nothing has trained in fp32 since the masters were written: return them exactly
+        if (w0) *w0 = (FT)m->h_w0;
+        if (w) for (int64_t i = 0; i < m->n1; ++i) w[i] = (FT)m->h_w[(size_t)i];
+        if (v) for (int64_t j = 0; j < m->n1 * m->k; ++j) v[j] = (FT)m->h_v[(size_t)j];
+        return FMHIP_OK;
+    }
     std::vector<float> hV((size_t)m->n1p * m->Kp), hw((size_t)m->n1p);
     float hw0 = 0.f;
     HIP_TRY(hipMemcpyAsync(hV.data(), m->V.p, hV.size() * sizeof(float), hipMemcpyDeviceToHost, m->stream));
@@ -856,6 +894,65 @@ int fmhip_batch_grad(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double *
         stats->nnz = d->batches[(size_t)batch].nnz;
     }
     return FMHIP_OK;
+}
+
+// ---- ALS (the reference's own learner), fp64
+
+int fmhip_als_epoch(fmhip_model_t m, fmhip_dataset_t d, double reg0, double regw, double regv) {
+    TRY(check_pair(m, d));
+    if (d->batches.size() > 1 || (d->nnz > 0 && !d->val64.p))
+        return fail(FMHIP_ERR_UNSUPPORTED, "ALS walks the whole-dataset transpose: create the dataset with batch_rows <= 0 "
+                                           "(single batch, at most 2^27 stored nonzeros)");
+    if (!m->host64_fresh) {   // parameters last changed by fp32 SGD: start from their fp64 widening
+        std::vector<double> w((size_t)m->n1), v((size_t)m->n1 * m->k);
+        double w0 = 0.0;
+        TRY(get_params_impl<double>(m, &w0, w.data(), v.data()));
+        m->h_w0 = w0;
+        m->h_w.swap(w);
+        m->h_v.swap(v);
+        m->host64_fresh = true;
+    }
+    const size_t n1 = (size_t)m->n1, nv = n1 * (size_t)m->k, nr = (size_t)std::max<int64_t>(d->n_rows, 1);
+    TRY(m->als_w0.ensure(1));
+    TRY(m->als_w.ensure(n1));
+    TRY(m->als_v.ensure(nv));
+    TRY(m->als_e.ensure(nr));
+    TRY(m->als_q.ensure(nr));
+    HIP_TRY(hipMemcpyAsync(m->als_w0.p, &m->h_w0, sizeof(double), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(m->als_w.p, m->h_w.data(), n1 * sizeof(double), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(m->als_v.p, m->h_v.data(), nv * sizeof(double), hipMemcpyHostToDevice, m->stream));
+    if (d->n_rows > 0) {
+        const BatchMeta &bm = d->batches[0];
+        AlsArgs a{};
+        a.k = m->k;
+        a.num_attribute = m->n;
+        a.n_rows = d->n_rows;
+        a.row_ptr = d->row_ptr.p;
+        a.col = d->col.p;
+        a.val = d->val64.p;
+        a.y = d->y64.p;
+        a.n_cols = bm.n_cols;
+        a.cfeat = d->cfeat.p;
+        a.cptr = d->cptr.p;
+        a.crow = d->crow.p;
+        a.cval = d->cval64.p;
+        a.w0 = m->als_w0.p;
+        a.w = m->als_w.p;
+        a.v = m->als_v.p;
+        a.reg0 = reg0;
+        a.regw = regw;
+        a.regv = regv;
+        a.e = m->als_e.p;
+        a.q = m->als_q.p;
+        HIP_TRY(launch_als_epoch(a, m->stream));
+    }
+    std::vector<double> w(n1), v(nv);
+    double w0 = 0.0;
+    HIP_TRY(hipMemcpyAsync(&w0, m->als_w0.p, sizeof(double), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(w.data(), m->als_w.p, n1 * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(v.data(), m->als_v.p, nv * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return set_params_impl<double>(m, w0, w.data(), v.data());   // refreshes the fp64 masters and the fp32 device copy
 }
 
 // ---- data-parallel split step

@@ -61,3 +61,19 @@ class HipSGD(FMLearn):
                                               self.regv, C.byref(st) if want_stats else None))
         fm._device_updated()
         return st.as_dict() if want_stats else None
+
+
+class HipALS(FMLearn):
+    """The reference's own learner on the GPU: one ``learn`` = one ``ALS.learn`` pass
+    (S/fm/lib/ALS.scala:15-75) in fp64, using the MODEL's regularisers ``fm.reg0/regw/regv`` as the
+    reference does (:21,:40,:56; defaults 0, 0, 10).  ``HipALS.run()`` mirrors ``ALS.run()`` (:202-208).
+    Needs a single-batch DataSet (``batch_rows=0``)."""
+
+    @classmethod
+    def run(cls):
+        return cls()
+
+    def learn(self, fm, dataset):
+        _ffi.check(_ffi.load().fmhip_als_epoch(fm.handle, dataset.handle, fm.reg0, fm.regw, fm.regv))
+        fm._device_updated()
+        return fm

@@ -394,6 +394,77 @@ def test_nonfinite_is_counted_not_masked(fmhip):
     fm.close()
 
 
+def test_als_epoch_matches_the_reference_learner(fmhip, kats):
+    """fmhip_als_epoch = ALS.learn (S/fm/lib/ALS.scala:15-75) in fp64 on the GPU: against the
+    120-digit KATs and against the oracle over several epochs (tree-ordered column sums vs the
+    oracle's sequential ones: agreement to fp64 reassociation)."""
+    for c in kats:
+        a = kat_arrays(c)
+        s = c["als"]
+        ds, fm = make(fmhip, a)
+        fm.reg0, fm.regw, fm.regv = f(s["reg0"]), f(s["regw"]), f(s["regv"])
+        fmhip.HipALS.run().learn(fm, ds)
+        assert fm.w0 == pytest.approx(f(s["w0"]), rel=1e-10, abs=1e-12)
+        np.testing.assert_allclose(fm.w, f(s["w"]), rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(fm.v, np.array(f(s["V"])), rtol=1e-9, atol=1e-11)
+        assert fm.w[-1] == a["w"][-1]                                # quirk Q1: last slot never trained
+        np.testing.assert_array_equal(fm.v[:, -1], a["v"][:, -1])
+        ds.unpersist()
+        fm.close()
+    a = random_problem(515, 1500, 120, 6, 0, 14, empty_rows=(7,))
+    rng = np.random.default_rng(2)
+    a["y"] = oracle.predict(0.3, rng.normal(0, 0.3, 120), rng.normal(0, 0.3, (3, 120)), a["row_ptr"], a["col"],
+                            a["val"]) + rng.normal(0, 0.05, 1500)
+    ds, fm = make(fmhip, a)
+    fm.reg0, fm.regw, fm.regv = 0.0, 0.1, 10.0
+    w0, w, v = a["w0"], a["w"], a["v"]
+    rm = [fm.computeRMSE(ds)]
+    for _ in range(4):
+        fmhip.HipALS.run().learn(fm, ds)
+        w0, w, v = oracle.als_epoch(w0, w, v, 0.0, 0.1, 10.0, a["row_ptr"], a["col"], a["val"], a["y"])
+        rm.append(fm.computeRMSE(ds))
+    np.testing.assert_allclose(fm.v, v, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(fm.w, w, rtol=1e-8, atol=1e-11)
+    assert fm.w0 == pytest.approx(w0, rel=1e-9)
+    assert rm[-1] < 0.5 * rm[0]                                      # ALS converges fast on a planted FM
+    assert rm[-1] == pytest.approx(oracle.rmse(w0, w, v, a["row_ptr"], a["col"], a["val"], a["y"]), rel=1e-5)
+    # SGD then ALS: the fp64 masters are refreshed from the fp32 device state first
+    fmhip.HipSGD(eta=0.01).learn(fm, ds)
+    w0, w, v = fm.w0, fm.w.copy(), fm.v.copy()
+    fmhip.HipALS.run().learn(fm, ds)
+    w0, w, v = oracle.als_epoch(w0, w, v, 0.0, 0.1, 10.0, a["row_ptr"], a["col"], a["val"], a["y"])
+    np.testing.assert_allclose(fm.v, v, rtol=1e-8, atol=1e-11)
+    multi = fmhip.DataSet(a["row_ptr"], a["col"], a["val"], a["y"], batch_rows=500).cache()
+    from sparkfm_amd import _ffi
+    with pytest.raises(_ffi.FmhipError) as ei:
+        fmhip.HipALS.run().learn(fm, multi)
+    assert ei.value.code == -5
+    multi.unpersist()
+    ds.unpersist()
+    fm.close()
+
+
+def test_config_c1_fit_with_als(fmhip):
+    """BASELINE config 1 — SparkFM fit() on 10k rows x 1k features, k=8 — through the reference's call
+    shape FM(dataset, numFactor, maxIteration).learnWith(ALS.run) (S/driver.scala:106-110), on the GPU."""
+    from sparkfm_amd import synth
+    d = synth.make_config("C1")
+    ds = fmhip.DataSet.from_arrays(d, name="C1")                      # single batch: ALS needs the whole transpose
+    trainer = fmhip.FM(ds, d["k"], maxIteration=3, seed=5)
+    fm = trainer.learnWith(fmhip.HipALS.run())
+    w0, w, v = 0.0, np.zeros(ds.dimension + 1), fmhip.FMModel(ds.dimension, 8, seed=5).v
+    val, y = d["val"].astype(np.float64), d["y"].astype(np.float64)
+    hist = []
+    for _ in range(3):
+        hist.append(oracle.rmse(w0, w, v, d["row_ptr"], d["col"], val, y))
+        w0, w, v = oracle.als_epoch(w0, w, v, 0.0, 0.0, 10.0, d["row_ptr"], d["col"], val, y)
+    np.testing.assert_allclose(trainer.rmse_history, hist, rtol=1e-5)
+    np.testing.assert_allclose(fm.v, v, rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(fm.w, w, rtol=1e-8, atol=1e-12)
+    assert fm.computeMAE(ds) > 0 and 0.0 <= fm.computeAccuracy(ds) <= 1.0
+    assert abs(fm.computeMeanError(ds)) < fm.computeMAE(ds)
+
+
 def test_fit_loop_like_the_reference(fmhip):
     """FM(dataset, numFactor, maxIteration).learnWith(learner) — S/fm/impl/FactorizationMachines.scala:30-51."""
     from sparkfm_amd import synth
