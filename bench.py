@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dp", action="store_true",
                     help="self-test: take the data-parallel path (RCCL all-reduce included) even with one rank")
-    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--cpu-budget", type=float, default=30.0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
