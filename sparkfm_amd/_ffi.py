@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfmhip.so")
+LIB_PATH = os.environ.get("FMHIP_LIB") or os.path.join(_HERE, "lib", "libfmhip.so")   # FMHIP_LIB: A/B builds
 
 OK = 0
 K_FORWARD, K_REDUCE, K_BACKWARD, K_FIXUP, K_APPLY, K_COUNT = 0, 1, 2, 3, 4, 5

@@ -47,6 +47,17 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// The CSR / CSC index and value streams are read exactly once per step: load them non-temporally
+// so they do not evict the gathered tables (V, P) from L2.
+template <typename T>
+__device__ __forceinline__ T stream_load(const T *p) {
+#ifdef FMHIP_STREAM_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4mul(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ void f4fma(float4 &acc, float4 a, float s) {
@@ -121,8 +132,8 @@ __global__ __launch_bounds__(kLdsBlock) void k_forward_lds(FwdArgs a) {
             int c = -1;
             float x = 0.f;
             if (p < p1) {
-                c = a.col[p];
-                x = a.val[p];
+                c = stream_load(a.col + p);
+                x = stream_load(a.val + p);
                 const float wv = c < T ? wt[c] : a.w[c];
                 lin = fmaf(wv, x, lin);
             }
@@ -223,8 +234,8 @@ __global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
             int c = 0;
             float x = 0.f;
             if (p < p1) {
-                c = a.col[p];
-                x = a.val[p];
+                c = stream_load(a.col + p);
+                x = stream_load(a.val + p);
                 lin = fmaf(a.w[c], x, lin);
             }
             const int cnt = (int)((p1 - base) < (int64_t)LPN ? (p1 - base) : (int64_t)LPN);
@@ -429,8 +440,8 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
         uint32_t rf = 0u;
         float x = 0.f, ee = 0.f;
         if (p < stop) {
-            rf = a.crow[p];
-            x = a.cval[p];
+            rf = stream_load(a.crow + p);
+            x = stream_load(a.cval + p);
             ee = a.e[rf & 0x7fffffffu];
         }
         const int cnt = (stop - base) < LPN ? (stop - base) : LPN;
@@ -549,7 +560,7 @@ __global__ __launch_bounds__(kBlock) void k_backward_p(BwdArgs a) {
             const int p = sbase + g * LPN + l;
             rf[g] = 0u;
             x[g] = 0.f;
-            if (p < stop) { rf[g] = a.crow[p]; x[g] = a.cval[p]; }
+            if (p < stop) { rf[g] = stream_load(a.crow + p); x[g] = stream_load(a.cval + p); }
         }
 #pragma unroll
         for (int g = 0; g < SG; ++g) {
