@@ -12,8 +12,8 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfmhip.so")
 SYNTH = os.path.join(LIBDIR, "libfmsynth.so")
 
-HIP_SOURCES = ["fm_kernels.hip", "als_kernels.hip", "fmhip_api.hip"]
-HIP_DEPS = ["fm_kernels.h", "als_kernels.h", os.path.join("..", "..", "include", "fmhip.h")]
+HIP_SOURCES = ["fm_kernels.hip", "als_kernels.hip", "csc_build.hip", "fmhip_api.hip"]
+HIP_DEPS = ["fm_kernels.h", "als_kernels.h", "csc_build.h", os.path.join("..", "..", "include", "fmhip.h")]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 
 

@@ -6,6 +6,7 @@
 #include "../../include/fmhip.h"
 #include "fm_kernels.h"
 #include "als_kernels.h"
+#include "csc_build.h"
 
 #include <algorithm>
 #include <cmath>
@@ -182,38 +183,12 @@ struct HostBatch {
     std::vector<int32_t> cfeat, cptr, range_seg, split_seg;
 };
 
-// Row -> column transpose of one batch (S/DataSet.scala:31-38: zipWithIndex + flatMap
-// (featureId -> (rowIdx, value)) + groupByKey), as a stable counting sort: inside a column
-// the batch-local row indices ascend.  `cnt` is a per-thread scratch of dimension+1 zeros.
-void build_batch(const int64_t *row_ptr, const int32_t *col, const float *val, const BatchMeta &bm,
-                 std::vector<int32_t> &cnt, uint32_t *crow, float *cval, HostBatch &hb,
-                 const double *val64 = nullptr, double *cval64 = nullptr) {
-    const int64_t p0 = bm.nnz0, p1 = bm.nnz0 + bm.nnz;
-    std::vector<int32_t> &feat = hb.cfeat;
-    feat.clear();
-    for (int64_t p = p0; p < p1; ++p)
-        if (cnt[col[p]]++ == 0) feat.push_back(col[p]);
-    std::sort(feat.begin(), feat.end());
-    const size_t nc = feat.size();
-    hb.cptr.assign(nc + 1, 0);
-    for (size_t s = 0; s < nc; ++s) {
-        hb.cptr[s + 1] = hb.cptr[s] + cnt[feat[s]];
-        cnt[feat[s]] = hb.cptr[s];  // becomes the write cursor of the column
-    }
-    for (int64_t r = 0; r < bm.rows; ++r) {
-        const int64_t a = row_ptr[bm.row0 + r], b = row_ptr[bm.row0 + r + 1];
-        for (int64_t p = a; p < b; ++p) {
-            const int32_t d = cnt[col[p]]++;
-            crow[d] = (uint32_t)r;
-            cval[d] = val[p];
-            if (cval64) cval64[d] = val64[p];
-        }
-    }
-    for (size_t s = 0; s < nc; ++s) {
-        crow[hb.cptr[s]] |= 0x80000000u;  // first entry of its column
-        cnt[feat[s]] = 0;                 // leave the scratch clean for the next batch
-    }
-    const int32_t n_ranges = (int32_t)((bm.nnz + kRangeLen - 1) / kRangeLen);
+// Host-side metadata of one batch from its column offsets (the transposed stream itself is built
+// on the device, csc_build.hip): the column open at the start of every 64-entry range and the
+// columns whose sum is assembled by k_fixup.
+void finish_batch_meta(HostBatch &hb, int32_t nnz) {
+    const size_t nc = hb.cfeat.size();
+    const int32_t n_ranges = (int32_t)((nnz + kRangeLen - 1) / kRangeLen);
     hb.range_seg.assign((size_t)n_ranges, 0);
     size_t s = 0;
     for (int32_t rho = 0; rho < n_ranges; ++rho) {
@@ -222,9 +197,8 @@ void build_batch(const int64_t *row_ptr, const int32_t *col, const float *val, c
         hb.range_seg[(size_t)rho] = (int32_t)s;
     }
     hb.split_seg.clear();
-    // columns whose sum is assembled by k_fixup — the same predicates k_backward applies: a
-    // column spanning two ranges whose remainder in the second is <= kExtend is finished by the
-    // first range's slot and needs no fixup
+    // the same predicates k_backward applies: a column spanning two ranges whose remainder in the
+    // second is <= kExtend is finished by the first range's slot and needs no fixup
     for (size_t c = 0; c < nc; ++c) {
         const int32_t ra = hb.cptr[c] / kRangeLen, rb = (hb.cptr[c + 1] - 1) / kRangeLen;
         if (rb > ra && !(rb == ra + 1 && hb.cptr[c + 1] - rb * kRangeLen <= kExtend)) hb.split_seg.push_back((int32_t)c);
@@ -285,34 +259,74 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     std::vector<float> valf((size_t)nnz), yf((size_t)n_rows);
     for (int64_t p = 0; p < nnz; ++p) valf[(size_t)p] = (float)val[p];
     for (int64_t r = 0; r < n_rows; ++r) yf[(size_t)r] = (float)y[r];
-    std::vector<uint32_t> crow((size_t)nnz);
-    std::vector<float> cval((size_t)nnz);
-    std::vector<HostBatch> hbs((size_t)nb);
     const bool keep64 = nb == 1 && nnz <= kAlsMaxNnz;
-    std::vector<double> val64, cval64, y64;
+    int rc = FMHIP_OK;
+    if ((rc = upload(d->row_ptr, row_ptr, (size_t)n_rows + 1)) || (rc = upload(d->col, col, (size_t)nnz)) ||
+        (rc = upload(d->val, valf.data(), (size_t)nnz)) || (rc = upload(d->y, yf.data(), (size_t)n_rows)) ||
+        (rc = d->crow.alloc((size_t)nnz)) || (rc = d->cval.alloc((size_t)nnz))) {
+        delete d;
+        return rc;
+    }
     if (keep64) {
-        val64.resize((size_t)nnz);
-        cval64.resize((size_t)nnz);
-        y64.resize((size_t)n_rows);
+        std::vector<double> val64((size_t)nnz), y64((size_t)n_rows);
         for (int64_t p = 0; p < nnz; ++p) val64[(size_t)p] = (double)val[p];
         for (int64_t r = 0; r < n_rows; ++r) y64[(size_t)r] = (double)y[r];
+        if ((rc = upload(d->val64, val64.data(), val64.size())) || (rc = upload(d->y64, y64.data(), y64.size())) ||
+            (rc = d->cval64.alloc((size_t)nnz))) {
+            delete d;
+            return rc;
+        }
     }
+    // per-batch row -> column transposes, built on the device (csc_build.hip); only the small
+    // column index (offsets, feature ids) comes back to the host
+    std::vector<HostBatch> hbs((size_t)nb);
     {
-        unsigned hw = std::thread::hardware_concurrency();
-        int nt = (int)std::min<int64_t>(nb, hw ? hw : 1);
-        nt = std::max(nt, 1);
-        std::vector<std::thread> pool;
-        auto work = [&](int t) {
-            std::vector<int32_t> cnt((size_t)dim + 2, 0);
-            for (int64_t b = t; b < nb; b += nt) {
-                const BatchMeta &bm = d->batches[(size_t)b];
-                build_batch(row_ptr, col, valf.data(), bm, cnt, crow.data() + bm.nnz0, cval.data() + bm.nnz0,
-                            hbs[(size_t)b], keep64 ? val64.data() : nullptr, keep64 ? cval64.data() : nullptr);
+        int32_t max_nnz = 0;
+        for (const BatchMeta &bm : d->batches) max_nnz = std::max(max_nnz, bm.nnz);
+        const size_t max_cols = (size_t)std::min<int64_t>((int64_t)max_nnz, (int64_t)dim + 1);
+        int key_bits = 1;
+        while (key_bits < 31 && ((int64_t)1 << key_bits) <= (int64_t)dim) ++key_bits;
+        DevBuf<int32_t> keys_a, keys_b, rowid, starts, feats, count;
+        DevBuf<uint32_t> idx_a, idx_b;
+        DevBuf<uint8_t> flags, tmp;
+        CscScratch sc;
+        size_t tmp_bytes = 0;
+        hipError_t he = max_nnz ? csc_scratch_bytes((size_t)max_nnz, key_bits, &tmp_bytes) : hipSuccess;
+        if (he != hipSuccess) {
+            delete d;
+            return fail(FMHIP_ERR_HIP, "rocPRIM scratch query failed: %s", hipGetErrorString(he));
+        }
+        if ((rc = keys_a.alloc((size_t)max_nnz)) || (rc = keys_b.alloc((size_t)max_nnz)) || (rc = idx_a.alloc((size_t)max_nnz)) ||
+            (rc = idx_b.alloc((size_t)max_nnz)) || (rc = rowid.alloc((size_t)max_nnz)) || (rc = flags.alloc((size_t)max_nnz)) ||
+            (rc = starts.alloc(max_cols + 1)) || (rc = feats.alloc(max_cols + 1)) || (rc = count.alloc(1)) ||
+            (rc = tmp.alloc(tmp_bytes + 16))) {
+            delete d;
+            return rc;
+        }
+        sc.keys_a = keys_a.p; sc.keys_b = keys_b.p; sc.idx_a = idx_a.p; sc.idx_b = idx_b.p; sc.rowid = rowid.p;
+        sc.flags = flags.p; sc.starts = starts.p; sc.feats = feats.p; sc.count = count.p; sc.tmp = tmp.p; sc.tmp_bytes = tmp_bytes;
+        for (int64_t b = 0; b < nb; ++b) {
+            const BatchMeta &bm = d->batches[(size_t)b];
+            HostBatch &hb = hbs[(size_t)b];
+            he = csc_build_batch(nullptr, sc, d->row_ptr.p, d->col.p, d->val.p, keep64 ? d->val64.p : nullptr, bm.row0, bm.rows,
+                                 bm.nnz0, bm.nnz, key_bits, d->crow.p, d->cval.p, keep64 ? d->cval64.p : nullptr);
+            int32_t nc = 0;
+            if (he == hipSuccess) he = hipMemcpy(&nc, sc.count, sizeof nc, hipMemcpyDeviceToHost);
+            if (he == hipSuccess) {
+                hb.cfeat.resize((size_t)nc);
+                hb.cptr.resize((size_t)nc + 1);
+                if (nc) {
+                    he = hipMemcpy(hb.cfeat.data(), sc.feats, (size_t)nc * sizeof(int32_t), hipMemcpyDeviceToHost);
+                    if (he == hipSuccess) he = hipMemcpy(hb.cptr.data(), sc.starts, (size_t)nc * sizeof(int32_t), hipMemcpyDeviceToHost);
+                }
+                hb.cptr[(size_t)nc] = bm.nnz;
             }
-        };
-        for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
-        work(0);
-        for (auto &th : pool) th.join();
+            if (he != hipSuccess) {
+                delete d;
+                return fail(FMHIP_ERR_HIP, "device transpose of batch %lld failed: %s", (long long)b, hipGetErrorString(he));
+            }
+            finish_batch_meta(hb, bm.nnz);
+        }
     }
     std::vector<int32_t> cfeat, cptr, range_seg, split_seg;
     for (int64_t b = 0; b < nb; ++b) {
@@ -334,15 +348,9 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     d->h_cfeat = cfeat;
     d->h_cptr = cptr;
     d->h_split = split_seg;
-    int rc = FMHIP_OK;
-    if ((rc = upload(d->row_ptr, row_ptr, (size_t)n_rows + 1)) || (rc = upload(d->col, col, (size_t)nnz)) ||
-        (rc = upload(d->val, valf.data(), (size_t)nnz)) || (rc = upload(d->y, yf.data(), (size_t)n_rows)) ||
-        (rc = upload(d->crow, crow.data(), (size_t)nnz)) || (rc = upload(d->cval, cval.data(), (size_t)nnz)) ||
-        (rc = upload(d->cfeat, cfeat.data(), cfeat.size())) || (rc = upload(d->cptr, cptr.data(), cptr.size())) ||
+    if ((rc = upload(d->cfeat, cfeat.data(), cfeat.size())) || (rc = upload(d->cptr, cptr.data(), cptr.size())) ||
         (rc = upload(d->range_seg, range_seg.data(), range_seg.size())) ||
-        (rc = upload(d->split_seg, split_seg.data(), split_seg.size())) ||
-        (keep64 && ((rc = upload(d->val64, val64.data(), val64.size())) || (rc = upload(d->cval64, cval64.data(), cval64.size())) ||
-                    (rc = upload(d->y64, y64.data(), y64.size()))))) {
+        (rc = upload(d->split_seg, split_seg.data(), split_seg.size()))) {
         delete d;
         return rc;
     }
