@@ -81,7 +81,10 @@ int fmhip_device_count(int *count);
  *   key 0  forward kernel : 0 = global-memory gathers (default), 20 = LDS V-tile (rows of the hottest,
  *                           i.e. lowest-id, features staged in LDS; ids must be frequency-ranked to benefit)
  *   key 1  backward kernel: 1 = pipelined buffer-load walk (default), 0 = plain walk
- *   key 2  LDS V-tile rows: 0 = auto (as many rows as fit 128 KiB) */
+ *   key 2  LDS V-tile rows: 0 = auto (as many rows as fit 128 KiB)
+ *   key 3  rows per row block of the transposes built by the NEXT fmhip_dataset_create (0 = off):
+ *          entries sorted by (row block, feature) so a block's slice of P stays L2-resident in the
+ *          backward; features occurring in several blocks are summed by an extra fixup pass */
 int fmhip_tune(int key, int value);
 
 /* ---- model: `new FMModel(num_attribute, num_factor)`  S/fm/FMModel.scala:9-22 -- */

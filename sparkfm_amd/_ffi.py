@@ -115,6 +115,10 @@ def load():
         fn = getattr(L, name)
         if name not in ("fmhip_version", "fmhip_last_error"):
             fn.restype = C.c_int
+    # FMHIP_TUNE="key=value,key=value": experiment knobs (fmhip_tune) applied at load time
+    for item in filter(None, os.environ.get("FMHIP_TUNE", "").split(",")):
+        k, v = item.split("=")
+        L.fmhip_tune(int(k), int(v))
     _lib = L
     return L
 

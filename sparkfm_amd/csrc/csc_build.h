@@ -23,12 +23,13 @@ hipError_t csc_scratch_bytes(size_t max_nnz, int key_bits, size_t *bytes);
 
 // Transposes the batch whose CSR entries are [nnz0, nnz0 + nnz) of col/val (rows row0 .. row0+rows):
 //   crow[nnz0 + p] = batch-local row | (first entry of its column) << 31, cval[nnz0 + p] = value,
-// sorted by feature id, rows ascending inside a column (stable sort of the CSR order) — the same
+// sorted by (row block = local row / rb_rows, feature id), rows ascending inside a column piece (stable sort of the CSR order) — the same
 // result as SparkFM's zipWithIndex + flatMap + groupByKey (S/DataSet.scala:31-38) with the
 // unspecified groupByKey order fixed to ascending rows.  Leaves the column starts / feature ids /
 // column count in the scratch (device) for the caller to read back.
 hipError_t csc_build_batch(hipStream_t s, const CscScratch &sc, const int64_t *row_ptr, const int32_t *col,
                            const float *val, const double *val64, int64_t row0, int64_t rows, int64_t nnz0,
-                           int32_t nnz, int key_bits, uint32_t *crow, float *cval, double *cval64);
+                           int32_t nnz, int key_bits, int32_t rb_rows, int rb_bits, uint32_t *crow, float *cval,
+                           double *cval64);
 
 }  // namespace fmhip

@@ -16,7 +16,8 @@ namespace fmhip {
 namespace {
 
 __global__ __launch_bounds__(256) void k_expand(const int64_t *row_ptr, const int32_t *col, int64_t row0, int64_t rows,
-                                                int64_t nnz0, int32_t *keys, uint32_t *idx, int32_t *rowid) {
+                                                int64_t nnz0, int32_t rb_rows, int key_bits, int32_t *keys, uint32_t *idx,
+                                                int32_t *rowid) {
     // one 8-lane group per row: coalesced 32-B pieces of the row's entries
     const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
     const int l = threadIdx.x & 7;
@@ -24,7 +25,8 @@ __global__ __launch_bounds__(256) void k_expand(const int64_t *row_ptr, const in
     const int64_t p0 = row_ptr[row0 + r], p1 = row_ptr[row0 + r + 1];
     for (int64_t p = p0 + l; p < p1; p += 8) {
         const int64_t o = p - nnz0;
-        keys[o] = col[p];
+        // sort key: (row block, feature id) — row blocks keep a block's P rows L2-resident in the backward
+        keys[o] = col[p] | (int32_t)((r / rb_rows) << key_bits);
         idx[o] = (uint32_t)o;
         rowid[o] = (int32_t)r;
     }
@@ -44,9 +46,9 @@ __global__ __launch_bounds__(256) void k_unpack(const int32_t *keys, const uint3
 }
 
 __global__ __launch_bounds__(256) void k_gather_feats(const int32_t *keys, const int32_t *starts, const int32_t *count,
-                                                      int32_t *feats) {
+                                                      int32_t feat_mask, int32_t *feats) {
     const int32_t s = blockIdx.x * 256 + threadIdx.x;
-    if (s < *count) feats[s] = keys[starts[s]];
+    if (s < *count) feats[s] = keys[starts[s]] & feat_mask;
 }
 
 }  // namespace
@@ -67,17 +69,18 @@ hipError_t csc_scratch_bytes(size_t max_nnz, int key_bits, size_t *bytes) {
 
 hipError_t csc_build_batch(hipStream_t s, const CscScratch &sc, const int64_t *row_ptr, const int32_t *col,
                            const float *val, const double *val64, int64_t row0, int64_t rows, int64_t nnz0,
-                           int32_t nnz, int key_bits, uint32_t *crow, float *cval, double *cval64) {
+                           int32_t nnz, int key_bits, int32_t rb_rows, int rb_bits, uint32_t *crow, float *cval,
+                           double *cval64) {
     hipError_t e = hipMemsetAsync(sc.count, 0, sizeof(int32_t), s);
     if (e != hipSuccess || nnz == 0) return e;
     {
         const int64_t threads = rows * 8;
         hipLaunchKernelGGL(k_expand, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, row_ptr, col, row0, rows, nnz0,
-                           sc.keys_a, sc.idx_a, sc.rowid);
+                           rb_rows, key_bits, sc.keys_a, sc.idx_a, sc.rowid);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     size_t tb = sc.tmp_bytes;
-    e = rocprim::radix_sort_pairs(sc.tmp, tb, sc.keys_a, sc.keys_b, sc.idx_a, sc.idx_b, (size_t)nnz, 0, (unsigned)key_bits, s);
+    e = rocprim::radix_sort_pairs(sc.tmp, tb, sc.keys_a, sc.keys_b, sc.idx_a, sc.idx_b, (size_t)nnz, 0, (unsigned)(key_bits + rb_bits), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_unpack, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, s, sc.keys_b, sc.idx_b, sc.rowid, val, val64,
                        nnz0, nnz, crow, cval, cval64, sc.flags);
@@ -87,7 +90,7 @@ hipError_t csc_build_batch(hipStream_t s, const CscScratch &sc, const int64_t *r
     if (e != hipSuccess) return e;
     // at most min(nnz, max_cols) columns; the launch covers that bound and reads the count on device
     hipLaunchKernelGGL(k_gather_feats, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, s, sc.keys_b, sc.starts, sc.count,
-                       sc.feats);
+                       (int32_t)(((int64_t)1 << key_bits) - 1), sc.feats);
     return hipGetLastError();
 }
 

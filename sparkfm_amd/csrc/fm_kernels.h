@@ -11,7 +11,7 @@ constexpr int kPartPad = 4;        // partial row = Kp floats + {sum e*x, sum e*
 constexpr int kScalars = 8;        // packed-gradient tail: {sum e, sum e^2, rows, nonfinite, ...}
 
 // runtime kernel-variant knobs (diagnostics / A-B benchmarking; fmhip_tune)
-enum { kTuneFwd = 0, kTuneBwd = 1, kTuneTile = 2, kTuneCount = 3 };
+enum { kTuneFwd = 0, kTuneBwd = 1, kTuneTile = 2, kTuneRowBlock = 3, kTuneXcd = 4, kTuneCount = 5 };
 extern int g_tune[kTuneCount];
 
 // padded factor count: 4 * LPN * J with LPN = lanes per row-slot (<= 16), J float4 per lane
@@ -47,11 +47,13 @@ struct BwdArgs {
     const float *cval;
     const int32_t *range_seg;  // [n_ranges] compressed column index holding entry rho*kRangeLen
     const int32_t *cfeat;      // [n_cols] feature id of compressed column
+    const int32_t *cdst;       // [n_cols] >= 0: G row (= feature id) | < 0: piece row -1-dst (feature has several pieces)
     const int32_t *cptr;       // [n_cols+1]
     const int32_t *split_seg;  // [n_split] compressed columns that span >1 range
     int32_t nnz;
     int32_t n_ranges;
     int32_t rho_lo, rho_hi;    // ranges this launch walks (whole batch: 0, n_ranges)
+    int32_t xcd_chunk;         // > 0: XCD-aware workgroup placement (set by the launcher)
     int32_t n_split;
     const float *P;            // [rows][Kp]
     uint32_t p_bytes;          // size of P in bytes, or 0 if it does not fit a 32-bit buffer descriptor
@@ -60,6 +62,10 @@ struct BwdArgs {
     float *Gw;                 // [n1p]
     float *Gb;                 // [n1p]
     float *part;               // [n_ranges][2][Kp + kPartPad]
+    float *pieces;             // [n_pieces][Kp + kPartPad] column pieces of multi-piece features (row-blocked streams)
+    const int32_t *mp_feat;    // [n_mp] features with several pieces
+    const int32_t *mp_ptr;     // [n_mp + 1] their piece-row intervals
+    int32_t n_mp;
     // optional: k_fixup's extra last block also sums the forward's per-block statistics
     const double *red_bsum;
     int32_t red_nblocks, red_rows;
@@ -78,6 +84,7 @@ struct ApplyArgs {
 hipError_t launch_forward(int Kp, FwdMode mode, const FwdArgs &a, hipStream_t s);
 hipError_t launch_backward(int Kp, const BwdArgs &a, hipStream_t s);
 hipError_t launch_fixup(int Kp, const BwdArgs &a, hipStream_t s);
+hipError_t launch_fixup2(int Kp, const BwdArgs &a, hipStream_t s);   // sums the pieces of multi-piece features
 hipError_t launch_apply(int Kp, const ApplyArgs &a, hipStream_t s);
 // scal[0..3] = {sum e, sum e^2, n_rows, nonfinite} (optional); acc (optional, 4 doubles) += the same
 hipError_t launch_reduce_blocks(const double *bsum, int32_t nblocks, int32_t n_rows, float *scal, double *acc,

@@ -21,7 +21,7 @@
 
 namespace fmhip {
 
-int g_tune[kTuneCount] = {0, 1, 0};   // forward: flat kernel; backward: pipelined kernel; tile rows: auto   // forward: flat-load kernel; backward: pipelined kernel (measured 12 % faster)
+int g_tune[kTuneCount] = {0, 1, 0, 0, 0};   // forward: flat kernel; backward: pipelined; tile rows: auto; row blocks: off   // forward: flat-load kernel; backward: pipelined kernel (measured 12 % faster)
 
 int padded_factors(int k) {
     int kp = 4;
@@ -356,6 +356,20 @@ __device__ __forceinline__ void store_row(float *dst, int l, const float4 (&acc)
     if (l == 0) { *dsa = sa; *dsb = sb; }
 }
 
+// A finished column piece goes to its destination: the G row of its feature when the feature has a
+// single piece in the batch, else a piece row that k_fixup2 sums per feature (row-blocked streams).
+template <int LPN, int J>
+__device__ __forceinline__ void store_seg(const BwdArgs &a, int seg, int l, const float4 (&acc)[J], float sa, float sb) {
+    constexpr int KP = 4 * LPN * J;
+    const int dst = a.cdst[seg];
+    if (dst >= 0) {
+        store_row<LPN, J>(a.GV + (size_t)dst * KP, l, acc, sa, sb, a.Gw + dst, a.Gb + dst);
+    } else {
+        float *pr = a.pieces + (size_t)(-1 - dst) * (KP + kPartPad);
+        store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1);
+    }
+}
+
 // sa += e*x (-> G_w, h(w_i) = x); sb += e*x^2 (-> G_b, the -x^2*v term of h(v)).  Written with
 // explicit fma's so that every code path (plain-chunk fast path, flush path, both kernels) rounds
 // identically whatever the compiler's contraction choices: results do not depend on which path a
@@ -404,8 +418,12 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
     constexpr int CH = (LPN * J > 16) ? (16 / J) : LPN;  // entries whose P rows are in flight together
     const int l = threadIdx.x & (LPN - 1);
     // a launch may cover only the ranges [rho_lo, rho_hi) (feature-chunked backward); block
-    // numbering stays aligned to the global range numbering so the wave-sum predicate is unchanged
-    const int rho = (a.rho_lo / SLOTS + blockIdx.x) * SLOTS + threadIdx.x / LPN;
+    // numbering stays aligned to the global range numbering so the wave-sum predicate is unchanged.
+    // xcd_chunk > 0: XCD-aware placement — workgroups b, b+8, b+16, .. share an XCD (round-robin
+    // dispatch), so XCD x is given the x-th contiguous eighth of the stream: with a row-blocked
+    // stream that is a few whole row blocks, whose slice of P then lives in that XCD's L2 only.
+    const int blk = a.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int rho = (a.rho_lo / SLOTS + blk) * SLOTS + threadIdx.x / LPN;
     if (rho < a.rho_lo || rho >= a.rho_hi) return;
     const int beg = rho * kRangeLen;
     const int end = (beg + kRangeLen < a.nnz) ? beg + kRangeLen : a.nnz;
@@ -467,8 +485,7 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
                             float *pr = a.part + ((size_t)rho * 2) * PR;
                             store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1);
                         } else {
-                            const int i = a.cfeat[seg];
-                            store_row<LPN, J>(a.GV + (size_t)i * KP, l, acc, sa, sb, a.Gw + i, a.Gb + i);
+                            store_seg<LPN, J>(a, seg, l, acc, sa, sb);
                         }
                         is_head = false;
                         ++seg;
@@ -500,8 +517,7 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
         float *pr = a.part + ((size_t)rho * 2 + 1) * PR;
         store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1);
     } else {
-        const int i = a.cfeat[seg];
-        store_row<LPN, J>(a.GV + (size_t)i * KP, l, acc, sa, sb, a.Gw + i, a.Gb + i);
+        store_seg<LPN, J>(a, seg, l, acc, sa, sb);
     }
 }
 
@@ -520,8 +536,12 @@ __global__ __launch_bounds__(kBlock) void k_backward_p(BwdArgs a) {
     constexpr int NCH = SG * LPN / CHB;                                       // chunks per super-group
     const int l = threadIdx.x & (LPN - 1);
     // a launch may cover only the ranges [rho_lo, rho_hi) (feature-chunked backward); block
-    // numbering stays aligned to the global range numbering so the wave-sum predicate is unchanged
-    const int rho = (a.rho_lo / SLOTS + blockIdx.x) * SLOTS + threadIdx.x / LPN;
+    // numbering stays aligned to the global range numbering so the wave-sum predicate is unchanged.
+    // xcd_chunk > 0: XCD-aware placement — workgroups b, b+8, b+16, .. share an XCD (round-robin
+    // dispatch), so XCD x is given the x-th contiguous eighth of the stream: with a row-blocked
+    // stream that is a few whole row blocks, whose slice of P then lives in that XCD's L2 only.
+    const int blk = a.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int rho = (a.rho_lo / SLOTS + blk) * SLOTS + threadIdx.x / LPN;
     if (rho < a.rho_lo || rho >= a.rho_hi) return;
     const __amdgpu_buffer_rsrc_t prs = make_rsrc(a.P, a.p_bytes);
     const int beg = rho * kRangeLen;
@@ -621,8 +641,7 @@ __global__ __launch_bounds__(kBlock) void k_backward_p(BwdArgs a) {
                             float *pr = a.part + ((size_t)rho * 2) * PR;
                             store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1);
                         } else {
-                            const int i = a.cfeat[seg];
-                            store_row<LPN, J>(a.GV + (size_t)i * KP, l, acc, sa, sb, a.Gw + i, a.Gb + i);
+                            store_seg<LPN, J>(a, seg, l, acc, sa, sb);
                         }
                         is_head = false;
                         ++seg;
@@ -654,8 +673,7 @@ __global__ __launch_bounds__(kBlock) void k_backward_p(BwdArgs a) {
         float *pr = a.part + ((size_t)rho * 2 + 1) * PR;
         store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1);
     } else {
-        const int i = a.cfeat[seg];
-        store_row<LPN, J>(a.GV + (size_t)i * KP, l, acc, sa, sb, a.Gw + i, a.Gb + i);
+        store_seg<LPN, J>(a, seg, l, acc, sa, sb);
     }
 }
 
@@ -729,9 +747,35 @@ __global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
     }
     slots_reduce<LPN, J>(acc, sa, sb);
     if (ws == 0) {
-        const int i = a.cfeat[seg];
-        store_row<LPN, J>(a.GV + (size_t)i * KP, l, acc, sa, sb, a.Gw + i, a.Gb + i);
+        store_seg<LPN, J>(a, seg, l, acc, sa, sb);
     }
+}
+
+// One slot per feature whose column was cut into several pieces (one per row block): the pieces lie
+// next to each other in the piece buffer, in row-block order; summed serially -> fixed order.
+template <int LPN, int J>
+__global__ __launch_bounds__(kBlock) void k_fixup2(BwdArgs a) {
+    constexpr int KP = 4 * LPN * J;
+    constexpr int SLOTS = kBlock / LPN;
+    constexpr int PR = KP + kPartPad;
+    const int l = threadIdx.x & (LPN - 1);
+    const int m = blockIdx.x * SLOTS + threadIdx.x / LPN;
+    if (m >= a.n_mp) return;
+    const int p0 = a.mp_ptr[m], p1 = a.mp_ptr[m + 1];
+    float4 acc[J];
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) acc[jj] = f4zero();
+    float sa = 0.f, sb = 0.f;
+    for (int p = p0; p < p1; ++p) {
+        const float *pr = a.pieces + (size_t)p * PR;
+        const float4 *p4 = reinterpret_cast<const float4 *>(pr) + l;
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) f4add(acc[jj], p4[jj * LPN]);
+        sa += pr[KP];
+        sb += pr[KP + 1];
+    }
+    const int i = a.mp_feat[m];
+    store_row<LPN, J>(a.GV + (size_t)i * KP, l, acc, sa, sb, a.Gw + i, a.Gb + i);
 }
 
 // ------------------------------------------------------------------ apply
@@ -805,10 +849,13 @@ hipError_t bwd_dispatch(const BwdArgs &a, hipStream_t s) {
     constexpr int SLOTS = kBlock / LPN;
     if (a.rho_hi <= a.rho_lo) return hipSuccess;
     const int first_block = a.rho_lo / SLOTS, last_block = (a.rho_hi - 1) / SLOTS;
-    dim3 g((unsigned)(last_block - first_block + 1)), b(kBlock);
+    const int nblk = last_block - first_block + 1;
+    BwdArgs a2 = a;
+    a2.xcd_chunk = a.xcd_chunk > 0 ? (nblk + 7) / 8 : 0;      // blocks per XCD
+    dim3 g((unsigned)(a2.xcd_chunk > 0 ? a2.xcd_chunk * 8 : nblk)), b(kBlock);
     // the pipelined kernel needs P to fit a 32-bit buffer view (< 4 GiB per batch)
-    if (a.p_bytes && g_tune[kTuneBwd] == 1) hipLaunchKernelGGL((k_backward_p<LPN, J>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((k_backward<LPN, J>), g, b, 0, s, a);
+    if (a.p_bytes && g_tune[kTuneBwd] == 1) hipLaunchKernelGGL((k_backward_p<LPN, J>), g, b, 0, s, a2);
+    else hipLaunchKernelGGL((k_backward<LPN, J>), g, b, 0, s, a2);
     return hipGetLastError();
 }
 
@@ -849,6 +896,21 @@ hipError_t launch_backward(int Kp, const BwdArgs &a, hipStream_t s) {
 
 hipError_t launch_fixup(int Kp, const BwdArgs &a, hipStream_t s) {
 #define CALL(L_, J_) fix_dispatch<L_, J_>(a, s)
+    FMHIP_KP_SWITCH(Kp, CALL)
+#undef CALL
+}
+
+template <int LPN, int J>
+hipError_t fix2_dispatch(const BwdArgs &a, hipStream_t s) {
+    constexpr int SLOTS = kBlock / LPN;
+    if (a.n_mp < 1) return hipSuccess;
+    dim3 g((unsigned)((a.n_mp + SLOTS - 1) / SLOTS)), b(kBlock);
+    hipLaunchKernelGGL((k_fixup2<LPN, J>), g, b, 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fixup2(int Kp, const BwdArgs &a, hipStream_t s) {
+#define CALL(L_, J_) fix2_dispatch<L_, J_>(a, s)
     FMHIP_KP_SWITCH(Kp, CALL)
 #undef CALL
 }

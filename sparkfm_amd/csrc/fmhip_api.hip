@@ -86,6 +86,10 @@ struct BatchMeta {
     int64_t range_off = 0;
     int32_t n_split = 0;
     int64_t split_off = 0;
+    int32_t n_feats = 0;    // distinct features present (== n_cols unless the stream is row-blocked)
+    int32_t n_mp = 0;       // features cut into several pieces (one per row block they occur in)
+    int64_t mp_off = 0;     // offset into mp_feat; mp_ptr offset is mp_off + batch index
+    int32_t n_pieces = 0;   // piece rows those features need
 };
 
 struct ProfRec {
@@ -107,8 +111,10 @@ struct fmhip_dataset {
     DevBuf<float> val, y;
     DevBuf<uint32_t> crow;
     DevBuf<float> cval;
-    DevBuf<int32_t> cfeat, cptr, range_seg, split_seg;
+    DevBuf<int32_t> cfeat, cptr, range_seg, split_seg, cdst, mp_feat, mp_ptr;
     std::vector<int32_t> h_cfeat, h_cptr, h_split;   // host copies (feature-chunked backward needs them)
+    int64_t rb_rows = 0;       // rows per row block of the transposes (0 = not row-blocked)
+    int32_t max_pieces = 0;
     // fp64 copies of the values (CSR order, CSC order) and labels for the fp64 ALS learner; kept only
     // for single-batch datasets of at most kAlsMaxNnz stored nonzeros
     DevBuf<double> val64, cval64, y64;
@@ -124,7 +130,7 @@ struct fmhip_model {
     DevBuf<float> grad_own;
     float *grad = nullptr;        // packed gradient in use (own or bound)
     bool grad_dirty = false;      // holds a gradient that has not been applied/zeroed
-    DevBuf<float> P, e, part;
+    DevBuf<float> P, e, part, pieces;
     DevBuf<double> acc;           // {sum e, sum e^2, rows, nonfinite}
     DevBuf<double> bsum;          // k_forward's per-block statistic partials
     int64_t last_nnz = 0, last_rows = 0;
@@ -180,14 +186,41 @@ int set_device(int device) {
 // ---- dataset construction -------------------------------------------------------
 
 struct HostBatch {
-    std::vector<int32_t> cfeat, cptr, range_seg, split_seg;
+    std::vector<int32_t> cfeat, cptr, range_seg, split_seg, cdst, mp_feat, mp_ptr;
+    int32_t n_feats = 0, n_pieces = 0;
 };
 
 // Host-side metadata of one batch from its column offsets (the transposed stream itself is built
 // on the device, csc_build.hip): the column open at the start of every 64-entry range and the
 // columns whose sum is assembled by k_fixup.
-void finish_batch_meta(HostBatch &hb, int32_t nnz) {
+void finish_batch_meta(HostBatch &hb, int32_t nnz, std::vector<int32_t> &cnt, std::vector<int32_t> &base) {
     const size_t nc = hb.cfeat.size();
+    // destinations of the column pieces: a feature with one piece stores straight to its G row; a
+    // feature with several (row-blocked stream) gets consecutive piece rows, in stream (= row block)
+    // order, that k_fixup2 sums.  `cnt` / `base` are zeroed scratch arrays of dimension + 1 entries.
+    {
+        std::vector<int32_t> multi;
+        hb.n_feats = 0;
+        for (size_t s = 0; s < nc; ++s) {
+            const int32_t c = ++cnt[hb.cfeat[s]];
+            if (c == 1) ++hb.n_feats;
+            if (c == 2) multi.push_back(hb.cfeat[s]);
+        }
+        std::sort(multi.begin(), multi.end());
+        hb.mp_feat = multi;
+        hb.mp_ptr.assign(multi.size() + 1, 0);
+        for (size_t m = 0; m < multi.size(); ++m) {
+            base[multi[m]] = hb.mp_ptr[m];
+            hb.mp_ptr[m + 1] = hb.mp_ptr[m] + cnt[multi[m]];
+        }
+        hb.n_pieces = multi.empty() ? 0 : hb.mp_ptr[multi.size()];
+        hb.cdst.resize(nc);
+        for (size_t s = 0; s < nc; ++s) {
+            const int32_t f = hb.cfeat[s];
+            hb.cdst[s] = cnt[f] > 1 ? -1 - (base[f]++) : f;
+        }
+        for (size_t s = 0; s < nc; ++s) { cnt[hb.cfeat[s]] = 0; base[hb.cfeat[s]] = 0; }
+    }
     const int32_t n_ranges = (int32_t)((nnz + kRangeLen - 1) / kRangeLen);
     hb.range_seg.assign((size_t)n_ranges, 0);
     size_t s = 0;
@@ -283,9 +316,21 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     {
         int32_t max_nnz = 0;
         for (const BatchMeta &bm : d->batches) max_nnz = std::max(max_nnz, bm.nnz);
-        const size_t max_cols = (size_t)std::min<int64_t>((int64_t)max_nnz, (int64_t)dim + 1);
+        const size_t max_cols = (size_t)max_nnz;   // row-blocked streams repeat a feature once per block
         int key_bits = 1;
         while (key_bits < 31 && ((int64_t)1 << key_bits) <= (int64_t)dim) ++key_bits;
+        // optional row blocking of the transposes (fmhip_tune key 3): entries sorted by (row block,
+        // feature) so that a block's slice of P stays L2-resident while its columns are walked
+        int64_t rb_rows = g_tune[kTuneRowBlock] > 0 ? g_tune[kTuneRowBlock] : 0;
+        int rb_bits = 0;
+        if (rb_rows > 0) {
+            const int64_t blocks = (d->max_rows + rb_rows - 1) / rb_rows;
+            while (((int64_t)1 << rb_bits) < blocks) ++rb_bits;
+            if (key_bits + rb_bits > 31) { rb_rows = 0; rb_bits = 0; }
+        }
+        d->rb_rows = rb_bits > 0 ? rb_rows : 0;
+        const int32_t rb_div = d->rb_rows > 0 ? (int32_t)std::min<int64_t>(d->rb_rows, INT32_MAX) : INT32_MAX;
+        std::vector<int32_t> cnt((size_t)dim + 2, 0), base((size_t)dim + 2, 0);
         DevBuf<int32_t> keys_a, keys_b, rowid, starts, feats, count;
         DevBuf<uint32_t> idx_a, idx_b;
         DevBuf<uint8_t> flags, tmp;
@@ -309,7 +354,7 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
             const BatchMeta &bm = d->batches[(size_t)b];
             HostBatch &hb = hbs[(size_t)b];
             he = csc_build_batch(nullptr, sc, d->row_ptr.p, d->col.p, d->val.p, keep64 ? d->val64.p : nullptr, bm.row0, bm.rows,
-                                 bm.nnz0, bm.nnz, key_bits, d->crow.p, d->cval.p, keep64 ? d->cval64.p : nullptr);
+                                 bm.nnz0, bm.nnz, key_bits, rb_div, rb_bits, d->crow.p, d->cval.p, keep64 ? d->cval64.p : nullptr);
             int32_t nc = 0;
             if (he == hipSuccess) he = hipMemcpy(&nc, sc.count, sizeof nc, hipMemcpyDeviceToHost);
             if (he == hipSuccess) {
@@ -325,13 +370,21 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
                 delete d;
                 return fail(FMHIP_ERR_HIP, "device transpose of batch %lld failed: %s", (long long)b, hipGetErrorString(he));
             }
-            finish_batch_meta(hb, bm.nnz);
+            finish_batch_meta(hb, bm.nnz, cnt, base);
         }
     }
-    std::vector<int32_t> cfeat, cptr, range_seg, split_seg;
+    std::vector<int32_t> cfeat, cptr, range_seg, split_seg, cdst, mp_feat, mp_ptr;
     for (int64_t b = 0; b < nb; ++b) {
         BatchMeta &bm = d->batches[(size_t)b];
         HostBatch &hb = hbs[(size_t)b];
+        bm.n_feats = hb.n_feats;
+        bm.n_mp = (int32_t)hb.mp_feat.size();
+        bm.mp_off = (int64_t)mp_feat.size();
+        bm.n_pieces = hb.n_pieces;
+        d->max_pieces = std::max(d->max_pieces, bm.n_pieces);
+        cdst.insert(cdst.end(), hb.cdst.begin(), hb.cdst.end());
+        mp_feat.insert(mp_feat.end(), hb.mp_feat.begin(), hb.mp_feat.end());
+        mp_ptr.insert(mp_ptr.end(), hb.mp_ptr.begin(), hb.mp_ptr.end());
         bm.n_cols = (int32_t)hb.cfeat.size();
         bm.col_off = (int64_t)cfeat.size();
         bm.n_ranges = (int32_t)hb.range_seg.size();
@@ -350,7 +403,8 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     d->h_split = split_seg;
     if ((rc = upload(d->cfeat, cfeat.data(), cfeat.size())) || (rc = upload(d->cptr, cptr.data(), cptr.size())) ||
         (rc = upload(d->range_seg, range_seg.data(), range_seg.size())) ||
-        (rc = upload(d->split_seg, split_seg.data(), split_seg.size()))) {
+        (rc = upload(d->split_seg, split_seg.data(), split_seg.size())) || (rc = upload(d->cdst, cdst.data(), cdst.size())) ||
+        (rc = upload(d->mp_feat, mp_feat.data(), mp_feat.size())) || (rc = upload(d->mp_ptr, mp_ptr.data(), mp_ptr.size()))) {
         delete d;
         return rc;
     }
@@ -379,6 +433,7 @@ int ensure_workspace(fmhip_model_t m, fmhip_dataset_t d) {
     TRY(m->P.ensure((size_t)std::max<int64_t>(d->max_rows, 1) * m->Kp));
     TRY(m->e.ensure((size_t)std::max<int64_t>(d->max_rows, 1)));
     TRY(m->part.ensure((size_t)std::max<int32_t>(d->max_ranges, 1) * 2 * (m->Kp + kPartPad)));
+    TRY(m->pieces.ensure((size_t)std::max<int32_t>(d->max_pieces, 1) * (m->Kp + kPartPad)));
     TRY(m->bsum.ensure((size_t)kMaxFwdBlocks * 4));
     return FMHIP_OK;
 }
@@ -425,12 +480,18 @@ BwdArgs bwd_args(fmhip_model_t m, fmhip_dataset_t d, int64_t b) {
     a.cval = d->cval.p + bm.nnz0;
     a.range_seg = d->range_seg.p + bm.range_off;
     a.cfeat = d->cfeat.p + bm.col_off;
+    a.cdst = d->cdst.p + bm.col_off;
+    a.pieces = m->pieces.p;
+    a.mp_feat = d->mp_feat.p + bm.mp_off;
+    a.mp_ptr = d->mp_ptr.p + bm.mp_off + b;
+    a.n_mp = bm.n_mp;
     a.cptr = d->cptr.p + bm.col_off + b;
     a.split_seg = d->split_seg.p + bm.split_off;
     a.nnz = bm.nnz;
     a.n_ranges = bm.n_ranges;
     a.rho_lo = 0;
     a.rho_hi = bm.n_ranges;
+    a.xcd_chunk = g_tune[kTuneXcd] > 0 ? 1 : 0;
     a.n_split = bm.n_split;
     a.P = m->P.p;
     {
@@ -474,6 +535,28 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
                   double *acc) {
     const BatchMeta &bm = d->batches[(size_t)b];
     BwdArgs ba = bwd_args(m, d, b);
+    const bool whole = feat_lo <= 0 && feat_hi >= m->n1;
+    if (d->rb_rows > 0 && !whole)
+        return fail(FMHIP_ERR_UNSUPPORTED, "feature-interval backward is not available on a row-blocked dataset");
+    if (whole) {   // the common case needs no host-side searches
+        if (finish) {
+            ba.red_bsum = m->bsum.p;
+            ba.red_nblocks = fwd_partials(m, bm.rows);
+            ba.red_rows = (int32_t)bm.rows;
+            ba.red_scal = m->scal();
+            ba.red_acc = acc;
+        }
+        {
+            ProfScope ps(m, FMHIP_K_BACKWARD, bm.nnz, bm.rows);
+            HIP_TRY(launch_backward(m->Kp, ba, m->stream));
+        }
+        {
+            ProfScope ps(m, FMHIP_K_FIXUP, bm.nnz, bm.rows);
+            HIP_TRY(launch_fixup(m->Kp, ba, m->stream));
+            HIP_TRY(launch_fixup2(m->Kp, ba, m->stream));
+        }
+        return FMHIP_OK;
+    }
     const int32_t *hf = d->h_cfeat.data() + bm.col_off, *hp = d->h_cptr.data() + bm.col_off + b;
     const int32_t *hs = d->h_split.data() + bm.split_off;
     const int32_t s_lo = (int32_t)(std::lower_bound(hf, hf + bm.n_cols, (int32_t)std::min<int64_t>(feat_lo, INT32_MAX)) - hf);
@@ -745,7 +828,7 @@ int fmhip_dataset_batch_info(fmhip_dataset_t d, int64_t batch, int64_t *row0, in
     if (row0) *row0 = bm.row0;
     if (rows) *rows = bm.rows;
     if (nnz) *nnz = bm.nnz;
-    if (n_columns) *n_columns = bm.n_cols;
+    if (n_columns) *n_columns = bm.n_feats;
     return FMHIP_OK;
 }
 
@@ -755,16 +838,32 @@ int fmhip_dataset_get_transpose(fmhip_dataset_t d, int64_t batch, int32_t *feat,
     TRY(check_batch(d, batch));
     TRY(set_device(d->device));
     const BatchMeta &bm = d->batches[(size_t)batch];
-    if (feat && bm.n_cols)
-        HIP_TRY(hipMemcpy(feat, d->cfeat.p + bm.col_off, (size_t)bm.n_cols * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (ptr)
-        HIP_TRY(hipMemcpy(ptr, d->cptr.p + bm.col_off + batch, ((size_t)bm.n_cols + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (rows && bm.nnz) {
-        HIP_TRY(hipMemcpy(rows, d->crow.p + bm.nnz0, (size_t)bm.nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
-        for (int32_t p = 0; p < bm.nnz; ++p) rows[p] &= 0x7fffffff;
+    // read the stream back and merge the pieces of a feature (one per row block, in row-block = row
+    // order) so the caller sees one column per feature whatever the device layout
+    std::vector<int32_t> hrow((size_t)bm.nnz);
+    std::vector<float> hval((size_t)bm.nnz);
+    if (bm.nnz) {
+        HIP_TRY(hipMemcpy(hrow.data(), d->crow.p + bm.nnz0, (size_t)bm.nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hval.data(), d->cval.p + bm.nnz0, (size_t)bm.nnz * sizeof(float), hipMemcpyDeviceToHost));
     }
-    if (vals && bm.nnz)
-        HIP_TRY(hipMemcpy(vals, d->cval.p + bm.nnz0, (size_t)bm.nnz * sizeof(float), hipMemcpyDeviceToHost));
+    const int32_t *hf = d->h_cfeat.data() + bm.col_off, *hp = d->h_cptr.data() + bm.col_off + batch;
+    std::vector<int32_t> order((size_t)bm.n_cols);
+    for (int32_t s = 0; s < bm.n_cols; ++s) order[(size_t)s] = s;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return hf[x] < hf[y]; });
+    int32_t nf = 0, pos = 0;
+    for (int32_t i = 0; i < bm.n_cols; ++i) {
+        const int32_t s = order[(size_t)i];
+        if (i == 0 || hf[s] != hf[order[(size_t)i - 1]]) {
+            if (feat) feat[nf] = hf[s];
+            if (ptr) ptr[nf] = pos;
+            ++nf;
+        }
+        for (int32_t p = hp[s]; p < hp[s + 1]; ++p, ++pos) {
+            if (rows) rows[pos] = hrow[(size_t)p] & 0x7fffffff;
+            if (vals) vals[pos] = hval[(size_t)p];
+        }
+    }
+    if (ptr) ptr[nf] = pos;
     return FMHIP_OK;
 }
 

@@ -150,6 +150,50 @@ def test_kernel_variants_agree_with_the_oracle(fmhip, fwd, bwd, tile):
         L.fmhip_tune(0, 0), L.fmhip_tune(1, 1), L.fmhip_tune(2, 0)
 
 
+@pytest.mark.parametrize("rb", [64, 100, 1000])
+def test_row_blocked_transposes(fmhip, rb):
+    """fmhip_tune(3, rb): the batch transposes are sorted by (row block of `rb` rows, feature); a
+    feature occurring in several blocks is cut into pieces summed by k_fixup2.  Same gradient (to fp32
+    reassociation), same transposes through the read-back API, deterministic."""
+    from sparkfm_amd import _ffi
+    L = _ffi.load()
+    try:
+        L.fmhip_tune(3, rb)
+        for k in (8, 32, 64):
+            a = random_problem(700 + k, 900, 150, k, 0, 25, empty_rows=(2, 450))
+            for r in range(900):                                    # feature 1 in (almost) every row: many pieces
+                s = slice(a["row_ptr"][r], a["row_ptr"][r + 1])
+                if s.stop > s.start and not (a["col"][s] == 1).any():
+                    a["col"][s.start] = 1
+            a["val"] = a["val"].astype(np.float32).astype(np.float64)
+            ds, fm = make(fmhip, a, batch_rows=400)
+            for b in range(3):
+                r0, r1 = b * 400, min(900, (b + 1) * 400)
+                sub = a["row_ptr"][r0:r1 + 1] - a["row_ptr"][r0]
+                sl = slice(a["row_ptr"][r0], a["row_ptr"][r1])
+                cp, rows, cv = oracle.transpose(a["n1"], sub, a["col"][sl], a["val"][sl])
+                feat, ptr, drows, dvals = ds.transposeInput(b)
+                present = np.nonzero(np.diff(cp))[0]
+                np.testing.assert_array_equal(feat, present.astype(np.int32))
+                np.testing.assert_array_equal(drows, rows)
+                np.testing.assert_array_equal(dvals.astype(np.float64), cv)
+                gv, gw, g0, st = fm.batchGradient(ds, b)
+                ogv, ogw, og0, osse, _ = oracle.batch_grad(a["w0"], a["w"], a["v"], r0, r1, a["row_ptr"], a["col"],
+                                                           a["val"], a["y"])
+                check_grad(gv, gw, ogv, ogw, np.abs(a["v"]).max())
+                gv2, gw2, _, _ = fm.batchGradient(ds, b)
+                np.testing.assert_array_equal(gv, gv2)
+            sgd = fmhip.HipSGD(eta=0.03, regv=1e-3)
+            sgd.learn(fm, ds)
+            w0, w, v, sse = oracle.sgd_epoch(a["w0"], a["w"], a["v"], 400, a["row_ptr"], a["col"], a["val"], a["y"],
+                                             0.03, 0.0, 0.0, 1e-3)
+            assert np.linalg.norm(fm.v - v) <= 1e-5 * np.linalg.norm(v)
+            ds.unpersist()
+            fm.close()
+    finally:
+        L.fmhip_tune(3, 0)
+
+
 def test_transpose_is_bit_exact(fmhip):
     """The device-resident per-batch transposes (S/DataSet.scala:31-38) against the oracle's:
     feature ids, row ids and values must match exactly (index gathers are bit-exact)."""

@@ -19,12 +19,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fwd", default="0")
-    ap.add_argument("--bwd", default="0")
+    ap.add_argument("--bwd", default="1")
     ap.add_argument("--config", default="C3")
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--batch-rows", type=int, default=131072)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--k", type=int, default=0)
+    ap.add_argument("--row-block", type=int, default=0, help="rows per row block of the transposes (fmhip_tune key 3)")
+    ap.add_argument("--xcd", type=int, default=0, help="XCD-aware workgroup placement in the backward (fmhip_tune key 4)")
     ap.add_argument("--tile", type=int, default=0, help="LDS V-tile rows for forward variant 20 (0 = auto: 128 KiB)")
     args = ap.parse_args()
     from sparkfm_amd import DataSet, FMModel, _ffi, synth
@@ -34,6 +36,8 @@ def main():
     d = synth.make_config(args.config, rows=rows)
     n1 = cfg["features"]
     w0, w, v = synth.init_params(1, n1, k)
+    if args.row_block:
+        _ffi.load().fmhip_tune(3, args.row_block)
     ds = DataSet.from_arrays(d, batch_rows=min(args.batch_rows, rows)).cache()
     fm = FMModel(n1 - 1, k)
     fm.w0, fm.w, fm.v = w0, w, v
@@ -41,6 +45,8 @@ def main():
     hm, hd, nb = fm.handle, ds.handle, ds.n_batches
     if args.tile:
         L.fmhip_tune(2, args.tile)
+    if args.xcd:
+        L.fmhip_tune(4, args.xcd)
     variants = list(itertools.product([int(x) for x in args.fwd.split(",")], [int(x) for x in args.bwd.split(",")]))
     res = {vv: [] for vv in variants}
     for rnd in range(args.rounds + 1):
