@@ -15,7 +15,6 @@
 #include <cstring>
 #include <new>
 #include <string>
-#include <thread>
 #include <vector>
 
 using namespace fmhip;

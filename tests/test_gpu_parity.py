@@ -528,3 +528,45 @@ def test_fit_loop_like_the_reference(fmhip):
         w0, w, v, _ = oracle.sgd_epoch(w0, w, v, 1000, d["row_ptr"], d["col"], val, y, 0.1, 0.0, 1e-4, 1e-4, threads=4)
     np.testing.assert_allclose(trainer.rmse_history, hist, rtol=1e-5)
     assert np.linalg.norm(fm.v - v) <= 1e-4 * np.linalg.norm(v)
+
+
+def test_random_shapes_property(fmhip):
+    """Property test over random shapes (hypothesis-style, fixed seeds so the GPU box runs the same
+    cases): rows/features/k/batch size/row-length law vary; GPU gradient and one SGD epoch vs the oracle."""
+    rng = np.random.default_rng(20261003)
+    for case in range(24):
+        k = int(rng.choice([1, 2, 5, 8, 13, 16, 32, 40, 64]))
+        n_rows = int(rng.integers(1, 1200))
+        n1 = int(rng.integers(2, 400))
+        hi = int(rng.integers(1, min(n1, 70) + 1))
+        lo = int(rng.integers(0, hi + 1))
+        batch_rows = int(rng.choice([0, 1, 7, 64, 300, 5000]))
+        a = random_problem(1000 + case, n_rows, n1, k, lo, hi, empty_rows=tuple(rng.integers(0, n_rows, 2).tolist()))
+        if case % 3 == 0 and len(a["col"]):                          # a few dominating features
+            hot = rng.integers(0, n1, 2)
+            for r in range(n_rows):
+                s = slice(a["row_ptr"][r], a["row_ptr"][r + 1])
+                if s.stop - s.start >= 2 and not np.isin(hot, a["col"][s]).any():
+                    a["col"][s.start] = hot[0]
+        ds, fm = make(fmhip, a, batch_rows=batch_rows)
+        info = ds.info()
+        nb = info["n_batches"]
+        b = int(rng.integers(0, nb))
+        bi = ds.batch_info(b)
+        r0, r1 = bi["row0"], bi["row0"] + bi["rows"]
+        gv, gw, g0, st = fm.batchGradient(ds, b)
+        ogv, ogw, og0, osse, _ = oracle.batch_grad(a["w0"], a["w"], a["v"], r0, r1, a["row_ptr"], a["col"], a["val"], a["y"])
+        check_grad(gv, gw, ogv, ogw, np.abs(a["v"]).max())
+        assert st["rows"] == r1 - r0 and st["sse"] == pytest.approx(osse, rel=1e-5, abs=1e-9), case
+        br = info["batch_rows"]
+        eta = 0.02 if br >= 64 else 0.001                            # per-row SGD on long rows diverges at 0.02
+        sgd = fmhip.HipSGD(eta=eta, reg0=0.01, regw=0.01, regv=0.01)
+        sgd.learn(fm, ds)
+        w0, w, v, sse = oracle.sgd_epoch(a["w0"], a["w"], a["v"], br, a["row_ptr"], a["col"], a["val"], a["y"],
+                                         eta, 0.01, 0.01, 0.01)
+        assert np.isfinite(v).all(), (case, "oracle diverged: pick a smaller eta for this case")
+        assert np.linalg.norm(fm.v - v) <= 1e-5 * max(np.linalg.norm(v), 1e-9), (case, k, n_rows, n1, batch_rows)
+        assert np.linalg.norm(fm.w - w) <= 1e-5 * max(np.linalg.norm(w), 1e-9), case
+        assert fm.w0 == pytest.approx(w0, rel=1e-5, abs=1e-7), case
+        ds.unpersist()
+        fm.close()
