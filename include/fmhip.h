@@ -78,10 +78,12 @@ int fmhip_version(void);
 const char *fmhip_last_error(void);
 int fmhip_device_count(int *count);
 /* tuning knobs (process-wide; results are identical across variants up to fp32 rounding):
- *   key 0  forward kernel : 0 = global-memory gathers (default), 20 = LDS V-tile (rows of the hottest,
- *                           i.e. lowest-id, features staged in LDS; ids must be frequency-ranked to benefit)
+ *   key 0  forward kernel : 60 = LDS w-tile (default: the linear weights of the 6144 lowest feature ids
+ *                           are staged in LDS), 0 = plain global-memory gathers, 20 = LDS V-tile (rows of
+ *                           the lowest-id features of V staged in LDS); the tiles only help when ids are
+ *                           frequency-ranked (hot = low id), results are the same either way
  *   key 1  backward kernel: 1 = pipelined buffer-load walk (default), 0 = plain walk
- *   key 2  LDS V-tile rows: 0 = auto (as many rows as fit 128 KiB)
+ *   key 2  LDS tile rows : 0 = auto (V-tile: as many rows as fit 128 KiB; w-tile: 6144)
  *   key 3  rows per row block of the transposes built by the NEXT fmhip_dataset_create (0 = off):
  *          entries sorted by (row block, feature) so a block's slice of P stays L2-resident in the
  *          backward; features occurring in several blocks are summed by an extra fixup pass */

@@ -20,6 +20,7 @@ int padded_factors(int k);
 constexpr int kMaxFwdBlocks = 16384;
 int forward_blocks(int Kp, int64_t n_rows);
 int forward_blocks_lds(int64_t n_rows);
+int forward_blocks_wt(int Kp, int64_t n_rows);    // grid of the w-tile forward
 int forward_blocks_r(int Kp, int64_t n_rows, int rows_per_slot);   // grid of the rolling-prefetch forward   // grid of the LDS V-tile forward
 
 enum FwdMode { kFwdTrain = 0, kFwdResidual = 1, kFwdQ = 2 };
@@ -40,6 +41,7 @@ struct FwdArgs {
     float *yhat;  // optional [rows]
     double *bsum; // optional [forward_blocks][4] per-block {sum e, sum e^2, nonfinite, 0}
     int32_t tile_rows; // LDS V-tile: rows of V (feature ids < tile_rows) staged in LDS; 0 = off
+    int32_t wt_rows;   // LDS w-tile: linear weights of feature ids < wt_rows staged in LDS
 };
 
 struct BwdArgs {

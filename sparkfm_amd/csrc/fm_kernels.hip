@@ -21,12 +21,18 @@
 
 namespace fmhip {
 
-int g_tune[kTuneCount] = {0, 1, 0, 0, 0};   // forward: flat kernel; backward: pipelined; tile rows: auto; row blocks: off   // forward: flat-load kernel; backward: pipelined kernel (measured 12 % faster)
+int g_tune[kTuneCount] = {60, 1, 0, 0, 0};   // forward: w-tile kernel; backward: pipelined kernel   // forward: flat kernel; backward: pipelined; tile rows: auto; row blocks: off   // forward: flat-load kernel; backward: pipelined kernel (measured 12 % faster)
 
 int padded_factors(int k) {
     int kp = 4;
     while (kp < k) kp <<= 1;
     return kp;
+}
+
+int forward_blocks_wt(int Kp, int64_t n_rows) {
+    // persistent: at most 5 workgroups of 256 threads per CU (24 KiB of LDS each), rows grid-strided
+    const int64_t need = forward_blocks(Kp, n_rows);
+    return (int)(need < 256 * 5 ? need : 256 * 5);
 }
 
 int forward_blocks_lds(int64_t n_rows) {
@@ -237,6 +243,114 @@ __global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
                 c = stream_load(a.col + p);
                 x = stream_load(a.val + p);
                 lin = fmaf(a.w[c], x, lin);
+            }
+            const int cnt = (int)((p1 - base) < (int64_t)LPN ? (p1 - base) : (int64_t)LPN);
+#pragma unroll
+            for (int c0 = 0; c0 < LPN; c0 += CH) {
+                float4 t[CH][J];
+                float xs[CH];
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int cj = __shfl(c, c0 + j, LPN);
+                    xs[j] = __shfl(x, c0 + j, LPN);
+                    const float4 *vr = reinterpret_cast<const float4 *>(a.V + (size_t)cj * KP) + l;
+#pragma unroll
+                    for (int jj = 0; jj < J; ++jj) t[j][jj] = vr[jj * LPN];
+                }
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const bool live = c0 + j < cnt;
+#pragma unroll
+                    for (int jj = 0; jj < J; ++jj) {
+                        float4 tv = f4mul(t[j][jj], xs[j]);
+                        if (!live) tv = f4zero();
+                        f4add(q[jj], tv);       // q_f accumulates in stored order (FMModel.scala:59)
+                        f4sqacc(s[jj], tv);     // sum_sqr_f (FMModel.scala:60)
+                    }
+                }
+            }
+        }
+        float u = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) u += f4sqminus(q[jj], s[jj]);
+        float tot = fmaf(0.5f, u, lin);
+#pragma unroll
+        for (int m = LPN >> 1; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, LPN);
+        const float yhat = w0 + tot;
+        const float e = yhat - a.y[a.row0 + r];
+        if (MODE == kFwdTrain) {
+            float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) pr[jj * LPN] = f4mul(q[jj], e);
+        } else if (MODE == kFwdQ) {
+            float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) pr[jj * LPN] = q[jj];
+        }
+        if (l == 0) {
+            if (a.e) a.e[r] = e;
+            if (a.yhat) a.yhat[r] = yhat;
+            st1 += e;
+            st2 = fmaf(e, e, st2);
+            if (!isfinite(e)) stbad += 1.f;
+        }
+    }
+    // block partial of the residual statistics (fixed order; k_reduce_blocks finishes the sum)
+    if (a.bsum) {
+        __shared__ double sh[3][kBlock / 64];
+        double d1 = st1, d2 = st2, db = stbad;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            d1 += __shfl_xor(d1, m, 64);
+            d2 += __shfl_xor(d2, m, 64);
+            db += __shfl_xor(db, m, 64);
+        }
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { sh[0][wv] = d1; sh[1][wv] = d2; sh[2][wv] = db; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t1 = 0.0, t2 = 0.0, tb = 0.0;
+#pragma unroll
+            for (int i = 0; i < kBlock / 64; ++i) { t1 += sh[0][i]; t2 += sh[1][i]; tb += sh[2][i]; }
+            double *o = a.bsum + (size_t)blockIdx.x * 4;
+            o[0] = t1; o[1] = t2; o[2] = tb; o[3] = 0.0;
+        }
+    }
+}
+
+// k_forward with an LDS-resident tile of the hot linear weights (see the comment in the body)
+template <int LPN, int J, int MODE>
+__global__ __launch_bounds__(kBlock) void k_forward_wt(FwdArgs a) {
+    constexpr int KP = 4 * LPN * J;
+    constexpr int SLOTS = kBlock / LPN;
+    constexpr int CH = (LPN * J > 16) ? (16 / J) : LPN;  // entries whose V rows are in flight together
+    const int l = threadIdx.x & (LPN - 1);
+    const int slot = threadIdx.x / LPN;
+    const float w0 = *a.w0;
+    // w-tile: the linear weights of the wt_rows lowest (= hottest, for frequency-ranked ids) feature
+    // ids live in LDS.  A 64-lane gather of w costs ~2 TA cycles per distinct line touched — as much
+    // per nonzero as the whole 128-B V-row gather (profiles/r01_experiments.md §13); lanes whose id is
+    // in the tile read LDS instead and drop out of the global gather.
+    extern __shared__ __attribute__((aligned(16))) float wt[];
+    const int T = a.wt_rows;
+    for (int i = threadIdx.x; i < T; i += kBlock) wt[i] = a.w[i];
+    __syncthreads();
+    float st1 = 0.f, st2 = 0.f, stbad = 0.f;   // this thread's share of {sum e, sum e^2, nonfinite}
+    for (int r = blockIdx.x * SLOTS + slot; r < a.n_rows; r += gridDim.x * SLOTS) {
+        const int64_t p0 = a.row_ptr[a.row0 + r], p1 = a.row_ptr[a.row0 + r + 1];
+        float4 q[J], s[J];
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) { q[jj] = f4zero(); s[jj] = f4zero(); }
+        float lin = 0.f;
+        for (int64_t base = p0; base < p1; base += LPN) {
+            const int64_t p = base + l;
+            int c = 0;
+            float x = 0.f;
+            if (p < p1) {
+                c = stream_load(a.col + p);
+                x = stream_load(a.val + p);
+                const float wv = c < T ? wt[c] : a.w[c];
+                lin = fmaf(wv, x, lin);
             }
             const int cnt = (int)((p1 - base) < (int64_t)LPN ? (p1 - base) : (int64_t)LPN);
 #pragma unroll
@@ -815,7 +929,20 @@ template <int LPN, int J>
 hipError_t fwd_dispatch(FwdMode mode, const FwdArgs &a, hipStream_t s) {
     int64_t blocks = forward_blocks(4 * LPN * J, a.n_rows);
     dim3 g((unsigned)blocks), b(kBlock);
-    const int var = a.v_bytes ? g_tune[kTuneFwd] : 0;    // the LDS-tile kernel needs V to fit a 32-bit buffer view
+    int var = g_tune[kTuneFwd];
+    if (var == 20 && !a.v_bytes) var = 0;    // the LDS V-tile kernel needs V to fit a 32-bit buffer view
+    if (var == 60 && a.wt_rows > 0) {
+        const size_t lds_bytes = (size_t)a.wt_rows * sizeof(float);
+        int64_t nb = forward_blocks_wt(4 * LPN * J, a.n_rows);
+        dim3 gw((unsigned)nb);
+        hipError_t e = hipSuccess;
+        switch (mode) {
+            case kFwdTrain: hipLaunchKernelGGL((k_forward_wt<LPN, J, kFwdTrain>), gw, b, lds_bytes, s, a); break;
+            case kFwdResidual: hipLaunchKernelGGL((k_forward_wt<LPN, J, kFwdResidual>), gw, b, lds_bytes, s, a); break;
+            case kFwdQ: hipLaunchKernelGGL((k_forward_wt<LPN, J, kFwdQ>), gw, b, lds_bytes, s, a); break;
+        }
+        return e != hipSuccess ? e : hipGetLastError();
+    }
     if (var == 20 && a.tile_rows > 0) {
         const size_t lds_bytes = (size_t)a.tile_rows * (4 * LPN * J + 1) * sizeof(float);
         dim3 gl((unsigned)forward_blocks_lds(a.n_rows)), bl(kLdsBlock);

@@ -441,6 +441,7 @@ int ensure_workspace(fmhip_model_t m, fmhip_dataset_t d) {
 int fwd_partials(fmhip_model_t m, int64_t rows) {
     const uint64_t vb = (uint64_t)m->n1p * m->Kp * sizeof(float);
     if (g_tune[kTuneFwd] == 20 && vb < 0xffffffffull) return forward_blocks_lds(rows);
+    if (g_tune[kTuneFwd] == 60) return forward_blocks_wt(m->Kp, rows);
     return forward_blocks(m->Kp, rows);
 }
 
@@ -468,6 +469,7 @@ FwdArgs fwd_args(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm) {
         int64_t t = (128 * 1024) / ((int64_t)m->Kp * 4);
         if (g_tune[kTuneTile] > 0) t = g_tune[kTuneTile];
         a.tile_rows = (int32_t)std::min<int64_t>(t, m->n1);
+        a.wt_rows = (int32_t)std::min<int64_t>(g_tune[kTuneTile] > 0 ? g_tune[kTuneTile] : 6144, m->n1);   // 24 KiB
     }
     return a;
 }

@@ -118,7 +118,7 @@ def test_forward_and_gradient_vs_oracle(fmhip, k):
     fm.close()
 
 
-@pytest.mark.parametrize("fwd,bwd,tile", [(20, 1, 0), (20, 1, 16), (0, 0, 0)])
+@pytest.mark.parametrize("fwd,bwd,tile", [(20, 1, 0), (20, 1, 16), (0, 0, 0), (60, 1, 0), (60, 1, 50)])
 def test_kernel_variants_agree_with_the_oracle(fmhip, fwd, bwd, tile):
     """fmhip_tune: the LDS V-tile forward (ids < tile rows come from LDS, the rest from global
     memory) and the plain backward walk give the same results as the default kernels."""
@@ -147,7 +147,7 @@ def test_kernel_variants_agree_with_the_oracle(fmhip, fwd, bwd, tile):
             ds.unpersist()
             fm.close()
     finally:
-        L.fmhip_tune(0, 0), L.fmhip_tune(1, 1), L.fmhip_tune(2, 0)
+        L.fmhip_tune(0, 60), L.fmhip_tune(1, 1), L.fmhip_tune(2, 0)
 
 
 @pytest.mark.parametrize("rb", [64, 100, 1000])
