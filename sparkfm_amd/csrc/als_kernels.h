@@ -9,6 +9,7 @@ struct AlsArgs {
     int32_t k;
     int64_t num_attribute;   // loop bound of the sweeps (arrays have num_attribute + 1 slots)
     int64_t n_rows;
+    int64_t nnz;
     // rows (CSR, stored order) — fp64 values
     const int64_t *row_ptr;
     const int32_t *col;

@@ -1035,6 +1035,7 @@ int fmhip_als_epoch(fmhip_model_t m, fmhip_dataset_t d, double reg0, double regw
         a.k = m->k;
         a.num_attribute = m->n;
         a.n_rows = d->n_rows;
+        a.nnz = d->nnz;
         a.row_ptr = d->row_ptr.p;
         a.col = d->col.p;
         a.val = d->val64.p;
