@@ -8,6 +8,7 @@ Tolerances (fp32 device arithmetic vs the fp64 oracle on identical inputs; SURVE
   parameters after T <= 20 steps: rel-L2 <= 1e-4 (measured ~1e-6; SURVEY proposed 1e-3)
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -570,3 +571,52 @@ def test_random_shapes_property(fmhip):
         assert fm.w0 == pytest.approx(w0, rel=1e-5, abs=1e-7), case
         ds.unpersist()
         fm.close()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_two_ranks_on_one_gpu(fmhip, tmp_path, overlap):
+    """The real data-parallel path with TWO processes (both on cuda:0, collective over gloo): HipEngine,
+    feature-chunked backward + async all-reduces (overlap) or one all-reduce per step, uneven shards
+    (rank 1 runs out of batches first and contributes zero gradients).  Replicas must end bit-identical
+    and match the oracle run over the equivalent global batches."""
+    import socket
+    import subprocess
+    import sys
+    from sparkfm_amd import synth
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    out = str(tmp_path / "dp")
+    here = os.path.dirname(os.path.abspath(__file__))
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "dist_gpu_worker.py"), str(r), "2", port, out,
+                               "1" if overlap else "0"]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
+    np.testing.assert_array_equal(r0["v"], r1["v"])
+    np.testing.assert_array_equal(r0["w"], r1["w"])
+    assert float(r0["w0"]) == float(r1["w0"])
+    if overlap:
+        assert list(r0["cuts"]) == list(r1["cuts"]) and r0["cuts"][0] == 0 and r0["cuts"][-1] == 800 and len(r0["cuts"]) == 3
+    # oracle: global batch j = rank0's batch j  U  rank1's batch j (rank 1 has 3 batches, rank 0 has 3)
+    shards = [synth.make_zipf(77, 3000, 800, 4, 24, zipf_s=1.05, row_begin=0),
+              synth.make_zipf(77, 2200, 800, 4, 24, zipf_s=1.05, row_begin=3000)]
+    w0, w, v = synth.init_params(5, 800, 32, stdev=0.05)
+    for _ in range(2):
+        for j in range(3):
+            rp, cols, vals, ys = [0], [], [], []
+            for d in shards:
+                n = len(d["y"])
+                b0, b1 = j * 1000, min(n, (j + 1) * 1000)
+                for r in range(b0, max(b0, b1)):
+                    a, b = d["row_ptr"][r], d["row_ptr"][r + 1]
+                    cols.append(d["col"][a:b])
+                    vals.append(d["val"][a:b].astype(np.float64))
+                    rp.append(rp[-1] + (b - a))
+                    ys.append(float(d["y"][r]))
+            w0, w, v, _ = oracle.sgd_step(w0, w, v, 0, len(ys), np.array(rp, np.int64), np.concatenate(cols),
+                                          np.concatenate(vals), np.array(ys), 0.05, 0.0, 1e-3, 1e-3)
+    assert np.linalg.norm(r0["v"] - v) <= 1e-5 * np.linalg.norm(v)
+    assert np.linalg.norm(r0["w"] - w) <= 1e-5 * np.linalg.norm(w)
+    assert float(r0["w0"]) == pytest.approx(w0, rel=1e-5, abs=1e-7)
