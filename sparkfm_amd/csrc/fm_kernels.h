@@ -51,12 +51,14 @@ struct BwdArgs {
     const int32_t *cfeat;      // [n_cols] feature id of compressed column
     const int32_t *cdst;       // [n_cols] >= 0: G row (= feature id) | < 0: piece row -1-dst (feature has several pieces)
     const int32_t *cptr;       // [n_cols+1]
-    const int32_t *split_seg;  // [n_split] compressed columns that span >1 range
+    const int32_t *split_seg;  // [n_split] cut columns spanning > 8 ranges (a wave each in k_fixup)
+    const int32_t *split_short; // [n_split_short] cut columns spanning <= 8 ranges (a slot each)
     int32_t nnz;
     int32_t n_ranges;
     int32_t rho_lo, rho_hi;    // ranges this launch walks (whole batch: 0, n_ranges)
     int32_t xcd_chunk;         // > 0: XCD-aware workgroup placement (set by the launcher)
     int32_t n_split;
+    int32_t n_split_short;
     const float *P;            // [rows][Kp]
     uint32_t p_bytes;          // size of P in bytes, or 0 if it does not fit a 32-bit buffer descriptor
     const float *e;            // [rows]

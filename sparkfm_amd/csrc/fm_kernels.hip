@@ -791,52 +791,90 @@ __global__ __launch_bounds__(kBlock) void k_backward_p(BwdArgs a) {
     }
 }
 
-// One wave per column whose entries were cut into several partials.  The column [ca, cb)
-// spans ranges ra..rb; its units are, in order: the ranges before the first wave-aligned
-// range, one wave-sum per wave lying wholly inside the column, the ranges after the last such
-// wave.  Units are taken slot-strided (4 in flight per slot) and tree-summed: a fixed order,
-// so results are run-to-run identical.
+// Sums the partials of the columns that were cut across ranges.  The column [ca, cb) spans ranges
+// ra..rb; its units are, in order: the ranges before the first wave-aligned range, one wave-sum per
+// wave lying wholly inside the column, the ranges after the last such wave.
+//   * columns spanning <= 8 ranges (the vast majority: short columns straddling a boundary) are
+//     summed by ONE SLOT each, units in order;
+//   * longer columns by a whole workgroup: units strided over its slots (4 in flight per slot),
+//     tree-summed per wave, the wave sums added in wave order.
+// Both are fixed orders, so results are run-to-run identical.  The last block of the launch
+// optionally finishes the step's residual statistics.
+template <int LPN, int J>
+struct ColumnUnits {
+    static constexpr int KP = 4 * LPN * J;
+    static constexpr int PR = KP + kPartPad;
+    static constexpr int WS = 64 / LPN;
+    static constexpr int WSPAN = WS * kRangeLen;
+    int ca, ra, w_lo, nw, nl, r2, count;
+    __device__ __forceinline__ ColumnUnits(int ca_, int cb) : ca(ca_) {
+        ra = ca / kRangeLen;
+        const int rb = (cb - 1) / kRangeLen;
+        w_lo = (ca + WSPAN - 1) / WSPAN;
+        const int w_hi = cb / WSPAN;                              // clean waves [w_lo, w_hi)
+        nw = w_hi > w_lo ? w_hi - w_lo : 0;
+        nl = nw ? w_lo * WS - ra : rb - ra + 1;                   // leading single ranges
+        r2 = w_hi * WS;                                           // first trailing range
+        count = nw ? nl + nw + (rb - r2 + 1) : nl;
+    }
+    __device__ __forceinline__ const float *row(const float *part, int t) const {
+        const int rho = t < nl ? ra + t : (t < nl + nw ? (w_lo + (t - nl)) * WS : r2 + (t - nl - nw));
+        return part + ((size_t)rho * 2 + (ca >= rho * kRangeLen ? 1 : 0)) * PR;
+    }
+};
+
 template <int LPN, int J>
 __global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
     constexpr int KP = 4 * LPN * J;
-    constexpr int PR = KP + kPartPad;
+    constexpr int SLOTS = kBlock / LPN;
     constexpr int WS = 64 / LPN;
-    constexpr int WSPAN = WS * kRangeLen;
-    const int lane = threadIdx.x & 63;
-    const int l = lane & (LPN - 1);
-    const int ws = lane / LPN;
     if (a.red_bsum && blockIdx.x == gridDim.x - 1) {
         // the extra last block finishes the residual statistics of this step (saves a launch)
         __shared__ double sh[3][kBlock / 64];
         reduce_blocks_body(a.red_bsum, a.red_nblocks, a.red_rows, a.red_scal, a.red_acc, sh);
         return;
     }
-    const int idx = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    if (idx >= a.n_split) return;
-    const int seg = a.split_seg[idx];
-    const int ca = a.cptr[seg], cb = a.cptr[seg + 1];
-    const int ra = ca / kRangeLen, rb = (cb - 1) / kRangeLen;
-    const int w_lo = (ca + WSPAN - 1) / WSPAN, w_hi = cb / WSPAN;   // clean waves [w_lo, w_hi)
-    const int nw = w_hi > w_lo ? w_hi - w_lo : 0;
-    const int nl = nw ? w_lo * WS - ra : rb - ra + 1;               // leading single ranges
-    const int r2 = w_hi * WS;                                       // first trailing range
-    const int count = nw ? nl + nw + (rb - r2 + 1) : nl;
+    const int lane = threadIdx.x & 63;
+    const int l = lane & (LPN - 1);
     float4 acc[J];
 #pragma unroll
     for (int jj = 0; jj < J; ++jj) acc[jj] = f4zero();
     float sa = 0.f, sb = 0.f;
-    auto unit_row = [&](int t) -> const float * {
-        const int rho = t < nl ? ra + t : (t < nl + nw ? (w_lo + (t - nl)) * WS : r2 + (t - nl - nw));
-        return a.part + ((size_t)rho * 2 + (ca >= rho * kRangeLen ? 1 : 0)) * PR;
-    };
-    int t = ws;
-    for (; t + 3 * WS < count; t += 4 * WS) {
+    const int blocks_short = (a.n_split_short + SLOTS - 1) / SLOTS;
+    if ((int)blockIdx.x < blocks_short) {
+        // ---- one slot per short column
+        const int idx = blockIdx.x * SLOTS + threadIdx.x / LPN;
+        if (idx >= a.n_split_short) return;
+        const int seg = a.split_short[idx];
+        const ColumnUnits<LPN, J> cu(a.cptr[seg], a.cptr[seg + 1]);
+        for (int t = 0; t < cu.count; ++t) {
+            const float *pr = cu.row(a.part, t);
+            const float4 *p4 = reinterpret_cast<const float4 *>(pr) + l;
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) f4add(acc[jj], p4[jj * LPN]);
+            sa += pr[KP];
+            sb += pr[KP + 1];
+        }
+        store_seg<LPN, J>(a, seg, l, acc, sa, sb);
+        return;
+    }
+    // ---- one WORKGROUP per long column: units strided over the 4 waves x WS slots, four in flight per
+    // slot; slots tree-summed inside each wave, the 4 wave sums added in wave order through LDS
+    const int ws = lane / LPN;
+    const int wv = threadIdx.x >> 6;
+    const int idx = (int)blockIdx.x - blocks_short;
+    if (idx >= a.n_split) return;
+    const int seg = a.split_seg[idx];
+    const ColumnUnits<LPN, J> cu(a.cptr[seg], a.cptr[seg + 1]);
+    constexpr int STRIDE = (kBlock / 64) * WS;
+    int t = wv * WS + ws;
+    for (; t + 3 * STRIDE < cu.count; t += 4 * STRIDE) {
         const float *pr[4];
         float4 v[4][J];
         float va[4], vb[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            pr[u] = unit_row(t + u * WS);
+            pr[u] = cu.row(a.part, t + u * STRIDE);
             const float4 *p4 = reinterpret_cast<const float4 *>(pr[u]) + l;
 #pragma unroll
             for (int jj = 0; jj < J; ++jj) v[u][jj] = p4[jj * LPN];
@@ -851,8 +889,8 @@ __global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
             sb += vb[u];
         }
     }
-    for (; t < count; t += WS) {
-        const float *pr = unit_row(t);
+    for (; t < cu.count; t += STRIDE) {
+        const float *pr = cu.row(a.part, t);
         const float4 *p4 = reinterpret_cast<const float4 *>(pr) + l;
 #pragma unroll
         for (int jj = 0; jj < J; ++jj) f4add(acc[jj], p4[jj * LPN]);
@@ -860,7 +898,26 @@ __global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
         sb += pr[KP + 1];
     }
     slots_reduce<LPN, J>(acc, sa, sb);
+    __shared__ float4 wsum[kBlock / 64][J][LPN];
+    __shared__ float wsc[kBlock / 64][2];
     if (ws == 0) {
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) wsum[wv][jj][l] = acc[jj];
+        if (l == 0) { wsc[wv][0] = sa; wsc[wv][1] = sb; }
+    }
+    __syncthreads();
+    if (wv == 0 && ws == 0) {
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) acc[jj] = wsum[0][jj][l];
+        sa = wsc[0][0];
+        sb = wsc[0][1];
+#pragma unroll
+        for (int w2 = 1; w2 < kBlock / 64; ++w2) {
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) f4add(acc[jj], wsum[w2][jj][l]);
+            sa += wsc[w2][0];
+            sb += wsc[w2][1];
+        }
         store_seg<LPN, J>(a, seg, l, acc, sa, sb);
     }
 }
@@ -988,9 +1045,10 @@ hipError_t bwd_dispatch(const BwdArgs &a, hipStream_t s) {
 
 template <int LPN, int J>
 hipError_t fix_dispatch(const BwdArgs &a, hipStream_t s) {
+    constexpr int SLOTS = kBlock / LPN;
     const int extra = a.red_bsum ? 1 : 0;
-    if (a.n_split < 1 && !extra) return hipSuccess;
-    dim3 g((unsigned)((a.n_split + 3) / 4 + extra)), b(kBlock);
+    if (a.n_split < 1 && a.n_split_short < 1 && !extra) return hipSuccess;
+    dim3 g((unsigned)((a.n_split_short + SLOTS - 1) / SLOTS + a.n_split + extra)), b(kBlock);
     hipLaunchKernelGGL((k_fixup<LPN, J>), g, b, 0, s, a);
     return hipGetLastError();
 }

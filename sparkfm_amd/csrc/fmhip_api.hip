@@ -83,8 +83,10 @@ struct BatchMeta {
     int64_t col_off = 0;    // offset into cfeat; cptr offset is col_off + batch index
     int32_t n_ranges = 0;
     int64_t range_off = 0;
-    int32_t n_split = 0;
+    int32_t n_split = 0;          // cut columns spanning > 8 ranges
     int64_t split_off = 0;
+    int32_t n_split_short = 0;    // cut columns spanning <= 8 ranges
+    int64_t split_short_off = 0;
     int32_t n_feats = 0;    // distinct features present (== n_cols unless the stream is row-blocked)
     int32_t n_mp = 0;       // features cut into several pieces (one per row block they occur in)
     int64_t mp_off = 0;     // offset into mp_feat; mp_ptr offset is mp_off + batch index
@@ -110,8 +112,8 @@ struct fmhip_dataset {
     DevBuf<float> val, y;
     DevBuf<uint32_t> crow;
     DevBuf<float> cval;
-    DevBuf<int32_t> cfeat, cptr, range_seg, split_seg, cdst, mp_feat, mp_ptr;
-    std::vector<int32_t> h_cfeat, h_cptr, h_split;   // host copies (feature-chunked backward needs them)
+    DevBuf<int32_t> cfeat, cptr, range_seg, split_seg, split_short, cdst, mp_feat, mp_ptr;
+    std::vector<int32_t> h_cfeat, h_cptr, h_split, h_split_short;   // host copies (feature-chunked backward needs them)
     int64_t rb_rows = 0;       // rows per row block of the transposes (0 = not row-blocked)
     int32_t max_pieces = 0;
     // fp64 copies of the values (CSR order, CSC order) and labels for the fp64 ALS learner; kept only
@@ -185,7 +187,7 @@ int set_device(int device) {
 // ---- dataset construction -------------------------------------------------------
 
 struct HostBatch {
-    std::vector<int32_t> cfeat, cptr, range_seg, split_seg, cdst, mp_feat, mp_ptr;
+    std::vector<int32_t> cfeat, cptr, range_seg, split_seg, split_short, cdst, mp_feat, mp_ptr;
     int32_t n_feats = 0, n_pieces = 0;
 };
 
@@ -229,11 +231,14 @@ void finish_batch_meta(HostBatch &hb, int32_t nnz, std::vector<int32_t> &cnt, st
         hb.range_seg[(size_t)rho] = (int32_t)s;
     }
     hb.split_seg.clear();
+    hb.split_short.clear();
     // the same predicates k_backward applies: a column spanning two ranges whose remainder in the
-    // second is <= kExtend is finished by the first range's slot and needs no fixup
+    // second is <= kExtend is finished by the first range's slot and needs no fixup; the others are
+    // summed by k_fixup, a slot each when they span <= 8 ranges, else a wave each
     for (size_t c = 0; c < nc; ++c) {
         const int32_t ra = hb.cptr[c] / kRangeLen, rb = (hb.cptr[c + 1] - 1) / kRangeLen;
-        if (rb > ra && !(rb == ra + 1 && hb.cptr[c + 1] - rb * kRangeLen <= kExtend)) hb.split_seg.push_back((int32_t)c);
+        if (rb > ra && !(rb == ra + 1 && hb.cptr[c + 1] - rb * kRangeLen <= kExtend))
+            (rb - ra + 1 <= 8 ? hb.split_short : hb.split_seg).push_back((int32_t)c);
     }
 }
 
@@ -372,7 +377,7 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
             finish_batch_meta(hb, bm.nnz, cnt, base);
         }
     }
-    std::vector<int32_t> cfeat, cptr, range_seg, split_seg, cdst, mp_feat, mp_ptr;
+    std::vector<int32_t> cfeat, cptr, range_seg, split_seg, split_short, cdst, mp_feat, mp_ptr;
     for (int64_t b = 0; b < nb; ++b) {
         BatchMeta &bm = d->batches[(size_t)b];
         HostBatch &hb = hbs[(size_t)b];
@@ -390,6 +395,9 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
         bm.range_off = (int64_t)range_seg.size();
         bm.n_split = (int32_t)hb.split_seg.size();
         bm.split_off = (int64_t)split_seg.size();
+        bm.n_split_short = (int32_t)hb.split_short.size();
+        bm.split_short_off = (int64_t)split_short.size();
+        split_short.insert(split_short.end(), hb.split_short.begin(), hb.split_short.end());
         d->max_ranges = std::max(d->max_ranges, bm.n_ranges);
         cfeat.insert(cfeat.end(), hb.cfeat.begin(), hb.cfeat.end());
         cptr.insert(cptr.end(), hb.cptr.begin(), hb.cptr.end());
@@ -400,9 +408,11 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     d->h_cfeat = cfeat;
     d->h_cptr = cptr;
     d->h_split = split_seg;
+    d->h_split_short = split_short;
     if ((rc = upload(d->cfeat, cfeat.data(), cfeat.size())) || (rc = upload(d->cptr, cptr.data(), cptr.size())) ||
         (rc = upload(d->range_seg, range_seg.data(), range_seg.size())) ||
-        (rc = upload(d->split_seg, split_seg.data(), split_seg.size())) || (rc = upload(d->cdst, cdst.data(), cdst.size())) ||
+        (rc = upload(d->split_seg, split_seg.data(), split_seg.size())) ||
+        (rc = upload(d->split_short, split_short.data(), split_short.size())) || (rc = upload(d->cdst, cdst.data(), cdst.size())) ||
         (rc = upload(d->mp_feat, mp_feat.data(), mp_feat.size())) || (rc = upload(d->mp_ptr, mp_ptr.data(), mp_ptr.size()))) {
         delete d;
         return rc;
@@ -488,6 +498,8 @@ BwdArgs bwd_args(fmhip_model_t m, fmhip_dataset_t d, int64_t b) {
     a.n_mp = bm.n_mp;
     a.cptr = d->cptr.p + bm.col_off + b;
     a.split_seg = d->split_seg.p + bm.split_off;
+    a.split_short = d->split_short.p + bm.split_short_off;
+    a.n_split_short = bm.n_split_short;
     a.nnz = bm.nnz;
     a.n_ranges = bm.n_ranges;
     a.rho_lo = 0;
@@ -569,6 +581,13 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
     const int32_t sp_hi = (int32_t)(std::lower_bound(hs, hs + bm.n_split, s_hi) - hs);
     ba.split_seg += sp_lo;
     ba.n_split = sp_hi - sp_lo;
+    {
+        const int32_t *hss = d->h_split_short.data() + bm.split_short_off;
+        const int32_t q_lo = (int32_t)(std::lower_bound(hss, hss + bm.n_split_short, s_lo) - hss);
+        const int32_t q_hi = (int32_t)(std::lower_bound(hss, hss + bm.n_split_short, s_hi) - hss);
+        ba.split_short += q_lo;
+        ba.n_split_short = q_hi - q_lo;
+    }
     if (finish) {
         ba.red_bsum = m->bsum.p;
         ba.red_nblocks = fwd_partials(m, bm.rows);
