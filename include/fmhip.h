@@ -95,6 +95,7 @@ int fmhip_tune(int key, int value);
  * hipStream_t (NULL = the library creates its own non-blocking stream). */
 int fmhip_model_create(int device, int64_t num_attribute, int32_t num_factor, void *stream, fmhip_model_t *out);
 int fmhip_model_destroy(fmhip_model_t m);
+/* padded_factors: floats per device row (whole 128-B lines: 32, 64, 128 or 256) */
 int fmhip_model_info(fmhip_model_t m, int64_t *num_attribute, int32_t *num_factor, int32_t *padded_factors);
 /* w: n+1 doubles, v: k*(n+1) doubles at v[f + i*k]  (FMModel.w0 / .w / .v, S/fm/FMModel.scala:17-19) */
 int fmhip_model_set_params(fmhip_model_t m, double w0, const double *w, const double *v);

@@ -42,6 +42,7 @@ struct FwdArgs {
     double *bsum; // optional [forward_blocks][4] per-block {sum e, sum e^2, nonfinite, 0}
     int32_t tile_rows; // LDS V-tile: rows of V (feature ids < tile_rows) staged in LDS; 0 = off
     int32_t wt_rows;   // LDS w-tile: linear weights of feature ids < wt_rows staged in LDS
+    int32_t pack_k;    // >= 0: packed rows — slot pack_k of a V row is w_i, of a P row is e (k < Kp); -1: off
 };
 
 struct BwdArgs {
@@ -70,6 +71,7 @@ struct BwdArgs {
     const int32_t *mp_feat;    // [n_mp] features with several pieces
     const int32_t *mp_ptr;     // [n_mp + 1] their piece-row intervals
     int32_t n_mp;
+    int32_t pack_k;            // >= 0: packed rows (see FwdArgs)
     // optional: k_fixup's extra last block also sums the forward's per-block statistics
     const double *red_bsum;
     int32_t red_nblocks, red_rows;
@@ -82,6 +84,7 @@ struct ApplyArgs {
     float *GV, *Gw, *Gb;
     const float *scal;  // {sum e, sum e^2, rows, ...}
     int64_t n1;         // n+1 (rows of V actually used)
+    int32_t pack_k;     // >= 0: packed rows — slot pack_k of a V row is the linear weight
     float eta, reg0, regw, regv;
 };
 

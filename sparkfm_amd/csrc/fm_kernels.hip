@@ -24,7 +24,7 @@ namespace fmhip {
 int g_tune[kTuneCount] = {60, 1, 0, 0, 0};   // forward: w-tile kernel; backward: pipelined kernel   // forward: flat kernel; backward: pipelined; tile rows: auto; row blocks: off   // forward: flat-load kernel; backward: pipelined kernel (measured 12 % faster)
 
 int padded_factors(int k) {
-    int kp = 4;
+    int kp = 32;   // a row is at least one 128-B line: the cost of a gather is per line, not per byte
     while (kp < k) kp <<= 1;
     return kp;
 }
@@ -73,6 +73,12 @@ __device__ __forceinline__ void f4add(float4 &acc, float4 a) { acc.x += a.x; acc
 __device__ __forceinline__ void f4sqacc(float4 &acc, float4 a) {
     acc.x = fmaf(a.x, a.x, acc.x); acc.y = fmaf(a.y, a.y, acc.y); acc.z = fmaf(a.z, a.z, acc.z); acc.w = fmaf(a.w, a.w, acc.w);
 }
+// component c (0..3) of a float4 without dynamic register indexing
+__device__ __forceinline__ float f4pick(float4 v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+__device__ __forceinline__ void f4set(float4 &v, int c, float x) {
+    if (c == 0) v.x = x; else if (c == 1) v.y = x; else if (c == 2) v.z = x; else v.w = x;
+}
+
 // (q*q - s) with the product rounded BEFORE the subtraction (no fma contraction): for a
 // single-nonzero row q = v*x and s = round((v*x)^2), so this is exactly 0 (quirk Q6).
 // (HIP's __fmul_rn/__fsub_rn are plain operators that hipcc would still contract into one fma,
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_forward_lds(FwdArgs a) {
     }
 }
 
-template <int LPN, int J, int MODE>
+template <int LPN, int J, int MODE, bool PACKED>
 __global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
     constexpr int KP = 4 * LPN * J;
     constexpr int SLOTS = kBlock / LPN;
@@ -228,6 +234,12 @@ __global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
     const int l = threadIdx.x & (LPN - 1);
     const int slot = threadIdx.x / LPN;
     const float w0 = *a.w0;
+    // Packed rows (k < Kp): slot k of every V row holds the feature's linear weight w_i, so q_k
+    // accumulates sum w_i x_i — the linear term — for free and there is no separate w gather (a
+    // 64-lane scalar gather costs the texture addresser as much as the whole row gather); slot k of
+    // the P row carries e to the backward the same way.
+    constexpr bool packed = PACKED;
+    const int kl = packed ? (a.pack_k >> 2) & (LPN - 1) : 0, kj = packed ? (a.pack_k >> 2) / LPN : 0, kc = a.pack_k & 3;
     float st1 = 0.f, st2 = 0.f, stbad = 0.f;   // this thread's share of {sum e, sum e^2, nonfinite}
     for (int r = blockIdx.x * SLOTS + slot; r < a.n_rows; r += gridDim.x * SLOTS) {
         const int64_t p0 = a.row_ptr[a.row0 + r], p1 = a.row_ptr[a.row0 + r + 1];
@@ -242,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
             if (p < p1) {
                 c = stream_load(a.col + p);
                 x = stream_load(a.val + p);
-                lin = fmaf(a.w[c], x, lin);
+                if (!packed) lin = fmaf(a.w[c], x, lin);
             }
             const int cnt = (int)((p1 - base) < (int64_t)LPN ? (p1 - base) : (int64_t)LPN);
 #pragma unroll
@@ -270,18 +282,33 @@ __global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
                 }
             }
         }
+        float lin_all = 0.f;   // packed: the complete linear term, identical in every lane of the slot
+        if (packed) {
+            float lk = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj)
+                if (jj == kj) {
+                    lk = f4pick(q[jj], kc);
+                    if (l == kl) { f4set(q[jj], kc, 0.f); f4set(s[jj], kc, 0.f); }   // slot k is not a factor
+                }
+            lin_all = __shfl(lk, kl, LPN);
+        }
         float u = 0.f;
 #pragma unroll
         for (int jj = 0; jj < J; ++jj) u += f4sqminus(q[jj], s[jj]);
         float tot = fmaf(0.5f, u, lin);
 #pragma unroll
         for (int m = LPN >> 1; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, LPN);
-        const float yhat = w0 + tot;
+        const float yhat = w0 + (tot + lin_all);
         const float e = yhat - a.y[a.row0 + r];
         if (MODE == kFwdTrain) {
             float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
 #pragma unroll
-            for (int jj = 0; jj < J; ++jj) pr[jj * LPN] = f4mul(q[jj], e);
+            for (int jj = 0; jj < J; ++jj) {
+                float4 o = f4mul(q[jj], e);
+                if (packed && jj == kj && l == kl) f4set(o, kc, e);   // slot k of the P row carries e
+                pr[jj * LPN] = o;
+            }
         } else if (MODE == kFwdQ) {
             float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
 #pragma unroll
@@ -463,24 +490,26 @@ __global__ __launch_bounds__(kBlock) void k_reduce_blocks(const double *bsum, in
 
 // ------------------------------------------------------------------ backward
 template <int LPN, int J>
-__device__ __forceinline__ void store_row(float *dst, int l, const float4 (&acc)[J], float sa, float sb, float *dsa, float *dsb) {
+__device__ __forceinline__ void store_row(float *dst, int l, const float4 (&acc)[J], float sa, float sb, float *dsa, float *dsb,
+                                          int sl = 0) {
     float4 *d4 = reinterpret_cast<float4 *>(dst) + l;
 #pragma unroll
     for (int jj = 0; jj < J; ++jj) d4[jj * LPN] = acc[jj];
-    if (l == 0) { *dsa = sa; *dsb = sb; }
+    if (l == sl) { *dsa = sa; *dsb = sb; }   // sl: the lane whose scalar sums are the real ones
 }
 
 // A finished column piece goes to its destination: the G row of its feature when the feature has a
 // single piece in the batch, else a piece row that k_fixup2 sums per feature (row-blocked streams).
 template <int LPN, int J>
-__device__ __forceinline__ void store_seg(const BwdArgs &a, int seg, int l, const float4 (&acc)[J], float sa, float sb) {
+__device__ __forceinline__ void store_seg(const BwdArgs &a, int seg, int l, const float4 (&acc)[J], float sa, float sb,
+                                          int sl = 0) {
     constexpr int KP = 4 * LPN * J;
     const int dst = a.cdst[seg];
     if (dst >= 0) {
-        store_row<LPN, J>(a.GV + (size_t)dst * KP, l, acc, sa, sb, a.Gw + dst, a.Gb + dst);
+        store_row<LPN, J>(a.GV + (size_t)dst * KP, l, acc, sa, sb, a.Gw + dst, a.Gb + dst, sl);
     } else {
         float *pr = a.pieces + (size_t)(-1 - dst) * (KP + kPartPad);
-        store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1);
+        store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
     }
 }
 
@@ -523,7 +552,7 @@ __device__ __forceinline__ void slots_reduce(float4 (&acc)[J], float &sa, float 
 //   wave sum   when the whole wave's span (64/LPN ranges) lies inside ONE column the slots are
 //              tree-summed in registers and a single partial is written for the wave.
 // k_fixup and the host-side split list (fmhip_api.hip) apply the same two predicates.
-template <int LPN, int J>
+template <int LPN, int J, bool PACKED>
 __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
     constexpr int KP = 4 * LPN * J;
     constexpr int SLOTS = kBlock / LPN;
@@ -531,6 +560,11 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
     constexpr int PR = KP + kPartPad;
     constexpr int CH = (LPN * J > 16) ? (16 / J) : LPN;  // entries whose P rows are in flight together
     const int l = threadIdx.x & (LPN - 1);
+    // packed rows (k < Kp): slot k of the P row is e, so slot k of acc IS sum e*x (the w gradient) and
+    // there is no e gather; sum e*x^2 is formed from that slot in the lane that owns it (lane sl)
+    constexpr bool packed = PACKED;
+    const int kl = packed ? (a.pack_k >> 2) & (LPN - 1) : 0, kj = packed ? (a.pack_k >> 2) / LPN : 0, kc = a.pack_k & 3;
+    const int sl = kl;
     // a launch may cover only the ranges [rho_lo, rho_hi) (feature-chunked backward); block
     // numbering stays aligned to the global range numbering so the wave-sum predicate is unchanged.
     // xcd_chunk > 0: XCD-aware placement — workgroups b, b+8, b+16, .. share an XCD (round-robin
@@ -574,7 +608,7 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
         if (p < stop) {
             rf = stream_load(a.crow + p);
             x = stream_load(a.cval + p);
-            ee = a.e[rf & 0x7fffffffu];
+            if (!packed) ee = a.e[rf & 0x7fffffffu];
         }
         const int cnt = (stop - base) < LPN ? (stop - base) : LPN;
 #pragma unroll
@@ -591,15 +625,15 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 const float xj = __shfl(x, c0 + j, LPN);
-                const float ej = __shfl(ee, c0 + j, LPN);
+                const float ej = packed ? 0.f : __shfl(ee, c0 + j, LPN);
                 if (c0 + j < cnt) {
                     if ((rj[j] >> 31) && (base + c0 + j != p0)) {
                         // the open column ends here: flush it
                         if (is_head) {
                             float *pr = a.part + ((size_t)rho * 2) * PR;
-                            store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1);
+                            store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
                         } else {
-                            store_seg<LPN, J>(a, seg, l, acc, sa, sb);
+                            store_seg<LPN, J>(a, seg, l, acc, sa, sb, sl);
                         }
                         is_head = false;
                         ++seg;
@@ -610,7 +644,15 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
                     }
 #pragma unroll
                     for (int jj = 0; jj < J; ++jj) f4fma(acc[jj], pv[j][jj], xj);  // sum x * (e*q)
-                    accum_scalars(sa, sb, ej, xj);
+                    if (packed) {
+                        float pk = 0.f;
+#pragma unroll
+                        for (int jj = 0; jj < J; ++jj)
+                            if (jj == kj) pk = f4pick(pv[j][jj], kc);
+                        sb = fmaf(__fmul_rn(pk, xj), xj, sb);
+                    } else {
+                        accum_scalars(sa, sb, ej, xj);
+                    }
                 }
             }
         }
@@ -619,19 +661,19 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
         slots_reduce<LPN, J>(acc, sa, sb);
         if (beg == wbeg) {
             float *pr = a.part + ((size_t)rho * 2 + (ca == wbeg ? 1 : 0)) * PR;
-            store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1);
+            store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
         }
         return;
     }
     if (p0 >= stop) return;   // everything in this range belonged to the previous slot
     if (is_head) {
         float *pr = a.part + ((size_t)rho * 2) * PR;
-        store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1);
+        store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
     } else if (tail_partial) {
         float *pr = a.part + ((size_t)rho * 2 + 1) * PR;
-        store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1);
+        store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
     } else {
-        store_seg<LPN, J>(a, seg, l, acc, sa, sb);
+        store_seg<LPN, J>(a, seg, l, acc, sa, sb, sl);
     }
 }
 
@@ -639,7 +681,7 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
 // value / e loads of a whole super-group (up to 64 entries) are issued up front, the P-row
 // gathers go through a buffer descriptor (dead entries fetch nothing) and are double-buffered in
 // chunks of CHB entries so chunk c+1 is in flight while chunk c is accumulated.
-template <int LPN, int J>
+template <int LPN, int J, bool PACKED>
 __global__ __launch_bounds__(kBlock) void k_backward_p(BwdArgs a) {
     constexpr int KP = 4 * LPN * J;
     constexpr int SLOTS = kBlock / LPN;
@@ -649,6 +691,11 @@ __global__ __launch_bounds__(kBlock) void k_backward_p(BwdArgs a) {
     constexpr int CHB = (LPN * J > 8) ? ((8 / J) > 0 ? (8 / J) : 1) : LPN;   // entries per gather chunk
     constexpr int NCH = SG * LPN / CHB;                                       // chunks per super-group
     const int l = threadIdx.x & (LPN - 1);
+    // packed rows (k < Kp): slot k of the P row is e, so slot k of acc IS sum e*x (the w gradient) and
+    // there is no e gather; sum e*x^2 is formed from that slot in the lane that owns it (lane sl)
+    constexpr bool packed = PACKED;
+    const int kl = packed ? (a.pack_k >> 2) & (LPN - 1) : 0, kj = packed ? (a.pack_k >> 2) / LPN : 0, kc = a.pack_k & 3;
+    const int sl = kl;
     // a launch may cover only the ranges [rho_lo, rho_hi) (feature-chunked backward); block
     // numbering stays aligned to the global range numbering so the wave-sum predicate is unchanged.
     // xcd_chunk > 0: XCD-aware placement — workgroups b, b+8, b+16, .. share an XCD (round-robin
@@ -700,7 +747,7 @@ __global__ __launch_bounds__(kBlock) void k_backward_p(BwdArgs a) {
         for (int g = 0; g < SG; ++g) {
             const int p = sbase + g * LPN + l;
             ee[g] = 0.f;
-            if (p < stop) ee[g] = a.e[rf[g] & 0x7fffffffu];
+            if (!packed && p < stop) ee[g] = a.e[rf[g] & 0x7fffffffu];
         }
         float4 pv[2][CHB][J];
         uint32_t rj[2][CHB];
@@ -736,10 +783,18 @@ __global__ __launch_bounds__(kBlock) void k_backward_p(BwdArgs a) {
                     const int ent = ch * CHB + j;
                     const int g = ent / LPN, jl = ent % LPN;
                     const float xj = __shfl(x[g], jl, LPN);
-                    const float ej = __shfl(ee[g], jl, LPN);
+                    const float ej = packed ? 0.f : __shfl(ee[g], jl, LPN);
 #pragma unroll
                     for (int jj = 0; jj < J; ++jj) f4fma(acc[jj], pv[buf][j][jj], xj);
-                    accum_scalars(sa, sb, ej, xj);
+                    if (packed) {
+                        float pk = 0.f;
+#pragma unroll
+                        for (int jj = 0; jj < J; ++jj)
+                            if (jj == kj) pk = f4pick(pv[buf][j][jj], kc);
+                        sb = fmaf(__fmul_rn(pk, xj), xj, sb);
+                    } else {
+                        accum_scalars(sa, sb, ej, xj);
+                    }
                 }
                 continue;
             }
@@ -748,14 +803,14 @@ __global__ __launch_bounds__(kBlock) void k_backward_p(BwdArgs a) {
                 const int ent = ch * CHB + j;
                 const int g = ent / LPN, jl = ent % LPN;
                 const float xj = __shfl(x[g], jl, LPN);
-                const float ej = __shfl(ee[g], jl, LPN);
+                const float ej = packed ? 0.f : __shfl(ee[g], jl, LPN);
                 if (sbase + ent < stop) {
                     if ((rj[buf][j] >> 31) && (sbase + ent != p0)) {
                         if (is_head) {
                             float *pr = a.part + ((size_t)rho * 2) * PR;
-                            store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1);
+                            store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
                         } else {
-                            store_seg<LPN, J>(a, seg, l, acc, sa, sb);
+                            store_seg<LPN, J>(a, seg, l, acc, sa, sb, sl);
                         }
                         is_head = false;
                         ++seg;
@@ -766,7 +821,15 @@ __global__ __launch_bounds__(kBlock) void k_backward_p(BwdArgs a) {
                     }
 #pragma unroll
                     for (int jj = 0; jj < J; ++jj) f4fma(acc[jj], pv[buf][j][jj], xj);
-                    accum_scalars(sa, sb, ej, xj);
+                    if (packed) {
+                        float pk = 0.f;
+#pragma unroll
+                        for (int jj = 0; jj < J; ++jj)
+                            if (jj == kj) pk = f4pick(pv[buf][j][jj], kc);
+                        sb = fmaf(__fmul_rn(pk, xj), xj, sb);
+                    } else {
+                        accum_scalars(sa, sb, ej, xj);
+                    }
                 }
             }
         }
@@ -775,19 +838,19 @@ __global__ __launch_bounds__(kBlock) void k_backward_p(BwdArgs a) {
         slots_reduce<LPN, J>(acc, sa, sb);
         if (beg == wbeg) {
             float *pr = a.part + ((size_t)rho * 2 + (ca == wbeg ? 1 : 0)) * PR;
-            store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1);
+            store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
         }
         return;
     }
     if (p0 >= stop) return;
     if (is_head) {
         float *pr = a.part + ((size_t)rho * 2) * PR;
-        store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1);
+        store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
     } else if (tail_partial) {
         float *pr = a.part + ((size_t)rho * 2 + 1) * PR;
-        store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1);
+        store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
     } else {
-        store_seg<LPN, J>(a, seg, l, acc, sa, sb);
+        store_seg<LPN, J>(a, seg, l, acc, sa, sb, sl);
     }
 }
 
@@ -963,10 +1026,17 @@ __global__ __launch_bounds__(kBlock) void k_apply(ApplyArgs a) {
         const int64_t i = idx / LPR;
         const float b = a.Gb[i];
         float4 g = G4[idx], v = V4[idx];
+        float wslot = 0.f;
+        const bool has_w = a.pack_k >= 0 && (int)(idx % LPR) == (a.pack_k >> 2);
+        if (has_w) {   // packed rows: this float4 holds the linear weight in component pack_k & 3
+            const float wi = f4pick(v, a.pack_k & 3);
+            wslot = wi - a.eta * fmaf(a.regw, wi, f4pick(g, a.pack_k & 3) * invb);
+        }
         v.x -= a.eta * fmaf(a.regv, v.x, (g.x - v.x * b) * invb);
         v.y -= a.eta * fmaf(a.regv, v.y, (g.y - v.y * b) * invb);
         v.z -= a.eta * fmaf(a.regv, v.z, (g.z - v.z * b) * invb);
         v.w -= a.eta * fmaf(a.regv, v.w, (g.w - v.w * b) * invb);
+        if (has_w) f4set(v, a.pack_k & 3, wslot);
         V4[idx] = v;
         G4[idx] = f4zero();
         if ((idx % LPR) == 0) {
@@ -987,6 +1057,7 @@ hipError_t fwd_dispatch(FwdMode mode, const FwdArgs &a, hipStream_t s) {
     int64_t blocks = forward_blocks(4 * LPN * J, a.n_rows);
     dim3 g((unsigned)blocks), b(kBlock);
     int var = g_tune[kTuneFwd];
+    if (a.pack_k >= 0) var = 0;              // packed rows carry w in the row: only the plain kernel handles them
     if (var == 20 && !a.v_bytes) var = 0;    // the LDS V-tile kernel needs V to fit a 32-bit buffer view
     if (var == 60 && a.wt_rows > 0) {
         const size_t lds_bytes = (size_t)a.wt_rows * sizeof(float);
@@ -1020,10 +1091,18 @@ hipError_t fwd_dispatch(FwdMode mode, const FwdArgs &a, hipStream_t s) {
         }
         return e != hipSuccess ? e : hipGetLastError();
     }
-    switch (mode) {
-        case kFwdTrain: hipLaunchKernelGGL((k_forward<LPN, J, kFwdTrain>), g, b, 0, s, a); break;
-        case kFwdResidual: hipLaunchKernelGGL((k_forward<LPN, J, kFwdResidual>), g, b, 0, s, a); break;
-        case kFwdQ: hipLaunchKernelGGL((k_forward<LPN, J, kFwdQ>), g, b, 0, s, a); break;
+    if (a.pack_k >= 0) {
+        switch (mode) {
+            case kFwdTrain: hipLaunchKernelGGL((k_forward<LPN, J, kFwdTrain, true>), g, b, 0, s, a); break;
+            case kFwdResidual: hipLaunchKernelGGL((k_forward<LPN, J, kFwdResidual, true>), g, b, 0, s, a); break;
+            case kFwdQ: hipLaunchKernelGGL((k_forward<LPN, J, kFwdQ, true>), g, b, 0, s, a); break;
+        }
+    } else {
+        switch (mode) {
+            case kFwdTrain: hipLaunchKernelGGL((k_forward<LPN, J, kFwdTrain, false>), g, b, 0, s, a); break;
+            case kFwdResidual: hipLaunchKernelGGL((k_forward<LPN, J, kFwdResidual, false>), g, b, 0, s, a); break;
+            case kFwdQ: hipLaunchKernelGGL((k_forward<LPN, J, kFwdQ, false>), g, b, 0, s, a); break;
+        }
     }
     return hipGetLastError();
 }
@@ -1037,9 +1116,16 @@ hipError_t bwd_dispatch(const BwdArgs &a, hipStream_t s) {
     BwdArgs a2 = a;
     a2.xcd_chunk = a.xcd_chunk > 0 ? (nblk + 7) / 8 : 0;      // blocks per XCD
     dim3 g((unsigned)(a2.xcd_chunk > 0 ? a2.xcd_chunk * 8 : nblk)), b(kBlock);
-    // the pipelined kernel needs P to fit a 32-bit buffer view (< 4 GiB per batch)
-    if (a.p_bytes && g_tune[kTuneBwd] == 1) hipLaunchKernelGGL((k_backward_p<LPN, J>), g, b, 0, s, a2);
-    else hipLaunchKernelGGL((k_backward<LPN, J>), g, b, 0, s, a2);
+    // the pipelined kernel needs P to fit a 32-bit buffer view (< 4 GiB per batch); for k > 64 (J > 1)
+    // its register footprint spills, so those sizes take the plain walk
+    const bool pipe = J == 1 && a.p_bytes && g_tune[kTuneBwd] == 1;
+    if (a.pack_k >= 0) {
+        if (pipe) hipLaunchKernelGGL((k_backward_p<LPN, J, true>), g, b, 0, s, a2);
+        else hipLaunchKernelGGL((k_backward<LPN, J, true>), g, b, 0, s, a2);
+    } else {
+        if (pipe) hipLaunchKernelGGL((k_backward_p<LPN, J, false>), g, b, 0, s, a2);
+        else hipLaunchKernelGGL((k_backward<LPN, J, false>), g, b, 0, s, a2);
+    }
     return hipGetLastError();
 }
 
@@ -1057,9 +1143,6 @@ hipError_t fix_dispatch(const BwdArgs &a, hipStream_t s) {
 
 #define FMHIP_KP_SWITCH(KPV, CALL)                       \
     switch (KPV) {                                       \
-        case 4: return CALL(1, 1);                       \
-        case 8: return CALL(2, 1);                       \
-        case 16: return CALL(4, 1);                      \
         case 32: return CALL(8, 1);                      \
         case 64: return CALL(16, 1);                     \
         case 128: return CALL(16, 2);                    \
@@ -1107,9 +1190,6 @@ hipError_t launch_apply(int Kp, const ApplyArgs &a, hipStream_t s) {
     if (blocks < 1) blocks = 1;
     dim3 g((unsigned)blocks), b(kBlock);
     switch (Kp) {
-        case 4: hipLaunchKernelGGL((k_apply<4>), g, b, 0, s, a); break;
-        case 8: hipLaunchKernelGGL((k_apply<8>), g, b, 0, s, a); break;
-        case 16: hipLaunchKernelGGL((k_apply<16>), g, b, 0, s, a); break;
         case 32: hipLaunchKernelGGL((k_apply<32>), g, b, 0, s, a); break;
         case 64: hipLaunchKernelGGL((k_apply<64>), g, b, 0, s, a); break;
         case 128: hipLaunchKernelGGL((k_apply<128>), g, b, 0, s, a); break;

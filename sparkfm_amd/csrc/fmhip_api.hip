@@ -151,6 +151,7 @@ struct fmhip_model {
     float *Gw() const { return grad + (size_t)n1p * Kp; }
     float *Gb() const { return grad + (size_t)n1p * Kp + n1p; }
     float *scal() const { return grad + (size_t)n1p * Kp + 2 * (size_t)n1p; }
+    int32_t pack_k() const { return k < Kp ? k : -1; }   // packed rows: slot k of a V row holds w_i
     size_t grad_floats() const { return (size_t)n1p * Kp + 2 * (size_t)n1p + kScalars; }
 };
 
@@ -447,11 +448,15 @@ int ensure_workspace(fmhip_model_t m, fmhip_dataset_t d) {
     return FMHIP_OK;
 }
 
-// number of per-block statistic partials the forward launch writes (depends on the variant)
+// number of per-block statistic partials the forward launch writes: must mirror the kernel choice
+// made by launch_forward (packed rows -> plain kernel; the LDS V-tile needs a 32-bit view of V)
 int fwd_partials(fmhip_model_t m, int64_t rows) {
     const uint64_t vb = (uint64_t)m->n1p * m->Kp * sizeof(float);
-    if (g_tune[kTuneFwd] == 20 && vb < 0xffffffffull) return forward_blocks_lds(rows);
-    if (g_tune[kTuneFwd] == 60) return forward_blocks_wt(m->Kp, rows);
+    int var = g_tune[kTuneFwd];
+    if (m->pack_k() >= 0) var = 0;
+    if (var == 20 && vb >= 0xffffffffull) var = 0;
+    if (var == 20) return forward_blocks_lds(rows);
+    if (var == 60) return forward_blocks_wt(m->Kp, rows);
     return forward_blocks(m->Kp, rows);
 }
 
@@ -473,6 +478,7 @@ FwdArgs fwd_args(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm) {
     a.P = m->P.p;
     a.e = m->e.p;
     a.yhat = nullptr;
+    a.pack_k = m->pack_k();
     a.bsum = m->bsum.p;
     {
         // LDS V-tile size: as many hot rows as fit 128 KiB (+ their w), capped by the model
@@ -496,6 +502,7 @@ BwdArgs bwd_args(fmhip_model_t m, fmhip_dataset_t d, int64_t b) {
     a.mp_feat = d->mp_feat.p + bm.mp_off;
     a.mp_ptr = d->mp_ptr.p + bm.mp_off + b;
     a.n_mp = bm.n_mp;
+    a.pack_k = m->pack_k();
     a.cptr = d->cptr.p + bm.col_off + b;
     a.split_seg = d->split_seg.p + bm.split_off;
     a.split_short = d->split_short.p + bm.split_short_off;
@@ -623,6 +630,7 @@ int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double reg
     a.Gb = m->Gb();
     a.scal = m->scal();
     a.n1 = m->n1;
+    a.pack_k = m->pack_k();
     a.eta = (float)eta;
     a.reg0 = (float)reg0;
     a.regw = (float)regw;
@@ -667,6 +675,7 @@ int set_params_impl(fmhip_model_t m, FT w0, const FT *w, const FT *v) {
     for (int64_t i = 0; i < m->n1; ++i) {
         hw[(size_t)i] = (float)w[i];
         for (int f = 0; f < m->k; ++f) hV[(size_t)i * m->Kp + f] = (float)v[f + i * (int64_t)m->k];
+        if (m->pack_k() >= 0) hV[(size_t)i * m->Kp + m->k] = (float)w[i];   // packed rows: w_i rides in slot k
     }
     const float hw0 = (float)w0;
     m->h_w0 = (double)w0;
@@ -700,7 +709,7 @@ int get_params_impl(fmhip_model_t m, FT *w0, FT *w, FT *v) {
     HIP_TRY(hipStreamSynchronize(m->stream));
     if (w0) *w0 = (FT)hw0;
     for (int64_t i = 0; i < m->n1; ++i) {
-        if (w) w[i] = (FT)hw[(size_t)i];
+        if (w) w[i] = (FT)(m->pack_k() >= 0 ? hV[(size_t)i * m->Kp + m->k] : hw[(size_t)i]);
         if (v)
             for (int f = 0; f < m->k; ++f) v[f + i * (int64_t)m->k] = (FT)hV[(size_t)i * m->Kp + f];
     }
@@ -1006,7 +1015,7 @@ int fmhip_batch_grad(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double *
     m->grad_dirty = false;
     const float *GV = hG.data(), *Gw = GV + (size_t)m->n1p * m->Kp, *Gb = Gw + m->n1p, *sc = Gb + m->n1p;
     for (int64_t i = 0; i < m->n1; ++i) {
-        if (gw) gw[i] = Gw[i];
+        if (gw) gw[i] = m->pack_k() >= 0 ? GV[(size_t)i * m->Kp + m->k] : Gw[i];
         if (gv)
             for (int f = 0; f < m->k; ++f)
                 gv[f + i * (int64_t)m->k] = (double)GV[(size_t)i * m->Kp + f] - (double)hV[(size_t)i * m->Kp + f] * (double)Gb[i];
