@@ -6,10 +6,11 @@
 //   k_fixup    sums the partials of columns cut across ranges (fixed order -> deterministic)
 //   k_apply    dense SGD update fused with zeroing the packed gradient
 //
-// Lane geometry: a "slot" = LPN consecutive lanes owning one CSR row (forward) or one CSC
-// range (backward); lane l of a slot holds factors 4*(l + jj*LPN) .. +3 for jj < J, so one
-// wave-instruction moves 64/LPN whole rows of Kp = 4*LPN*J floats, each row a contiguous,
-// 16-B-per-lane coalesced segment.  Index/value streams are read LPN entries at a time (one
+// Lane geometry: a "slot" = LPN consecutive lanes (8 at Kp = 32, 16 above) owning one CSR row
+// (forward) or one CSC range (backward); lane l of a slot holds factors 4*(l + jj*LPN) .. +3 for
+// jj < J, so one wave-instruction moves 64/LPN whole rows of Kp = 4*LPN*J floats (whole 128-B
+// lines: the texture addresser charges ~2 cycles per distinct line, whatever the bytes used), each
+// row a contiguous, 16-B-per-lane coalesced segment.  Index/value streams are read LPN entries at a time (one
 // per lane, contiguous) and broadcast inside the slot with ds_bpermute (__shfl width LPN).
 //
 // Formulas restated from SparkFM (S/ = src/main/scala/io/edstud/spark/):
