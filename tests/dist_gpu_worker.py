@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     rank, world, port, out, overlap = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5] == "1"
+    k = int(sys.argv[6]) if len(sys.argv) > 6 else 32
     import torch
     import torch.distributed as dist
     from sparkfm_amd import DataSet, FMModel, synth
@@ -23,8 +24,9 @@ def main():
     # the same virtual dataset as the single-process reference: rank r owns rows [r*3000, (r+1)*3000)
     d = synth.make_zipf(77, 3000 if rank == 0 else 2200, 800, 4, 24, zipf_s=1.05, row_begin=rank * 3000)
     ds = DataSet.from_arrays(d, batch_rows=1000, device=0).cache()
-    w0, w, v = synth.init_params(5, 800, 32, stdev=0.05)
-    fm = FMModel(799, 32, device=0, stream=torch_stream_handle(0))
+    w0, w, v = synth.init_params(5, 800, k, stdev=0.05)
+    w = np.random.default_rng(9).normal(0, 0.05, 800)
+    fm = FMModel(799, k, device=0, stream=torch_stream_handle(0))
     fm.w0, fm.w, fm.v = w0, w, v
     dp = DataParallelSGD(eta=0.05, regw=1e-3, regv=1e-3, overlap=overlap)
     for _ in range(2):

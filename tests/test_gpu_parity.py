@@ -573,8 +573,8 @@ def test_random_shapes_property(fmhip):
         fm.close()
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_two_ranks_on_one_gpu(fmhip, tmp_path, overlap):
+@pytest.mark.parametrize("overlap,k", [(True, 32), (False, 32), (True, 16)])
+def test_two_ranks_on_one_gpu(fmhip, tmp_path, overlap, k):
     """The real data-parallel path with TWO processes (both on cuda:0, collective over gloo): HipEngine,
     feature-chunked backward + async all-reduces (overlap) or one all-reduce per step, uneven shards
     (rank 1 runs out of batches first and contributes zero gradients).  Replicas must end bit-identical
@@ -590,7 +590,7 @@ def test_two_ranks_on_one_gpu(fmhip, tmp_path, overlap):
     out = str(tmp_path / "dp")
     here = os.path.dirname(os.path.abspath(__file__))
     procs = [subprocess.Popen([sys.executable, os.path.join(here, "dist_gpu_worker.py"), str(r), "2", port, out,
-                               "1" if overlap else "0"]) for r in range(2)]
+                               "1" if overlap else "0", str(k)]) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=300) == 0
     r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
@@ -602,7 +602,8 @@ def test_two_ranks_on_one_gpu(fmhip, tmp_path, overlap):
     # oracle: global batch j = rank0's batch j  U  rank1's batch j (rank 1 has 3 batches, rank 0 has 3)
     shards = [synth.make_zipf(77, 3000, 800, 4, 24, zipf_s=1.05, row_begin=0),
               synth.make_zipf(77, 2200, 800, 4, 24, zipf_s=1.05, row_begin=3000)]
-    w0, w, v = synth.init_params(5, 800, 32, stdev=0.05)
+    w0, w, v = synth.init_params(5, 800, k, stdev=0.05)
+    w = np.random.default_rng(9).normal(0, 0.05, 800)
     for _ in range(2):
         for j in range(3):
             rp, cols, vals, ys = [0], [], [], []
