@@ -115,6 +115,21 @@ def als_c1(device):
             "note": "Gauss-Seidel over features: a fidelity path (one persistent workgroup), not a throughput path"}
 
 
+def pmc_traffic(config, k, batch_rows, kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes
+    (profiles/pmc_traffic.json), or None when no pass exists for this configuration."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            entries = json.load(f)["entries"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for e in entries:
+        if (e["config"], e["k"], e["batch_rows"], e["kernel"]) == (config, k, batch_rows, kernel):
+            return e["traffic_bytes"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -260,7 +275,8 @@ def main():
                        "allreduce": ("overlapped with the feature-chunked backward" if overlap_used else
                                      ("one all-reduce per step" if use_dp else "none"))},
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK, "traffic": None,
+                         "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
+                         "traffic": pmc_traffic(args.config, k, batch_rows, "k_" + dom),
                          "alg_bytes_per_nnz": ab[dom], "nnz_per_launch": pd[dom]["nnz"] / max(pd[dom]["launches"], 1),
                          "avg_launch_ms": kern[dom]["avg_ms"] if dom in kern else None},
             "step_roofline": {"alg_bytes_per_nnz": ab["step"], "achieved_GBps": value / world * ab["step"] / 1e9,

@@ -86,7 +86,14 @@ int fmhip_device_count(int *count);
  *   key 2  LDS tile rows : 0 = auto (V-tile: as many rows as fit 128 KiB; w-tile: 6144)
  *   key 3  rows per row block of the transposes built by the NEXT fmhip_dataset_create (0 = off):
  *          entries sorted by (row block, feature) so a block's slice of P stays L2-resident in the
- *          backward; features occurring in several blocks are summed by an extra fixup pass */
+ *          backward; features occurring in several blocks are summed by an extra fixup pass
+ *   key 4  XCD-aware workgroup placement in the backward (0 = off, default)
+ *   key 5  dense hot block, applied by the NEXT fmhip_dataset_create (1 = on, default; 0 = off): in a
+ *          dataset of more than one mini-batch the (at most 16) features present in >= 10 % of the rows —
+ *          none that occurs twice in a row or with a stored zero — leave the sparse streams for a dense
+ *          [rows][16] fp32 array; their V rows are served from LDS in the forward and their gradient rows
+ *          are a small dense product (MFMA) in the backward.  Invisible at this interface: batch_info,
+ *          get_transpose, statistics and gradients report every stored nonzero. */
 int fmhip_tune(int key, int value);
 
 /* ---- model: `new FMModel(num_attribute, num_factor)`  S/fm/FMModel.scala:9-22 -- */

@@ -11,7 +11,8 @@ constexpr int kPartPad = 4;        // partial row = Kp floats + {sum e*x, sum e*
 constexpr int kScalars = 8;        // packed-gradient tail: {sum e, sum e^2, rows, nonfinite, ...}
 
 // runtime kernel-variant knobs (diagnostics / A-B benchmarking; fmhip_tune)
-enum { kTuneFwd = 0, kTuneBwd = 1, kTuneTile = 2, kTuneRowBlock = 3, kTuneXcd = 4, kTuneCount = 5 };
+enum { kTuneFwd = 0, kTuneBwd = 1, kTuneTile = 2, kTuneRowBlock = 3, kTuneXcd = 4, kTuneHot = 5, kTuneCount = 6 };
+constexpr int kHotT = 16;           // slots of the dense hot block (fp32 per row: one 64-B half line)
 extern int g_tune[kTuneCount];
 
 // padded factor count: 4 * LPN * J with LPN = lanes per row-slot (<= 16), J float4 per lane
@@ -43,8 +44,24 @@ struct FwdArgs {
     int32_t tile_rows; // LDS V-tile: rows of V (feature ids < tile_rows) staged in LDS; 0 = off
     int32_t wt_rows;   // LDS w-tile: linear weights of feature ids < wt_rows staged in LDS
     int32_t pack_k;    // >= 0: packed rows — slot pack_k of a V row is w_i, of a P row is e (k < Kp); -1: off
+    // dense hot block: xhot[r][h] = value of feature hot_ids[h] in row r (0 = absent), h < kHotT
+    int32_t hot_T;           // 0 = none
+    const float *xhot;       // [n_rows][kHotT], this batch's slice
+    const int32_t *hot_ids;  // [kHotT], -1 = unused slot
 };
 
+// dense hot block, gradient side: G rows of the hot features = xhot^T . P (plus their two scalar sums)
+struct HotArgs {
+    const float *P;          // [n_rows][Kp] = e*q (slot pack_k = e for packed rows)
+    const float *e;          // [n_rows]
+    const float *xhot;       // [n_rows][kHotT]
+    const int32_t *hot_ids;  // [kHotT], -1 = unused slot
+    float *part;             // [hot_blocks][kHotT][Kp + kPartPad] per-workgroup partial sums
+    float *GV, *Gw, *Gb;
+    int32_t n_rows;
+    int32_t pack_k;
+    int32_t nblk;            // hot_blocks(Kp, n_rows)
+};
 struct BwdArgs {
     const uint32_t *crow;      // batch CSC: bit31 = first entry of its column, low bits = batch-local row
     const float *cval;
@@ -77,6 +94,10 @@ struct BwdArgs {
     int32_t red_nblocks, red_rows;
     float *red_scal;
     double *red_acc;
+    // dense hot block (hot_blocks > 0): the first hot_blocks workgroups of the backward launch form its
+    // partial sums while the others walk the sparse stream; kHotT extra workgroups of k_fixup finish it
+    HotArgs hot;
+    int32_t hot_blocks;
 };
 
 struct ApplyArgs {
@@ -87,6 +108,8 @@ struct ApplyArgs {
     int32_t pack_k;     // >= 0: packed rows — slot pack_k of a V row is the linear weight
     float eta, reg0, regw, regv;
 };
+
+int hot_blocks(int Kp, int64_t n_rows);
 
 hipError_t launch_forward(int Kp, FwdMode mode, const FwdArgs &a, hipStream_t s);
 hipError_t launch_backward(int Kp, const BwdArgs &a, hipStream_t s);

@@ -22,7 +22,7 @@
 
 namespace fmhip {
 
-int g_tune[kTuneCount] = {60, 1, 0, 0, 0};   // forward: w-tile kernel; backward: pipelined kernel   // forward: flat kernel; backward: pipelined; tile rows: auto; row blocks: off   // forward: flat-load kernel; backward: pipelined kernel (measured 12 % faster)
+int g_tune[kTuneCount] = {60, 1, 0, 0, 0, 1};   // forward: w-tile kernel; backward: pipelined; tile rows: auto; row blocks, XCD placement: off; hot block: on
 
 int padded_factors(int k) {
     int kp = 32;   // a row is at least one 128-B line: the cost of a gather is per line, not per byte
@@ -112,6 +112,80 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t o
 // issues NO global request (its buffer offset is out of range); only the colder ids go to L2.
 // With power-law ids the tile absorbs most gathers (58 % at T = 1024 on the C3 workload).
 constexpr int kLdsBlock = 1024;
+
+// ------------------------------------------------------------------ dense hot block (forward side)
+// The kHotT most frequent features of a dataset are not in its sparse streams: their values sit in
+// xhot[row][slot] (0 = absent) and their V rows / linear weights are staged in LDS once per
+// workgroup, so a hot nonzero costs an LDS read instead of a 128-B gather through the texture
+// addresser (profiles/r01_experiments.md §12/§15).  Contributions enter q, s and the linear term
+// exactly as a stored nonzero's would (FMModel.scala:41-46,57-63); an absent feature adds nothing.
+template <int KP>
+__device__ __forceinline__ bool hot_stage(const FwdArgs &a, float *vh, float *wh) {
+    int bad = 0;
+    for (int i = threadIdx.x; i < kHotT * (KP / 4); i += blockDim.x) {
+        const int h = i / (KP / 4), c = i % (KP / 4);
+        const int id = a.hot_ids[h];
+        const float4 t = id >= 0 ? reinterpret_cast<const float4 *>(a.V + (size_t)id * KP)[c] : f4zero();
+        reinterpret_cast<float4 *>(vh)[i] = t;
+        bad |= !(isfinite(t.x) && isfinite(t.y) && isfinite(t.z) && isfinite(t.w));
+    }
+    if (threadIdx.x < kHotT) {
+        const int id = a.hot_ids[threadIdx.x];
+        const float t = id >= 0 ? a.w[id] : 0.f;
+        wh[threadIdx.x] = t;
+        bad |= !isfinite(t);
+    }
+    // (also the barrier that publishes the tile) all staged parameters finite: 0 * v is exactly 0 and
+    // an absent slot needs no masking; otherwise the masked prologue keeps absent features out
+    return __syncthreads_or(bad) == 0;
+}
+
+// The row's kHotT values, issued together with the row's offsets so their latency is paid once.  Lane
+// l of the slot loads the float4 of hot slots 4*(l&3)..+3 — 16 B per lane: the texture path returns
+// 64 B/clk/CU whatever the coalescing, so every lane loading all 64 B would cost four times as much —
+// and the prologue broadcasts each value inside the quad with a DPP move (no LDS crossbar).
+__device__ __forceinline__ float4 hot_load(const FwdArgs &a, int r, int l) {
+    return reinterpret_cast<const float4 *>(a.xhot + (size_t)r * kHotT)[l & 3];
+}
+
+template <int G>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), G * 0x55, 0xf, 0xf, false));   // quad_perm:[G,G,G,G]
+}
+
+template <int LPN, int J, bool WITH_LIN, bool MASKED, int G>
+__device__ __forceinline__ void hot_group(const float4 xq, const float *vh, const float *wh, int l, float4 (&q)[J],
+                                          float4 (&s)[J], float &lin) {
+    constexpr int KP = 4 * LPN * J;
+    const float xs[4] = {quad_bcast<G>(xq.x), quad_bcast<G>(xq.y), quad_bcast<G>(xq.z), quad_bcast<G>(xq.w)};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int h = G * 4 + c;
+        const float x = xs[c];
+        const bool live = x != 0.f;
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) {
+            float4 tv = f4mul(reinterpret_cast<const float4 *>(vh + h * KP)[jj * LPN + l], x);
+            if (MASKED && !live) tv = f4zero();
+            f4add(q[jj], tv);
+            f4sqacc(s[jj], tv);
+        }
+        if (WITH_LIN && (h & (LPN - 1)) == l && (!MASKED || live)) lin = fmaf(wh[h], x, lin);
+    }
+    // four slots' LDS reads in flight at a time: the prologue must not raise the kernel's register count
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int LPN, int J, bool WITH_LIN, bool MASKED>
+__device__ __forceinline__ void hot_prologue(const float4 xq, const float *vh, const float *wh, int l,
+                                             float4 (&q)[J], float4 (&s)[J], float &lin) {
+    static_assert(kHotT == 16, "one float4 per quad lane");
+    hot_group<LPN, J, WITH_LIN, MASKED, 0>(xq, vh, wh, l, q, s, lin);
+    hot_group<LPN, J, WITH_LIN, MASKED, 1>(xq, vh, wh, l, q, s, lin);
+    hot_group<LPN, J, WITH_LIN, MASKED, 2>(xq, vh, wh, l, q, s, lin);
+    hot_group<LPN, J, WITH_LIN, MASKED, 3>(xq, vh, wh, l, q, s, lin);
+}
+
 template <int LPN, int J, int MODE>
 __global__ __launch_bounds__(kLdsBlock) void k_forward_lds(FwdArgs a) {
     constexpr int KP = 4 * LPN * J;
@@ -227,7 +301,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_forward_lds(FwdArgs a) {
     }
 }
 
-template <int LPN, int J, int MODE, bool PACKED>
+template <int LPN, int J, int MODE, bool PACKED, bool HOT>
 __global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
     constexpr int KP = 4 * LPN * J;
     constexpr int SLOTS = kBlock / LPN;
@@ -241,13 +315,23 @@ __global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
     // the P row carries e to the backward the same way.
     constexpr bool packed = PACKED;
     const int kl = packed ? (a.pack_k >> 2) & (LPN - 1) : 0, kj = packed ? (a.pack_k >> 2) / LPN : 0, kc = a.pack_k & 3;
+    __shared__ __attribute__((aligned(16))) float vh[HOT ? kHotT * KP : 4];
+    __shared__ float wh[HOT ? kHotT : 1];
+    bool hot_plain = false;
+    if (HOT) hot_plain = hot_stage<KP>(a, vh, wh);
     float st1 = 0.f, st2 = 0.f, stbad = 0.f;   // this thread's share of {sum e, sum e^2, nonfinite}
     for (int r = blockIdx.x * SLOTS + slot; r < a.n_rows; r += gridDim.x * SLOTS) {
+        float4 xh = f4zero();
+        if (HOT) xh = hot_load(a, r, l);
         const int64_t p0 = a.row_ptr[a.row0 + r], p1 = a.row_ptr[a.row0 + r + 1];
         float4 q[J], s[J];
 #pragma unroll
         for (int jj = 0; jj < J; ++jj) { q[jj] = f4zero(); s[jj] = f4zero(); }
         float lin = 0.f;
+        if (HOT) {
+            if (hot_plain) hot_prologue<LPN, J, !PACKED, false>(xh, vh, wh, l, q, s, lin);
+            else hot_prologue<LPN, J, !PACKED, true>(xh, vh, wh, l, q, s, lin);
+        }
         for (int64_t base = p0; base < p1; base += LPN) {
             const int64_t p = base + l;
             int c = 0;
@@ -347,8 +431,10 @@ __global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
 }
 
 // k_forward with an LDS-resident tile of the hot linear weights (see the comment in the body)
-template <int LPN, int J, int MODE>
-__global__ __launch_bounds__(kBlock) void k_forward_wt(FwdArgs a) {
+// (second launch bound = waves per SIMD: the persistent grid of forward_blocks_wt is sized for 5, and a
+// register count that admits only 4 would run it in two rounds)
+template <int LPN, int J, int MODE, bool HOT>
+__global__ __launch_bounds__(kBlock, (LPN * J <= 8 ? 5 : 1)) void k_forward_wt(FwdArgs a) {
     constexpr int KP = 4 * LPN * J;
     constexpr int SLOTS = kBlock / LPN;
     constexpr int CH = (LPN * J > 16) ? (16 / J) : LPN;  // entries whose V rows are in flight together
@@ -361,15 +447,25 @@ __global__ __launch_bounds__(kBlock) void k_forward_wt(FwdArgs a) {
     // in the tile read LDS instead and drop out of the global gather.
     extern __shared__ __attribute__((aligned(16))) float wt[];
     const int T = a.wt_rows;
+    __shared__ __attribute__((aligned(16))) float vh[HOT ? kHotT * KP : 4];
+    __shared__ float wh[HOT ? kHotT : 1];
     for (int i = threadIdx.x; i < T; i += kBlock) wt[i] = a.w[i];
-    __syncthreads();
+    bool hot_plain = false;
+    if (HOT) hot_plain = hot_stage<KP>(a, vh, wh);
+    else __syncthreads();
     float st1 = 0.f, st2 = 0.f, stbad = 0.f;   // this thread's share of {sum e, sum e^2, nonfinite}
     for (int r = blockIdx.x * SLOTS + slot; r < a.n_rows; r += gridDim.x * SLOTS) {
+        float4 xh = f4zero();
+        if (HOT) xh = hot_load(a, r, l);
         const int64_t p0 = a.row_ptr[a.row0 + r], p1 = a.row_ptr[a.row0 + r + 1];
         float4 q[J], s[J];
 #pragma unroll
         for (int jj = 0; jj < J; ++jj) { q[jj] = f4zero(); s[jj] = f4zero(); }
         float lin = 0.f;
+        if (HOT) {
+            if (hot_plain) hot_prologue<LPN, J, true, false>(xh, vh, wh, l, q, s, lin);
+            else hot_prologue<LPN, J, true, true>(xh, vh, wh, l, q, s, lin);
+        }
         for (int64_t base = p0; base < p1; base += LPN) {
             const int64_t p = base + l;
             int c = 0;
@@ -539,6 +635,113 @@ __device__ __forceinline__ void slots_reduce(float4 (&acc)[J], float &sa, float 
     }
 }
 
+// ------------------------------------------------------------------ dense hot block (gradient side)
+// G_V[hot h][f] = sum_r xhot[r][h] * P[r][f], G_w = sum_r e_r x, G_b = sum_r e_r x^2: a dense
+// [kHotT x rows] . [rows x Kp] product, the one GEMM-shaped piece of the path, streamed once over P
+// and xhot.  Each wave owns a contiguous run of rows and feeds them four at a time to
+// v_mfma_f32_16x16x4_f32 (exact f32, a k-ordered fmaf chain): A[h][k] = xhot[r0+k][h] is ONE
+// coalesced dword load per lane (lane l <-> xhot[r0*16 + l]), B[k][f] = P[r0+k][16j + f]; the 16 x Kp
+// result lives in Kp/16 accumulators of 4 registers.  The two scalar sums ride on the A operand's
+// lanes.  Waves of a workgroup are summed through LDS in wave order into one partial per workgroup;
+// hot_reduce_body sums the partials in workgroup order: fixed orders, bit-identical run to run, no atomics.
+// The body runs in the FIRST hot_blocks workgroups of the backward launch (HBM streaming next to the
+// gather-bound column walk of the other workgroups, no extra launch); the reduction rides in k_fixup.
+template <int NJ>
+__device__ __forceinline__ void hot_backward_body(const HotArgs &a, int bx, int nbx) {
+    static_assert(kHotT == 16 && kBlock == 256, "tile mapping below assumes a 16-slot hot block and 4 waves");
+    constexpr int KP = 16 * NJ, PR = KP + kPartPad, W = kBlock / 64;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int kk = lane >> 4, jj = lane & 15;
+    const int nw = nbx * W;
+    const int per = (((a.n_rows + nw - 1) / nw) + 3) & ~3;      // rows per wave, a multiple of 4
+    const int64_t beg64 = (int64_t)(bx * W + wv) * per;
+    const int r_beg = beg64 < a.n_rows ? (int)beg64 : a.n_rows;
+    const int r_end = r_beg + per < a.n_rows ? r_beg + per : a.n_rows;
+    f32x4 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float sa = 0.f, sb = 0.f;
+    constexpr int U = NJ <= 4 ? 4 : 2;                         // 4-row steps whose loads are in flight together
+    for (int r0 = r_beg; r0 < r_end; r0 += 4 * U) {
+        float x[U], e[U], b[U][NJ];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + 4 * u + kk;
+            x[u] = 0.f;
+            e[u] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b[u][j] = 0.f;
+            if (r < r_end) {
+                x[u] = a.xhot[(size_t)r * kHotT + jj];
+                const float *pr = a.P + (size_t)r * KP;
+                e[u] = a.pack_k >= 0 ? pr[a.pack_k] : a.e[r];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[u][j] = pr[j * 16 + jj];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            accum_scalars(sa, sb, e[u], x[u]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u], b[u][j], acc[j], 0, 0, 0);
+        }
+    }
+    sa += __shfl_xor(sa, 16, 64);
+    sb += __shfl_xor(sb, 16, 64);
+    sa += __shfl_xor(sa, 32, 64);
+    sb += __shfl_xor(sb, 32, 64);                              // lanes 0..15: the sums of hot slot `lane`
+    __shared__ float red[W][kHotT][17];
+    __shared__ float reds[W][kHotT][2];
+    float *out = a.part + (size_t)bx * kHotT * PR;
+    const int oh = threadIdx.x >> 4, of = threadIdx.x & 15;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (j) __syncthreads();
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) red[wv][kk * 4 + reg][jj] = acc[j][reg];   // C/D: row = (lane>>4)*4 + reg, col = lane&15
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < W; ++w) t += red[w][oh][of];
+        out[(size_t)oh * PR + j * 16 + of] = t;
+    }
+    if (lane < kHotT) { reds[wv][lane][0] = sa; reds[wv][lane][1] = sb; }
+    __syncthreads();
+    if (threadIdx.x < kHotT * 2) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < W; ++w) t += reds[w][threadIdx.x >> 1][threadIdx.x & 1];
+        out[(size_t)(threadIdx.x >> 1) * PR + KP + (threadIdx.x & 1)] = t;
+    }
+}
+
+// one workgroup per hot slot: sums that slot's partial rows over the hot workgroups (groups of threads
+// take interleaved partials, then the groups are summed in order) and stores the G row
+__device__ __forceinline__ void hot_reduce_body(const HotArgs &a, int h, int kp) {
+    const int id = a.hot_ids[h];
+    if (id < 0) return;
+    const int PR = kp + kPartPad, R4 = PR / 4;
+    __shared__ float4 sh[kBlock];
+    const int G = kBlock / R4 < 1 ? 1 : kBlock / R4;   // thread groups (R4 <= 65 <= kBlock)
+    const int f = threadIdx.x % R4, g = threadIdx.x / R4;
+    float4 t = f4zero();
+    if (g < G)
+        for (int b = g; b < a.nblk; b += G) f4add(t, reinterpret_cast<const float4 *>(a.part + ((size_t)b * kHotT + h) * PR)[f]);
+    sh[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x < R4) {
+        float4 u = f4zero();
+        for (int gg = 0; gg < G; ++gg) f4add(u, sh[gg * R4 + threadIdx.x]);
+        if (threadIdx.x < kp / 4) {
+            reinterpret_cast<float4 *>(a.GV + (size_t)id * kp)[threadIdx.x] = u;
+        } else {
+            a.Gw[id] = a.pack_k >= 0 ? 0.f : u.x;
+            a.Gb[id] = u.y;
+        }
+    }
+}
+
 // One slot walks kRangeLen consecutive entries of the batch's CSC stream.  Column
 // boundaries inside the range are handled serially (flush + reset), so every slot does the
 // same amount of work whatever the column-length skew (power-law features), no atomics are
@@ -553,9 +756,14 @@ __device__ __forceinline__ void slots_reduce(float4 (&acc)[J], float &sa, float 
 //   wave sum   when the whole wave's span (64/LPN ranges) lies inside ONE column the slots are
 //              tree-summed in registers and a single partial is written for the wave.
 // k_fixup and the host-side split list (fmhip_api.hip) apply the same two predicates.
-template <int LPN, int J, bool PACKED>
+template <int LPN, int J, bool PACKED, bool HOT>
 __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
     constexpr int KP = 4 * LPN * J;
+    if (HOT && (int)blockIdx.x < a.hot_blocks) {
+        hot_backward_body<KP / 16>(a.hot, (int)blockIdx.x, a.hot_blocks);
+        return;
+    }
+    const int bx = HOT ? (int)blockIdx.x - a.hot_blocks : (int)blockIdx.x;
     constexpr int SLOTS = kBlock / LPN;
     constexpr int WS = 64 / LPN;                        // slots (ranges) per wave
     constexpr int PR = KP + kPartPad;
@@ -571,7 +779,7 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
     // xcd_chunk > 0: XCD-aware placement — workgroups b, b+8, b+16, .. share an XCD (round-robin
     // dispatch), so XCD x is given the x-th contiguous eighth of the stream: with a row-blocked
     // stream that is a few whole row blocks, whose slice of P then lives in that XCD's L2 only.
-    const int blk = a.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int blk = a.xcd_chunk > 0 ? (bx & 7) * a.xcd_chunk + (bx >> 3) : bx;
     const int rho = (a.rho_lo / SLOTS + blk) * SLOTS + threadIdx.x / LPN;
     if (rho < a.rho_lo || rho >= a.rho_hi) return;
     const int beg = rho * kRangeLen;
@@ -682,9 +890,16 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
 // value / e loads of a whole super-group (up to 64 entries) are issued up front, the P-row
 // gathers go through a buffer descriptor (dead entries fetch nothing) and are double-buffered in
 // chunks of CHB entries so chunk c+1 is in flight while chunk c is accumulated.
-template <int LPN, int J, bool PACKED>
-__global__ __launch_bounds__(kBlock) void k_backward_p(BwdArgs a) {
+// (HOT: the waves-per-SIMD bound keeps the MFMA accumulators of the hot body from costing the walkers
+// their third wave)
+template <int LPN, int J, bool PACKED, bool HOT>
+__global__ __launch_bounds__(kBlock, (HOT && J == 1 ? 3 : 1)) void k_backward_p(BwdArgs a) {
     constexpr int KP = 4 * LPN * J;
+    if (HOT && (int)blockIdx.x < a.hot_blocks) {
+        hot_backward_body<KP / 16>(a.hot, (int)blockIdx.x, a.hot_blocks);
+        return;
+    }
+    const int bx = HOT ? (int)blockIdx.x - a.hot_blocks : (int)blockIdx.x;
     constexpr int SLOTS = kBlock / LPN;
     constexpr int WS = 64 / LPN;
     constexpr int PR = KP + kPartPad;
@@ -702,7 +917,7 @@ __global__ __launch_bounds__(kBlock) void k_backward_p(BwdArgs a) {
     // xcd_chunk > 0: XCD-aware placement — workgroups b, b+8, b+16, .. share an XCD (round-robin
     // dispatch), so XCD x is given the x-th contiguous eighth of the stream: with a row-blocked
     // stream that is a few whole row blocks, whose slice of P then lives in that XCD's L2 only.
-    const int blk = a.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int blk = a.xcd_chunk > 0 ? (bx & 7) * a.xcd_chunk + (bx >> 3) : bx;
     const int rho = (a.rho_lo / SLOTS + blk) * SLOTS + threadIdx.x / LPN;
     if (rho < a.rho_lo || rho >= a.rho_hi) return;
     const __amdgpu_buffer_rsrc_t prs = make_rsrc(a.P, a.p_bytes);
@@ -887,7 +1102,7 @@ struct ColumnUnits {
     }
 };
 
-template <int LPN, int J>
+template <int LPN, int J, bool HOT>
 __global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
     constexpr int KP = 4 * LPN * J;
     constexpr int SLOTS = kBlock / LPN;
@@ -897,6 +1112,14 @@ __global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
         __shared__ double sh[3][kBlock / 64];
         reduce_blocks_body(a.red_bsum, a.red_nblocks, a.red_rows, a.red_scal, a.red_acc, sh);
         return;
+    }
+    if (HOT) {
+        // kHotT more workgroups finish the dense hot block's gradient rows
+        const int hot0 = (int)gridDim.x - (a.red_bsum ? 1 : 0) - kHotT;
+        if ((int)blockIdx.x >= hot0) {
+            hot_reduce_body(a.hot, (int)blockIdx.x - hot0, KP);
+            return;
+        }
     }
     const int lane = threadIdx.x & 63;
     const int l = lane & (LPN - 1);
@@ -1053,24 +1276,28 @@ __global__ __launch_bounds__(kBlock) void k_apply(ApplyArgs a) {
     }
 }
 
+
 template <int LPN, int J>
 hipError_t fwd_dispatch(FwdMode mode, const FwdArgs &a, hipStream_t s) {
     int64_t blocks = forward_blocks(4 * LPN * J, a.n_rows);
     dim3 g((unsigned)blocks), b(kBlock);
     int var = g_tune[kTuneFwd];
     if (a.pack_k >= 0) var = 0;              // packed rows carry w in the row: only the plain kernel handles them
-    if (var == 20 && !a.v_bytes) var = 0;    // the LDS V-tile kernel needs V to fit a 32-bit buffer view
+    if (var == 20 && (!a.v_bytes || a.hot_T)) var = a.hot_T ? 60 : 0;   // the LDS V-tile kernel needs V to fit a 32-bit buffer view; it has no hot-block prologue
     if (var == 60 && a.wt_rows > 0) {
         const size_t lds_bytes = (size_t)a.wt_rows * sizeof(float);
         int64_t nb = forward_blocks_wt(4 * LPN * J, a.n_rows);
         dim3 gw((unsigned)nb);
-        hipError_t e = hipSuccess;
+#define FMHIP_WT(MODE_)                                                                                  \
+    if (a.hot_T) hipLaunchKernelGGL((k_forward_wt<LPN, J, MODE_, true>), gw, b, lds_bytes, s, a);         \
+    else hipLaunchKernelGGL((k_forward_wt<LPN, J, MODE_, false>), gw, b, lds_bytes, s, a)
         switch (mode) {
-            case kFwdTrain: hipLaunchKernelGGL((k_forward_wt<LPN, J, kFwdTrain>), gw, b, lds_bytes, s, a); break;
-            case kFwdResidual: hipLaunchKernelGGL((k_forward_wt<LPN, J, kFwdResidual>), gw, b, lds_bytes, s, a); break;
-            case kFwdQ: hipLaunchKernelGGL((k_forward_wt<LPN, J, kFwdQ>), gw, b, lds_bytes, s, a); break;
+            case kFwdTrain: FMHIP_WT(kFwdTrain); break;
+            case kFwdResidual: FMHIP_WT(kFwdResidual); break;
+            case kFwdQ: FMHIP_WT(kFwdQ); break;
         }
-        return e != hipSuccess ? e : hipGetLastError();
+#undef FMHIP_WT
+        return hipGetLastError();
     }
     if (var == 20 && a.tile_rows > 0) {
         const size_t lds_bytes = (size_t)a.tile_rows * (4 * LPN * J + 1) * sizeof(float);
@@ -1092,41 +1319,44 @@ hipError_t fwd_dispatch(FwdMode mode, const FwdArgs &a, hipStream_t s) {
         }
         return e != hipSuccess ? e : hipGetLastError();
     }
-    if (a.pack_k >= 0) {
-        switch (mode) {
-            case kFwdTrain: hipLaunchKernelGGL((k_forward<LPN, J, kFwdTrain, true>), g, b, 0, s, a); break;
-            case kFwdResidual: hipLaunchKernelGGL((k_forward<LPN, J, kFwdResidual, true>), g, b, 0, s, a); break;
-            case kFwdQ: hipLaunchKernelGGL((k_forward<LPN, J, kFwdQ, true>), g, b, 0, s, a); break;
-        }
-    } else {
-        switch (mode) {
-            case kFwdTrain: hipLaunchKernelGGL((k_forward<LPN, J, kFwdTrain, false>), g, b, 0, s, a); break;
-            case kFwdResidual: hipLaunchKernelGGL((k_forward<LPN, J, kFwdResidual, false>), g, b, 0, s, a); break;
-            case kFwdQ: hipLaunchKernelGGL((k_forward<LPN, J, kFwdQ, false>), g, b, 0, s, a); break;
-        }
+#define FMHIP_FW(MODE_)                                                                                   \
+    if (a.pack_k >= 0) {                                                                                  \
+        if (a.hot_T) hipLaunchKernelGGL((k_forward<LPN, J, MODE_, true, true>), g, b, 0, s, a);           \
+        else hipLaunchKernelGGL((k_forward<LPN, J, MODE_, true, false>), g, b, 0, s, a);                  \
+    } else {                                                                                              \
+        if (a.hot_T) hipLaunchKernelGGL((k_forward<LPN, J, MODE_, false, true>), g, b, 0, s, a);          \
+        else hipLaunchKernelGGL((k_forward<LPN, J, MODE_, false, false>), g, b, 0, s, a);                 \
     }
+    switch (mode) {
+        case kFwdTrain: FMHIP_FW(kFwdTrain) break;
+        case kFwdResidual: FMHIP_FW(kFwdResidual) break;
+        case kFwdQ: FMHIP_FW(kFwdQ) break;
+    }
+#undef FMHIP_FW
     return hipGetLastError();
 }
 
 template <int LPN, int J>
 hipError_t bwd_dispatch(const BwdArgs &a, hipStream_t s) {
     constexpr int SLOTS = kBlock / LPN;
-    if (a.rho_hi <= a.rho_lo) return hipSuccess;
-    const int first_block = a.rho_lo / SLOTS, last_block = (a.rho_hi - 1) / SLOTS;
-    const int nblk = last_block - first_block + 1;
+    if (a.rho_hi <= a.rho_lo && a.hot_blocks < 1) return hipSuccess;
+    int nblk = 0;
+    if (a.rho_hi > a.rho_lo) nblk = (a.rho_hi - 1) / SLOTS - a.rho_lo / SLOTS + 1;
     BwdArgs a2 = a;
     a2.xcd_chunk = a.xcd_chunk > 0 ? (nblk + 7) / 8 : 0;      // blocks per XCD
-    dim3 g((unsigned)(a2.xcd_chunk > 0 ? a2.xcd_chunk * 8 : nblk)), b(kBlock);
+    dim3 g((unsigned)((a2.xcd_chunk > 0 ? a2.xcd_chunk * 8 : nblk) + a.hot_blocks)), b(kBlock);
     // the pipelined kernel needs P to fit a 32-bit buffer view (< 4 GiB per batch); for k > 64 (J > 1)
     // its register footprint spills, so those sizes take the plain walk
     const bool pipe = J == 1 && a.p_bytes && g_tune[kTuneBwd] == 1;
+#define FMHIP_BW(PACKED_, HOT_)                                                               \
+    if (pipe) hipLaunchKernelGGL((k_backward_p<LPN, J, PACKED_, HOT_>), g, b, 0, s, a2);      \
+    else hipLaunchKernelGGL((k_backward<LPN, J, PACKED_, HOT_>), g, b, 0, s, a2)
     if (a.pack_k >= 0) {
-        if (pipe) hipLaunchKernelGGL((k_backward_p<LPN, J, true>), g, b, 0, s, a2);
-        else hipLaunchKernelGGL((k_backward<LPN, J, true>), g, b, 0, s, a2);
+        if (a.hot_blocks > 0) { FMHIP_BW(true, true); } else { FMHIP_BW(true, false); }
     } else {
-        if (pipe) hipLaunchKernelGGL((k_backward_p<LPN, J, false>), g, b, 0, s, a2);
-        else hipLaunchKernelGGL((k_backward<LPN, J, false>), g, b, 0, s, a2);
+        if (a.hot_blocks > 0) { FMHIP_BW(false, true); } else { FMHIP_BW(false, false); }
     }
+#undef FMHIP_BW
     return hipGetLastError();
 }
 
@@ -1134,9 +1364,11 @@ template <int LPN, int J>
 hipError_t fix_dispatch(const BwdArgs &a, hipStream_t s) {
     constexpr int SLOTS = kBlock / LPN;
     const int extra = a.red_bsum ? 1 : 0;
-    if (a.n_split < 1 && a.n_split_short < 1 && !extra) return hipSuccess;
-    dim3 g((unsigned)((a.n_split_short + SLOTS - 1) / SLOTS + a.n_split + extra)), b(kBlock);
-    hipLaunchKernelGGL((k_fixup<LPN, J>), g, b, 0, s, a);
+    const int hot = a.hot_blocks > 0 ? kHotT : 0;
+    if (a.n_split < 1 && a.n_split_short < 1 && !extra && !hot) return hipSuccess;
+    dim3 g((unsigned)((a.n_split_short + SLOTS - 1) / SLOTS + a.n_split + hot + extra)), b(kBlock);
+    if (hot) hipLaunchKernelGGL((k_fixup<LPN, J, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_fixup<LPN, J, false>), g, b, 0, s, a);
     return hipGetLastError();
 }
 
@@ -1182,6 +1414,13 @@ hipError_t launch_fixup2(int Kp, const BwdArgs &a, hipStream_t s) {
 #define CALL(L_, J_) fix2_dispatch<L_, J_>(a, s)
     FMHIP_KP_SWITCH(Kp, CALL)
 #undef CALL
+}
+
+int hot_blocks(int Kp, int64_t n_rows) {
+    (void)Kp;
+    int64_t b = (n_rows + 63) / 64;       // at least 16 rows per wave
+    if (b > 256) b = 256;                 // one hot workgroup per CU, next to the column walkers
+    return b < 1 ? 1 : (int)b;
 }
 
 hipError_t launch_apply(int Kp, const ApplyArgs &a, hipStream_t s) {

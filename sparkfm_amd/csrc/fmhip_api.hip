@@ -91,6 +91,8 @@ struct BatchMeta {
     int32_t n_mp = 0;       // features cut into several pieces (one per row block they occur in)
     int64_t mp_off = 0;     // offset into mp_feat; mp_ptr offset is mp_off + batch index
     int32_t n_pieces = 0;   // piece rows those features need
+    int64_t nnz_total = 0;  // stored nonzeros of the batch incl. those held in the dense hot block
+    uint32_t hot_mask = 0;  // hot slots with at least one nonzero in this batch
 };
 
 struct ProfRec {
@@ -116,6 +118,13 @@ struct fmhip_dataset {
     std::vector<int32_t> h_cfeat, h_cptr, h_split, h_split_short;   // host copies (feature-chunked backward needs them)
     int64_t rb_rows = 0;       // rows per row block of the transposes (0 = not row-blocked)
     int32_t max_pieces = 0;
+    // dense hot block: the entries of the (up to kHotT) most frequent features are held as a dense
+    // [n_rows][kHotT] fp32 array instead of in the sparse streams (0 where the feature is absent)
+    int32_t hot_T = 0;                 // 0 = no hot block
+    std::vector<int32_t> hot_ids;      // [kHotT] feature id per slot, -1 = unused slot
+    DevBuf<float> xhot;
+    DevBuf<int32_t> d_hot_ids;
+    int64_t nnz_sparse = 0;
     // fp64 copies of the values (CSR order, CSC order) and labels for the fp64 ALS learner; kept only
     // for single-batch datasets of at most kAlsMaxNnz stored nonzeros
     DevBuf<double> val64, cval64, y64;
@@ -131,7 +140,8 @@ struct fmhip_model {
     DevBuf<float> grad_own;
     float *grad = nullptr;        // packed gradient in use (own or bound)
     bool grad_dirty = false;      // holds a gradient that has not been applied/zeroed
-    DevBuf<float> P, e, part, pieces;
+    DevBuf<float> P, e, part, pieces, hot_part;
+    bool hot_pending = false;   // the dense hot block's gradient of the current step is still to be formed
     DevBuf<double> acc;           // {sum e, sum e^2, rows, nonfinite}
     DevBuf<double> bsum;          // k_forward's per-block statistic partials
     int64_t last_nnz = 0, last_rows = 0;
@@ -278,12 +288,87 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     if (batch_rows <= 0 || batch_rows > n_rows) batch_rows = std::max<int64_t>(n_rows, 1);
     d->batch_rows = batch_rows;
     const int64_t nb = n_rows > 0 ? (n_rows + batch_rows - 1) / batch_rows : 0;
+    // ---- dense hot block (fmhip_tune key 5): features present in >= 10 % of the rows (the kHotT most
+    // frequent of them) leave the sparse streams; x_rh sits in xhot[r][slot].  A second occurrence of a
+    // hot feature inside one row stays sparse.  Single-batch datasets (the ALS learner walks their
+    // whole transpose) are never split.
+    const int64_t *orig_row_ptr = row_ptr;
+    std::vector<int64_t> sp_ptr;
+    std::vector<int32_t> sp_col;
+    std::vector<float> sp_val, xhot;
+    std::vector<uint32_t> hot_masks;
+    bool split = false;
+    if (g_tune[kTuneHot] > 0 && nb > 1 && nnz > 0) {
+        std::vector<int64_t> cnt((size_t)dim + 1, 0);
+        for (int64_t p = 0; p < nnz; ++p) ++cnt[(size_t)col[p]];
+        std::vector<int32_t> cand;
+        for (int32_t f = 0; f <= dim; ++f)
+            if (cnt[(size_t)f] * 10 >= n_rows) cand.push_back(f);
+        std::sort(cand.begin(), cand.end(), [&](int32_t x, int32_t y) { return cnt[(size_t)x] != cnt[(size_t)y] ? cnt[(size_t)x] > cnt[(size_t)y] : x < y; });
+        if (cand.size() > (size_t)kHotT) cand.resize(kHotT);
+        {
+            // a candidate that occurs twice in one row, or is stored with an explicit zero, keeps the
+            // sparse path (its G row must have exactly one writer)
+            std::vector<int8_t> cslot((size_t)dim + 1, -1);
+            for (size_t h = 0; h < cand.size(); ++h) cslot[(size_t)cand[h]] = (int8_t)h;
+            uint32_t bad = 0;
+            for (int64_t r = 0; r < n_rows; ++r) {
+                uint32_t seen = 0;
+                for (int64_t p = row_ptr[r]; p < row_ptr[r + 1]; ++p) {
+                    const int8_t h = cslot[(size_t)col[p]];
+                    if (h < 0) continue;
+                    if ((seen >> h & 1u) || (float)val[p] == 0.f) bad |= 1u << h;
+                    seen |= 1u << h;
+                }
+            }
+            std::vector<int32_t> ok;
+            for (size_t h = 0; h < cand.size(); ++h)
+                if (!(bad >> h & 1u)) ok.push_back(cand[h]);
+            cand.swap(ok);
+        }
+        if (cand.size() >= 2) {
+            std::sort(cand.begin(), cand.end());
+            d->hot_ids.assign(kHotT, -1);
+            std::vector<int8_t> slot((size_t)dim + 1, -1);
+            for (size_t h = 0; h < cand.size(); ++h) { d->hot_ids[h] = cand[h]; slot[(size_t)cand[h]] = (int8_t)h; }
+            xhot.assign((size_t)n_rows * kHotT, 0.f);
+            sp_ptr.assign((size_t)n_rows + 1, 0);
+            sp_col.reserve((size_t)nnz);
+            sp_val.reserve((size_t)nnz);
+            hot_masks.assign((size_t)nb, 0u);
+            for (int64_t r = 0; r < n_rows; ++r) {
+                uint32_t seen = 0;
+                for (int64_t p = row_ptr[r]; p < row_ptr[r + 1]; ++p) {
+                    const int8_t h = slot[(size_t)col[p]];
+                    if (h >= 0) {
+                        seen |= 1u << h;
+                        xhot[(size_t)r * kHotT + h] = (float)val[p];
+                    } else {
+                        sp_col.push_back(col[p]);
+                        sp_val.push_back((float)val[p]);
+                    }
+                }
+                hot_masks[(size_t)(r / batch_rows)] |= seen;
+                sp_ptr[(size_t)r + 1] = (int64_t)sp_col.size();
+            }
+            split = true;
+            d->hot_T = kHotT;
+        }
+    }
+    if (split) {
+        row_ptr = sp_ptr.data();
+        col = sp_col.data();
+    }
+    const int64_t nnz_s = split ? (int64_t)sp_col.size() : nnz;
+    d->nnz_sparse = nnz_s;
     d->batches.resize((size_t)nb);
     for (int64_t b = 0; b < nb; ++b) {
         BatchMeta &bm = d->batches[(size_t)b];
         bm.row0 = b * batch_rows;
         bm.rows = std::min(batch_rows, n_rows - bm.row0);
         bm.nnz0 = row_ptr[bm.row0];
+        bm.nnz_total = orig_row_ptr[bm.row0 + bm.rows] - orig_row_ptr[bm.row0];
+        bm.hot_mask = split ? hot_masks[(size_t)b] : 0u;
         const int64_t bn = row_ptr[bm.row0 + bm.rows] - bm.nnz0;
         if (bn > (int64_t)0x7fffffff - 2 * kRangeLen || bm.rows > 0x7fffffff) {
             delete d;
@@ -294,14 +379,15 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
         d->max_rows = std::max(d->max_rows, bm.rows);
     }
     // fp32 copies of the streams (device arithmetic is fp32)
-    std::vector<float> valf((size_t)nnz), yf((size_t)n_rows);
-    for (int64_t p = 0; p < nnz; ++p) valf[(size_t)p] = (float)val[p];
+    std::vector<float> valf((size_t)nnz_s), yf((size_t)n_rows);
+    for (int64_t p = 0; p < nnz_s; ++p) valf[(size_t)p] = split ? sp_val[(size_t)p] : (float)val[p];
     for (int64_t r = 0; r < n_rows; ++r) yf[(size_t)r] = (float)y[r];
-    const bool keep64 = nb == 1 && nnz <= kAlsMaxNnz;
+    const bool keep64 = !split && nb == 1 && nnz <= kAlsMaxNnz;
     int rc = FMHIP_OK;
-    if ((rc = upload(d->row_ptr, row_ptr, (size_t)n_rows + 1)) || (rc = upload(d->col, col, (size_t)nnz)) ||
-        (rc = upload(d->val, valf.data(), (size_t)nnz)) || (rc = upload(d->y, yf.data(), (size_t)n_rows)) ||
-        (rc = d->crow.alloc((size_t)nnz)) || (rc = d->cval.alloc((size_t)nnz))) {
+    if ((rc = upload(d->row_ptr, row_ptr, (size_t)n_rows + 1)) || (rc = upload(d->col, col, (size_t)nnz_s)) ||
+        (rc = upload(d->val, valf.data(), (size_t)nnz_s)) || (rc = upload(d->y, yf.data(), (size_t)n_rows)) ||
+        (rc = d->crow.alloc((size_t)nnz_s)) || (rc = d->cval.alloc((size_t)nnz_s)) ||
+        (split && ((rc = upload(d->xhot, xhot.data(), xhot.size())) || (rc = upload(d->d_hot_ids, d->hot_ids.data(), d->hot_ids.size()))))) {
         delete d;
         return rc;
     }
@@ -445,6 +531,7 @@ int ensure_workspace(fmhip_model_t m, fmhip_dataset_t d) {
     TRY(m->part.ensure((size_t)std::max<int32_t>(d->max_ranges, 1) * 2 * (m->Kp + kPartPad)));
     TRY(m->pieces.ensure((size_t)std::max<int32_t>(d->max_pieces, 1) * (m->Kp + kPartPad)));
     TRY(m->bsum.ensure((size_t)kMaxFwdBlocks * 4));
+    if (d->hot_T) TRY(m->hot_part.ensure((size_t)hot_blocks(m->Kp, d->max_rows) * kHotT * (m->Kp + kPartPad)));
     return FMHIP_OK;
 }
 
@@ -479,6 +566,9 @@ FwdArgs fwd_args(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm) {
     a.e = m->e.p;
     a.yhat = nullptr;
     a.pack_k = m->pack_k();
+    a.hot_T = d->hot_T;
+    a.xhot = d->hot_T ? d->xhot.p + (size_t)bm.row0 * kHotT : nullptr;
+    a.hot_ids = d->d_hot_ids.p;
     a.bsum = m->bsum.p;
     {
         // LDS V-tile size: as many hot rows as fit 128 KiB (+ their w), capped by the model
@@ -535,14 +625,36 @@ int step_forward(fmhip_model_t m, fmhip_dataset_t d, int64_t b) {
         m->grad_dirty = false;
     }
     {
-        ProfScope ps(m, FMHIP_K_FORWARD, bm.nnz, bm.rows);
+        ProfScope ps(m, FMHIP_K_FORWARD, bm.nnz_total, bm.rows);
         HIP_TRY(launch_forward(m->Kp, kFwdTrain, fwd_args(m, d, bm), m->stream));
     }
     m->grad_dirty = true;
-    m->last_nnz = bm.nnz;
+    m->last_nnz = bm.nnz_total;
     m->last_rows = bm.rows;
     m->bw_next_hi = INT64_MAX;
+    m->hot_pending = d->hot_T > 0;
     return FMHIP_OK;
+}
+
+// gradient rows of the dense hot block (whole batch; they do not depend on the feature interval, so
+// the first backward call of a step forms them and every later interval finds them complete): the
+// work rides in that call's backward and fixup launches
+void hot_attach(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm, BwdArgs &ba) {
+    if (!m->hot_pending) return;
+    HotArgs &h = ba.hot;
+    h.P = m->P.p;
+    h.e = m->e.p;
+    h.xhot = d->xhot.p + (size_t)bm.row0 * kHotT;
+    h.hot_ids = d->d_hot_ids.p;
+    h.part = m->hot_part.p;
+    h.GV = m->GV();
+    h.Gw = m->Gw();
+    h.Gb = m->Gb();
+    h.n_rows = (int32_t)bm.rows;
+    h.pack_k = m->pack_k();
+    h.nblk = hot_blocks(m->Kp, bm.rows);
+    ba.hot_blocks = h.nblk;
+    m->hot_pending = false;
 }
 
 // backward + fixup of the columns whose feature id lies in [feat_lo, feat_hi) into the packed
@@ -555,6 +667,7 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
                   double *acc) {
     const BatchMeta &bm = d->batches[(size_t)b];
     BwdArgs ba = bwd_args(m, d, b);
+    hot_attach(m, d, bm, ba);
     const bool whole = feat_lo <= 0 && feat_hi >= m->n1;
     if (d->rb_rows > 0 && !whole)
         return fail(FMHIP_ERR_UNSUPPORTED, "feature-interval backward is not available on a row-blocked dataset");
@@ -567,11 +680,11 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
             ba.red_acc = acc;
         }
         {
-            ProfScope ps(m, FMHIP_K_BACKWARD, bm.nnz, bm.rows);
+            ProfScope ps(m, FMHIP_K_BACKWARD, bm.nnz_total, bm.rows);
             HIP_TRY(launch_backward(m->Kp, ba, m->stream));
         }
         {
-            ProfScope ps(m, FMHIP_K_FIXUP, bm.nnz, bm.rows);
+            ProfScope ps(m, FMHIP_K_FIXUP, bm.nnz_total, bm.rows);
             HIP_TRY(launch_fixup(m->Kp, ba, m->stream));
             HIP_TRY(launch_fixup2(m->Kp, ba, m->stream));
         }
@@ -856,8 +969,8 @@ int fmhip_dataset_batch_info(fmhip_dataset_t d, int64_t batch, int64_t *row0, in
     const BatchMeta &bm = d->batches[(size_t)batch];
     if (row0) *row0 = bm.row0;
     if (rows) *rows = bm.rows;
-    if (nnz) *nnz = bm.nnz;
-    if (n_columns) *n_columns = bm.n_feats;
+    if (nnz) *nnz = bm.nnz_total;
+    if (n_columns) *n_columns = bm.n_feats + __builtin_popcount(bm.hot_mask);
     return FMHIP_OK;
 }
 
@@ -879,10 +992,37 @@ int fmhip_dataset_get_transpose(fmhip_dataset_t d, int64_t batch, int32_t *feat,
     std::vector<int32_t> order((size_t)bm.n_cols);
     for (int32_t s = 0; s < bm.n_cols; ++s) order[(size_t)s] = s;
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return hf[x] < hf[y]; });
+    // the dense hot block's columns (never present in the sparse stream) are merged in by feature id
+    std::vector<float> hx;
+    if (bm.hot_mask) {
+        hx.resize((size_t)bm.rows * kHotT);
+        HIP_TRY(hipMemcpy(hx.data(), d->xhot.p + (size_t)bm.row0 * kHotT, hx.size() * sizeof(float), hipMemcpyDeviceToHost));
+    }
     int32_t nf = 0, pos = 0;
+    int hnext = 0;
+    auto emit_hot_below = [&](int64_t bound) {
+        for (; hnext < kHotT; ++hnext) {
+            if (!bm.hot_mask) { hnext = kHotT; break; }
+            const int32_t id = d->hot_ids[(size_t)hnext];
+            if (id < 0 || !(bm.hot_mask >> hnext & 1u)) continue;
+            if ((int64_t)id >= bound) break;
+            if (feat) feat[nf] = id;
+            if (ptr) ptr[nf] = pos;
+            ++nf;
+            for (int64_t r = 0; r < bm.rows; ++r) {
+                const float x = hx[(size_t)r * kHotT + hnext];
+                if (x != 0.f) {
+                    if (rows) rows[pos] = (int32_t)r;
+                    if (vals) vals[pos] = x;
+                    ++pos;
+                }
+            }
+        }
+    };
     for (int32_t i = 0; i < bm.n_cols; ++i) {
         const int32_t s = order[(size_t)i];
         if (i == 0 || hf[s] != hf[order[(size_t)i - 1]]) {
+            emit_hot_below(hf[s]);
             if (feat) feat[nf] = hf[s];
             if (ptr) ptr[nf] = pos;
             ++nf;
@@ -892,6 +1032,7 @@ int fmhip_dataset_get_transpose(fmhip_dataset_t d, int64_t batch, int32_t *feat,
             if (vals) vals[pos] = hval[(size_t)p];
         }
     }
+    emit_hot_below(INT64_MAX);
     if (ptr) ptr[nf] = pos;
     return FMHIP_OK;
 }
@@ -975,7 +1116,7 @@ int fmhip_sgd_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double eta
     if (stats) {
         memset(stats, 0, sizeof *stats);
         TRY(read_scal(m, stats));
-        stats->nnz = d->batches[(size_t)batch].nnz;
+        stats->nnz = d->batches[(size_t)batch].nnz_total;
         stats->steps = 1;
     }
     return step_apply(m, eta, reg0, regw, regv);
@@ -1027,7 +1168,7 @@ int fmhip_batch_grad(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double *
         stats->sse = sc[1];
         stats->rows = (int64_t)llround(sc[2]);
         stats->nonfinite = (int64_t)llround(sc[3]);
-        stats->nnz = d->batches[(size_t)batch].nnz;
+        stats->nnz = d->batches[(size_t)batch].nnz_total;
     }
     return FMHIP_OK;
 }

@@ -195,6 +195,124 @@ def test_row_blocked_transposes(fmhip, rb):
         L.fmhip_tune(3, 0)
 
 
+def hot_problem(seed, n_rows, n1, k, n_hot, dup_feature=None, zero_feature=None):
+    """Rows over n1 features of which the first n_hot (scattered over the id range) occur in 15-95 % of
+    the rows; optionally one hot feature occurs twice in some rows / is stored with explicit zeros."""
+    rng = np.random.default_rng(seed)
+    hot_ids = np.sort(rng.choice(n1, size=n_hot, replace=False))
+    freq = rng.uniform(0.15, 0.95, n_hot)
+    cold = np.setdiff1d(np.arange(n1), hot_ids)
+    rows, vals = [], []
+    for r in range(n_rows):
+        idx = list(hot_ids[rng.random(n_hot) < freq])
+        idx += list(rng.choice(cold, size=int(rng.integers(0, 6)), replace=False))
+        x = list(rng.uniform(0.1, 1.0, len(idx)))
+        if dup_feature is not None and r % 7 == 0:
+            idx.append(hot_ids[dup_feature]); x.append(0.5)
+        if zero_feature is not None and r % 5 == 0 and hot_ids[zero_feature] not in idx:
+            idx.append(hot_ids[zero_feature]); x.append(0.0)
+        perm = rng.permutation(len(idx))
+        rows.append(np.asarray(idx, np.int32)[perm]); vals.append(np.asarray(x)[perm])
+    row_ptr = np.zeros(n_rows + 1, np.int64)
+    row_ptr[1:] = np.cumsum([len(r) for r in rows])
+    return dict(k=k, n1=n1, w0=0.25, w=rng.normal(0, 0.1, n1), v=rng.normal(0, 0.1, (k, n1)), row_ptr=row_ptr,
+                col=np.concatenate(rows), val=np.concatenate(vals), y=rng.normal(0, 1, n_rows)), hot_ids
+
+
+@pytest.mark.parametrize("k,n_hot,dup,zero", [(32, 16, None, None), (32, 20, None, None), (16, 5, None, None),
+                                                (64, 9, 2, None), (100, 16, None, 3), (8, 12, 0, 1)])
+def test_dense_hot_block(fmhip, k, n_hot, dup, zero):
+    """fmhip_tune(5, 1): the most frequent features (>= 10 % of the rows, at most 16, none that occurs
+    twice in a row or with a stored zero) leave the sparse streams for a dense [rows][16] block.
+    Forward, gradient, transposes, epochs and the feature-chunked backward must not notice."""
+    from sparkfm_amd import _ffi
+    L = _ffi.load()
+    a, hot_ids = hot_problem(100 + k, 3000, 500, k, n_hot, dup, zero)
+    a["val"] = a["val"].astype(np.float32).astype(np.float64)       # exactly representable in fp32
+    n_rows, br = 3000, 700
+    try:
+        L.fmhip_tune(5, 1)
+        ds, fm = make(fmhip, a, batch_rows=br)
+    finally:
+        L.fmhip_tune(5, 0)
+    # scoring
+    yh = fm.predict(ds)
+    oy = oracle.predict(a["w0"], a["w"], a["v"], a["row_ptr"], a["col"], a["val"])
+    assert (np.abs(yh - oy) <= TOL_Y * term_scale(a)).all()
+    assert fm.computeRMSE(ds) == pytest.approx(oracle.rmse(a["w0"], a["w"], a["v"], a["row_ptr"], a["col"], a["val"], a["y"]), rel=1e-5)
+    # transposes: the caller sees every feature, hot or not, bit-exact
+    for j in range(ds.n_batches):
+        lo, hi = j * br, min(n_rows, (j + 1) * br)
+        sub = a["row_ptr"][lo:hi + 1] - a["row_ptr"][lo]
+        sl = slice(a["row_ptr"][lo], a["row_ptr"][hi])
+        cp, rows, cv = oracle.transpose(a["n1"], sub, a["col"][sl], a["val"][sl])
+        feat, ptr, drows, dvals = ds.transposeInput(j)
+        present = np.nonzero(np.diff(cp))[0]
+        np.testing.assert_array_equal(feat, present.astype(np.int32))
+        np.testing.assert_array_equal(ptr, cp[np.r_[present, a["n1"]]].astype(np.int32))
+        np.testing.assert_array_equal(drows, rows)
+        np.testing.assert_array_equal(dvals.astype(np.float64), cv)
+    # gradient of every batch, and its run-to-run identity
+    for j in range(ds.n_batches):
+        lo, hi = j * br, min(n_rows, (j + 1) * br)
+        gv, gw, g0, st = fm.batchGradient(ds, j)
+        ogv, ogw, og0, osse, _ = oracle.batch_grad(a["w0"], a["w"], a["v"], lo, hi, a["row_ptr"], a["col"], a["val"], a["y"],
+                                                   threads=4)
+        check_grad(gv, gw, ogv, ogw, np.abs(a["v"]).max())
+        assert st["nnz"] == a["row_ptr"][hi] - a["row_ptr"][lo]
+        gv2, gw2, _, _ = fm.batchGradient(ds, j)
+        np.testing.assert_array_equal(gv, gv2)
+        np.testing.assert_array_equal(gw, gw2)
+    # training
+    eta, regs = 0.02, (0.0, 1e-3, 1e-3)
+    sgd = fmhip.HipSGD(eta=eta, reg0=regs[0], regw=regs[1], regv=regs[2])
+    w0, w, v = a["w0"], a["w"], a["v"]
+    for _ in range(3):
+        fm = sgd.learn(fm, ds)
+        w0, w, v, sse = oracle.sgd_epoch(w0, w, v, br, a["row_ptr"], a["col"], a["val"], a["y"], eta, *regs)
+        assert sgd.last_stats["sse"] == pytest.approx(sse, rel=1e-5)
+    assert np.linalg.norm(fm.v - v) <= 1e-4 * np.linalg.norm(v)
+    assert np.linalg.norm(fm.w - w) <= 1e-4 * np.linalg.norm(w)
+    ds.unpersist()
+    fm.close()
+
+
+def test_dense_hot_block_chunked_backward(fmhip):
+    """The feature-interval backward on a dataset with a dense hot block: the hot rows are complete
+    after the first interval's call, whatever interval their ids fall into."""
+    import ctypes as C
+    from sparkfm_amd import _ffi
+    L = _ffi.load()
+    a, hot_ids = hot_problem(77, 2500, 600, 32, 14)
+    try:
+        L.fmhip_tune(5, 1)
+        ds, fm = make(fmhip, a, batch_rows=900)
+    finally:
+        L.fmhip_tune(5, 0)
+    import torch
+    from sparkfm_amd.distributed import HipEngine
+    eng = HipEngine(fm, ds)
+    for batch in range(ds.n_batches):
+        eng.compute(batch)
+        torch.cuda.synchronize()
+        want = eng.grad.clone()
+        eng.grad.zero_()
+        torch.cuda.synchronize()
+        _ffi.check(L.fmhip_grad_bind(fm.handle, C.c_void_p(eng.grad.data_ptr())))   # marks the zeroed buffer clean
+        for cuts in ([0, 600], [0, 37, 300, 301, 600], [0, int(hot_ids[3]), int(hot_ids[3]) + 1, 600]):
+            eng.forward(batch)
+            for i in range(len(cuts) - 1, 0, -1):
+                eng.backward(batch, cuts[i - 1], cuts[i], finish=(i == 1))
+            torch.cuda.synchronize()
+            assert torch.equal(eng.grad, want), cuts
+            eng.grad.zero_()
+            torch.cuda.synchronize()
+            _ffi.check(L.fmhip_grad_bind(fm.handle, C.c_void_p(eng.grad.data_ptr())))
+    eng.close()
+    ds.unpersist()
+    fm.close()
+
+
 def test_transpose_is_bit_exact(fmhip):
     """The device-resident per-batch transposes (S/DataSet.scala:31-38) against the oracle's:
     feature ids, row ids and values must match exactly (index gathers are bit-exact)."""

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--row-block", type=int, default=0, help="rows per row block of the transposes (fmhip_tune key 3)")
     ap.add_argument("--xcd", type=int, default=0, help="XCD-aware workgroup placement in the backward (fmhip_tune key 4)")
+    ap.add_argument("--hot", type=int, default=0, help="dense hot block for the most frequent features (fmhip_tune key 5)")
     ap.add_argument("--tile", type=int, default=0, help="LDS V-tile rows for forward variant 20 (0 = auto: 128 KiB)")
     args = ap.parse_args()
     from sparkfm_amd import DataSet, FMModel, _ffi, synth
@@ -38,6 +39,7 @@ def main():
     w0, w, v = synth.init_params(1, n1, k)
     if args.row_block:
         _ffi.load().fmhip_tune(3, args.row_block)
+    _ffi.load().fmhip_tune(5, args.hot)
     ds = DataSet.from_arrays(d, batch_rows=min(args.batch_rows, rows)).cache()
     fm = FMModel(n1 - 1, k)
     fm.w0, fm.w, fm.v = w0, w, v

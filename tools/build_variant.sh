@@ -1,0 +1,22 @@
+#!/bin/bash
+# Builds the library from another git revision into sparkfm_amd/lib/libfmhip_<name>.so (A/B runs on one
+# GPU box: FMHIP_LIB=sparkfm_amd/lib/libfmhip_<name>.so python tools/ab_bench.py ...).
+#   tools/build_variant.sh <name> [git-rev, default HEAD]
+set -e
+name=$1; rev=${2:-HEAD}
+root=$(cd "$(dirname "$0")/.." && pwd)
+tmp=$(mktemp -d /tmp/fmhip_variant.XXXXXX)
+mkdir -p $tmp/sparkfm_amd/csrc $tmp/include
+for f in fm_kernels.hip fm_kernels.h als_kernels.hip als_kernels.h csc_build.hip csc_build.h fmhip_api.hip; do
+  git -C $root show $rev:sparkfm_amd/csrc/$f > $tmp/sparkfm_amd/csrc/$f
+done
+git -C $root show $rev:include/fmhip.h > $tmp/include/fmhip.h
+objs=""
+for f in fm_kernels als_kernels csc_build fmhip_api; do
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -c $tmp/sparkfm_amd/csrc/$f.hip -o $tmp/$f.o &
+  objs="$objs $tmp/$f.o"
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/sparkfm_amd/lib/libfmhip_$name.so $objs -Wl,-rpath,/opt/rocm/lib -lpthread
+rm -rf $tmp
+echo $root/sparkfm_amd/lib/libfmhip_$name.so
