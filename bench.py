@@ -144,6 +144,11 @@ def main():
                     help="self-test: take the data-parallel path (RCCL all-reduce included) even with one rank")
     ap.add_argument("--cpu-budget", type=float, default=30.0)
     args = ap.parse_args()
+    # stdout carries exactly one JSON line: libraries that print banners to fd 1 (RCCL prints its
+    # version block there at communicator creation) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -289,7 +294,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(d, k, n1, batch_rows, args.eta, regs, w0, w, v, args.cpu_budget)
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
             out["als_c1"] = als_c1(local_rank)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dp:
         dist.barrier()
         dist.destroy_process_group()

@@ -163,10 +163,13 @@ int fmhip_batch_grad(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double *
 int fmhip_als_epoch(fmhip_model_t m, fmhip_dataset_t d, double reg0, double regw, double regv);
 
 /* ---- data-parallel split step ---------------------------------------------------
- * packed fp32 gradient: [ G_V (n1p*Kp) | G_w (n1p) | G_b (n1p) | scalars (8) ], n1p = n+1
- * rounded up to 4, Kp = padded factors.  G_V holds sum e*x*q; G_b holds sum e*x^2 (the
- * -x^2*v term of h is applied in fmhip_step_apply, so the packed buffer is a plain sum
- * over rows and all-reduces with `sum`).  scalars = {sum e, sum e^2, rows, nonfinite}. */
+ * packed fp32 gradient: [ scalars (32, 8 used) | G_w (n1p) | G_b (n1p) | pad to 32 | G_V (n1p*Kp) ],
+ * n1p = n+1 rounded up to 4, Kp = padded factors; fmhip_grad_layout returns Kp and the offset of
+ * G_V.  G_V holds sum e*x*q; G_b holds sum e*x^2 (the -x^2*v term of h is applied in
+ * fmhip_step_apply, so the packed buffer is a plain sum over rows and all-reduces with `sum`).
+ * scalars = {sum e, sum e^2, rows, nonfinite}.  The head (everything before G_V) lies next to the
+ * G_V rows of the lowest feature ids — the interval a feature-chunked backward finishes last — so
+ * the last collective of a step can cover head + interval in one message. */
 int fmhip_grad_floats(fmhip_model_t m, int64_t *n_floats);
 /* use caller-owned DEVICE memory (e.g. a torch tensor the host all-reduces); NULL = internal.
  * The buffer must be zero-filled by the caller before the first step. */
@@ -179,13 +182,13 @@ int fmhip_step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t batch);
  *                                            disjoint intervals covering [0, n+1) in DESCENDING order
  *                                            (the cold, high-id features first: most of the gradient
  *                                            volume, least of the work), finish = 1 on the last one
- * After a call returns, floats [lo*row_floats, hi*row_floats) of the packed buffer are final and can
- * be all-reduced while the next interval computes; floats [gv_floats, end) (G_w | G_b | scalars) are
- * final after the call with finish = 1. */
+ * After a call returns, floats [gv_offset + lo*row_floats, gv_offset + hi*row_floats) of the packed
+ * buffer are final and can be all-reduced while the next interval computes; the head, floats
+ * [0, gv_offset) (scalars | G_w | G_b), is final after the call with finish = 1. */
 int fmhip_step_forward(fmhip_model_t m, fmhip_dataset_t d, int64_t batch);
 int fmhip_step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, int64_t feat_lo, int64_t feat_hi,
                         int finish);
-int fmhip_grad_layout(fmhip_model_t m, int64_t *row_floats, int64_t *gv_floats);
+int fmhip_grad_layout(fmhip_model_t m, int64_t *row_floats, int64_t *gv_offset);
 /* applies the packed gradient (after the host's all-reduce, if any), then zeroes it */
 int fmhip_step_apply(fmhip_model_t m, double eta, double reg0, double regw, double regv);
 /* scalars of the packed gradient as last computed/all-reduced (synchronises) */

@@ -9,6 +9,7 @@ constexpr int kRangeLen = 64;      // == FMHIP_RANGE_LEN
 constexpr int kExtend = 16;        // a slot finishes a column that ends this close behind its range
 constexpr int kPartPad = 4;        // partial row = Kp floats + {sum e*x, sum e*x^2, pad, pad}
 constexpr int kScalars = 8;        // packed-gradient tail: {sum e, sum e^2, rows, nonfinite, ...}
+constexpr int kGradHead = 32;      // floats reserved for them at the front of the packed gradient (one 128-B line)
 
 // runtime kernel-variant knobs (diagnostics / A-B benchmarking; fmhip_tune)
 enum { kTuneFwd = 0, kTuneBwd = 1, kTuneTile = 2, kTuneRowBlock = 3, kTuneXcd = 4, kTuneHot = 5, kTuneCount = 6 };

@@ -157,12 +157,16 @@ struct fmhip_model {
     int64_t prof_step = 0;
     std::vector<ProfRec> prof;
 
-    float *GV() const { return grad; }
-    float *Gw() const { return grad + (size_t)n1p * Kp; }
-    float *Gb() const { return grad + (size_t)n1p * Kp + n1p; }
-    float *scal() const { return grad + (size_t)n1p * Kp + 2 * (size_t)n1p; }
+    // packed gradient: [ scalars (kGradHead floats, 8 used) | G_w (n1p) | G_b (n1p) | pad | G_V (n1p*Kp) ]: the
+    // small head sits next to the G_V rows of the LOWEST feature ids, which the feature-chunked backward
+    // finishes last, so a data-parallel host moves head + last interval in one collective
+    size_t head_floats() const { return ((size_t)kGradHead + 2 * (size_t)n1p + 31) / 32 * 32; }
+    float *scal() const { return grad; }
+    float *Gw() const { return grad + kGradHead; }
+    float *Gb() const { return grad + kGradHead + n1p; }
+    float *GV() const { return grad + head_floats(); }
     int32_t pack_k() const { return k < Kp ? k : -1; }   // packed rows: slot k of a V row holds w_i
-    size_t grad_floats() const { return (size_t)n1p * Kp + 2 * (size_t)n1p + kScalars; }
+    size_t grad_floats() const { return head_floats() + (size_t)n1p * Kp; }
 };
 
 namespace {
@@ -1154,7 +1158,7 @@ int fmhip_batch_grad(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double *
     HIP_TRY(hipMemsetAsync(m->grad, 0, m->grad_floats() * sizeof(float), m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
     m->grad_dirty = false;
-    const float *GV = hG.data(), *Gw = GV + (size_t)m->n1p * m->Kp, *Gb = Gw + m->n1p, *sc = Gb + m->n1p;
+    const float *sc = hG.data(), *Gw = sc + kGradHead, *Gb = Gw + m->n1p, *GV = sc + m->head_floats();
     for (int64_t i = 0; i < m->n1; ++i) {
         if (gw) gw[i] = m->pack_k() >= 0 ? GV[(size_t)i * m->Kp + m->k] : Gw[i];
         if (gv)
@@ -1284,10 +1288,10 @@ int fmhip_step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, int64
     return FMHIP_OK;
 }
 
-int fmhip_grad_layout(fmhip_model_t m, int64_t *row_floats, int64_t *gv_floats) {
+int fmhip_grad_layout(fmhip_model_t m, int64_t *row_floats, int64_t *gv_offset) {
     if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
     if (row_floats) *row_floats = m->Kp;
-    if (gv_floats) *gv_floats = (int64_t)m->n1p * m->Kp;
+    if (gv_offset) *gv_offset = (int64_t)m->head_floats();
     return FMHIP_OK;
 }
 

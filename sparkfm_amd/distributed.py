@@ -33,7 +33,7 @@ class HipEngine:
         self.n_batches = dataset.n_batches
         rf, gv = C.c_int64(), C.c_int64()
         _ffi.check(self.L.fmhip_grad_layout(fm.handle, C.byref(rf), C.byref(gv)))
-        self.row_floats, self.gv_floats = int(rf.value), int(gv.value)
+        self.row_floats, self.gv_offset = int(rf.value), int(gv.value)
         self.n1 = fm.num_attribute + 1
 
     def forward(self, batch):
@@ -43,13 +43,14 @@ class HipEngine:
         """Gradient rows of features lo <= id < hi (intervals in descending order, finish on the last)."""
         _ffi.check(self.L.fmhip_step_backward(self.fm.handle, self.dataset.handle, batch, lo, hi, 1 if finish else 0))
 
-    def gv_slice(self, lo, hi):
-        """The part of the packed buffer that holds G_V of features lo <= id < hi."""
-        return self.grad[lo * self.row_floats:min(hi, self.n1) * self.row_floats]
-
-    def tail_slice(self):
-        """G_w | G_b | scalars."""
-        return self.grad[self.gv_floats:]
+    def gv_slice(self, lo, hi, with_head=False):
+        """The part of the packed buffer that holds G_V of features lo <= id < hi; with_head (lo must be
+        0): preceded by the head (scalars | G_w | G_b), which lies right in front of feature 0's row."""
+        end = self.gv_offset + min(hi, self.n1) * self.row_floats
+        if with_head:
+            assert lo == 0
+            return self.grad[:end]
+        return self.grad[self.gv_offset + lo * self.row_floats:end]
 
     def compute(self, batch):
         _ffi.check(self.L.fmhip_step_compute(self.fm.handle, self.dataset.handle, batch))
@@ -172,8 +173,9 @@ class DataParallelSGD(FMLearn):
             lo, hi = self.cuts[i - 1], self.cuts[i]
             if live:
                 eng.backward(j, lo, hi, finish=(i == 1))
-            works.append(dist.all_reduce(eng.gv_slice(lo, hi), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        works.append(dist.all_reduce(eng.tail_slice(), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            # the last interval (lowest ids) carries the head along: one collective fewer per step
+            works.append(dist.all_reduce(eng.gv_slice(lo, hi, with_head=(i == 1)), op=dist.ReduceOp.SUM, group=self.group,
+                                         async_op=True))
         for w in works:
             w.wait()
         eng.apply(self.eta, self.reg0, self.regw, self.regv)
