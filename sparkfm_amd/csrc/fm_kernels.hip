@@ -30,10 +30,14 @@ int padded_factors(int k) {
     return kp;
 }
 
+int forward_wt_occupancy(int Kp);   // workgroups of k_forward_wt one CU holds (defined next to the kernel)
+
 int forward_blocks_wt(int Kp, int64_t n_rows) {
-    // persistent: at most 5 workgroups of 256 threads per CU (24 KiB of LDS each), rows grid-strided
+    // persistent: as many workgroups as the chip holds at once (24 KiB of LDS each; the register count
+    // decides: 5 per CU at Kp = 32, fewer for wider rows), rows grid-strided
     const int64_t need = forward_blocks(Kp, n_rows);
-    return (int)(need < 256 * 5 ? need : 256 * 5);
+    const int64_t cap = (int64_t)256 * forward_wt_occupancy(Kp);
+    return (int)(need < cap ? need : cap);
 }
 
 int forward_blocks_lds(int64_t n_rows) {
@@ -1382,6 +1386,34 @@ hipError_t fix_dispatch(const BwdArgs &a, hipStream_t s) {
         case 256: return CALL(16, 4);                    \
         default: return hipErrorInvalidValue;            \
     }
+
+template <int LPN, int J>
+static int wt_occupancy() {
+    // the training-mode kernels decide (the scoring modes need no more registers); w-tile of 6144 floats
+    int n0 = 0, n1 = 0;
+    const size_t lds = 6144 * sizeof(float);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, (const void *)k_forward_wt<LPN, J, kFwdTrain, false>, kBlock, lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, (const void *)k_forward_wt<LPN, J, kFwdTrain, true>, kBlock, lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return 1;
+    }
+    const int n = n0 < n1 ? n0 : n1;
+    return n < 1 ? 1 : (n > 5 ? 5 : n);
+}
+
+int forward_wt_occupancy(int Kp) {
+    static int cache[4] = {0, 0, 0, 0};
+    const int idx = Kp == 32 ? 0 : Kp == 64 ? 1 : Kp == 128 ? 2 : 3;
+    if (!cache[idx]) {
+        switch (Kp) {
+            case 32: cache[idx] = wt_occupancy<8, 1>(); break;
+            case 64: cache[idx] = wt_occupancy<16, 1>(); break;
+            case 128: cache[idx] = wt_occupancy<16, 2>(); break;
+            default: cache[idx] = wt_occupancy<16, 4>(); break;
+        }
+    }
+    return cache[idx];
+}
 
 hipError_t launch_forward(int Kp, FwdMode mode, const FwdArgs &a, hipStream_t s) {
 #define CALL(L_, J_) fwd_dispatch<L_, J_>(mode, a, s)
