@@ -108,6 +108,11 @@ struct ApplyArgs {
     int64_t n1;         // n+1 (rows of V actually used)
     int32_t pack_k;     // >= 0: packed rows — slot pack_k of a V row is the linear weight
     float eta, reg0, regw, regv;
+    // rows-only variant (feat != NULL): just the listed distinct features and the hot block's ids
+    const int32_t *feat;     // [n_feat] distinct feature ids of the batch
+    int32_t n_feat;
+    const int32_t *hot_ids;  // [n_hot], -1 = unused
+    int32_t n_hot;
 };
 
 int hot_blocks(int Kp, int64_t n_rows);

@@ -737,8 +737,21 @@ int step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double *acc) {
     return step_backward(m, d, b, 0, INT64_MAX, true, acc);
 }
 
-int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double regv) {
+// `d`/`b` given: the gradient in the buffer is exactly batch b's (no exchange happened), so with no
+// weight decay the update may be restricted to the rows that batch touched
+int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double regv, fmhip_dataset_t d = nullptr,
+               int64_t b = -1) {
     ApplyArgs a{};
+    if (d && b >= 0 && regw == 0.0 && regv == 0.0 && d->rb_rows == 0) {
+        const BatchMeta &bm = d->batches[(size_t)b];
+        const int64_t touched = (int64_t)bm.n_cols + (d->hot_T ? kHotT : 0);
+        if (touched * 4 <= m->n1) {     // otherwise the dense, perfectly coalesced pass is as cheap
+            a.feat = d->cfeat.p + bm.col_off;
+            a.n_feat = bm.n_cols;
+            a.hot_ids = d->d_hot_ids.p;
+            a.n_hot = d->hot_T ? kHotT : 0;
+        }
+    }
     a.V = m->V.p;
     a.w = m->w.p;
     a.w0 = m->w0.p;
@@ -1123,7 +1136,7 @@ int fmhip_sgd_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double eta
         stats->nnz = d->batches[(size_t)batch].nnz_total;
         stats->steps = 1;
     }
-    return step_apply(m, eta, reg0, regw, regv);
+    return step_apply(m, eta, reg0, regw, regv, d, batch);
 }
 
 int fmhip_sgd_epoch(fmhip_model_t m, fmhip_dataset_t d, double eta, double reg0, double regw, double regv,
@@ -1136,7 +1149,7 @@ int fmhip_sgd_epoch(fmhip_model_t m, fmhip_dataset_t d, double eta, double reg0,
     for (int64_t j = 0; j < nb; ++j) {
         const int64_t b = order ? order[j] : j;
         TRY(step_compute(m, d, b, m->acc.p));
-        TRY(step_apply(m, eta, reg0, regw, regv));
+        TRY(step_apply(m, eta, reg0, regw, regv, d, b));
     }
     if (stats) {
         memset(stats, 0, sizeof *stats);

@@ -430,6 +430,39 @@ def test_sgd_epochs_track_the_oracle(fmhip, k, batch_rows):
     fm.close()
 
 
+@pytest.mark.parametrize("k", [16, 32, 64])
+def test_rows_only_apply_for_wide_models(fmhip, k):
+    """Without weight decay a step may update just the rows its batch touched (a model far wider than a
+    batch: the dense pass would rewrite every other row unchanged).  Same parameters, bit for bit, as
+    the dense update of the split-step path; both track the oracle."""
+    import torch
+    from sparkfm_amd.distributed import DataParallelSGD
+    a, _ = hot_problem(300 + k, 1500, 40000, k, 6)
+    ds, fm = make(fmhip, a, batch_rows=400)
+    fm2 = fmhip.FMModel(a["n1"] - 1, k)
+    fm2.w0, fm2.w, fm2.v = a["w0"], a["w"], a["v"]
+    eta = 0.05
+    sgd = fmhip.HipSGD(eta=eta, reg0=0.0, regw=0.0, regv=0.0)            # fused path: rows-only apply
+    dp = DataParallelSGD(eta=eta, reg0=0.0, regw=0.0, regv=0.0)           # split-step path: dense apply
+    w0, w, v = a["w0"], a["w"], a["v"]
+    for _ in range(3):
+        fm = sgd.learn(fm, ds)
+        dp.learn(fm2, ds)
+        w0, w, v, sse = oracle.sgd_epoch(w0, w, v, 400, a["row_ptr"], a["col"], a["val"], a["y"], eta, 0.0, 0.0, 0.0)
+        assert sgd.last_stats["sse"] == pytest.approx(sse, rel=1e-5)
+    torch.cuda.synchronize()
+    assert fm.w0 == fm2.w0
+    np.testing.assert_array_equal(fm.w, fm2.w)
+    np.testing.assert_array_equal(fm.v, fm2.v)
+    assert np.linalg.norm(fm.v - v) <= 1e-4 * np.linalg.norm(v)
+    assert np.linalg.norm(fm.w - w) <= 1e-4 * max(np.linalg.norm(w), 1e-12)
+    untouched = np.setdiff1d(np.arange(a["n1"]), a["col"])
+    np.testing.assert_array_equal(fm.v[:, untouched], a["v"][:, untouched].astype(np.float32))
+    ds.unpersist()
+    fm.close()
+    fm2.close()
+
+
 def test_batch_order_and_determinism(fmhip):
     a = random_problem(61, 1500, 300, 16, 1, 20)
     outs = []
