@@ -19,6 +19,9 @@
 //   q         S/fm/lib/ALS.scala:146-150 q_f = sum_i v_fi x_i
 //   gradient  S/fm/lib/ALS.scala:56-58   h(v_fi) = x*q_f - x^2*v_fi ; :40 h(w_i) = x ; :21 h(w0) = 1
 #include "fm_kernels.h"
+#ifndef FMHIP_DPP_BCAST
+#define FMHIP_DPP_BCAST 1
+#endif
 
 namespace fmhip {
 
@@ -157,6 +160,38 @@ __device__ __forceinline__ float quad_bcast(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), G * 0x55, 0xf, 0xf, false));   // quad_perm:[G,G,G,G]
 }
 
+constexpr bool g_dpp_bcast = FMHIP_DPP_BCAST;
+// Broadcast of lane `SRC` of every 8-lane slot to the slot's lanes with two DPP moves on the vector ALU
+// (quad broadcast, then a 4-lane row shift into the other quad of the slot) instead of a ds_bpermute
+// through the one LDS crossbar per CU — the pipe the per-entry broadcasts used to keep 35-56 % busy.
+template <int SRC>
+__device__ __forceinline__ int slot8_bcast_i(int v) {
+    const int t = __builtin_amdgcn_update_dpp(0, v, (SRC & 3) * 0x55, 0xf, 0xf, false);       // quad_perm:[s,s,s,s]
+    if (SRC < 4) return __builtin_amdgcn_update_dpp(t, t, 0x114, 0xf, 0xa, false);             // row_shr:4 into quads 1,3
+    return __builtin_amdgcn_update_dpp(t, t, 0x104, 0xf, 0x5, false);                           // row_shl:4 into quads 0,2
+}
+
+template <int LPN>
+__device__ __forceinline__ int slot_bcast(int v, int src) {
+    if (LPN == 8 && g_dpp_bcast) {
+        switch (src) {
+            case 0: return slot8_bcast_i<0>(v);
+            case 1: return slot8_bcast_i<1>(v);
+            case 2: return slot8_bcast_i<2>(v);
+            case 3: return slot8_bcast_i<3>(v);
+            case 4: return slot8_bcast_i<4>(v);
+            case 5: return slot8_bcast_i<5>(v);
+            case 6: return slot8_bcast_i<6>(v);
+            default: return slot8_bcast_i<7>(v);
+        }
+    }
+    return __shfl(v, src, LPN);
+}
+template <int LPN>
+__device__ __forceinline__ float slot_bcast(float v, int src) { return __int_as_float(slot_bcast<LPN>(__float_as_int(v), src)); }
+template <int LPN>
+__device__ __forceinline__ uint32_t slot_bcast(uint32_t v, int src) { return (uint32_t)slot_bcast<LPN>((int)v, src); }
+
 template <int LPN, int J, bool WITH_LIN, bool MASKED, int G>
 __device__ __forceinline__ void hot_group(const float4 xq, const float *vh, const float *wh, int l, float4 (&q)[J],
                                           float4 (&s)[J], float &lin) {
@@ -235,8 +270,8 @@ __global__ __launch_bounds__(kLdsBlock) void k_forward_lds(FwdArgs a) {
                 bool hot[CH];
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
-                    const int cj = __shfl(c, c0 + j, LPN);
-                    xs[j] = __shfl(x, c0 + j, LPN);
+                    const int cj = slot_bcast<LPN>(c, c0 + j);
+                    xs[j] = slot_bcast<LPN>(x, c0 + j);
                     hot[j] = (unsigned)cj < (unsigned)T;            // false for dead entries (cj = -1)
                     const uint32_t off = (uint32_t)cj * (KP * 4u) + (uint32_t)l * 16u;
                     const float4 *lp = reinterpret_cast<const float4 *>(vt + (size_t)(hot[j] ? cj : 0) * KP) + l;
@@ -352,8 +387,8 @@ __global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
                 float xs[CH];
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
-                    const int cj = __shfl(c, c0 + j, LPN);
-                    xs[j] = __shfl(x, c0 + j, LPN);
+                    const int cj = slot_bcast<LPN>(c, c0 + j);
+                    xs[j] = slot_bcast<LPN>(x, c0 + j);
                     const float4 *vr = reinterpret_cast<const float4 *>(a.V + (size_t)cj * KP) + l;
 #pragma unroll
                     for (int jj = 0; jj < J; ++jj) t[j][jj] = vr[jj * LPN];
@@ -487,8 +522,8 @@ __global__ __launch_bounds__(kBlock, (LPN * J <= 8 ? 5 : 1)) void k_forward_wt(F
                 float xs[CH];
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
-                    const int cj = __shfl(c, c0 + j, LPN);
-                    xs[j] = __shfl(x, c0 + j, LPN);
+                    const int cj = slot_bcast<LPN>(c, c0 + j);
+                    xs[j] = slot_bcast<LPN>(x, c0 + j);
                     const float4 *vr = reinterpret_cast<const float4 *>(a.V + (size_t)cj * KP) + l;
 #pragma unroll
                     for (int jj = 0; jj < J; ++jj) t[j][jj] = vr[jj * LPN];
@@ -830,15 +865,15 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
             uint32_t rj[CH];
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
-                rj[j] = __shfl(rf, c0 + j, LPN);
+                rj[j] = slot_bcast<LPN>(rf, c0 + j);
                 const float4 *pr = reinterpret_cast<const float4 *>(a.P + (size_t)(rj[j] & 0x7fffffffu) * KP) + l;
 #pragma unroll
                 for (int jj = 0; jj < J; ++jj) pv[j][jj] = pr[jj * LPN];
             }
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
-                const float xj = __shfl(x, c0 + j, LPN);
-                const float ej = packed ? 0.f : __shfl(ee, c0 + j, LPN);
+                const float xj = slot_bcast<LPN>(x, c0 + j);
+                const float ej = packed ? 0.f : slot_bcast<LPN>(ee, c0 + j);
                 if (c0 + j < cnt) {
                     if ((rj[j] >> 31) && (base + c0 + j != p0)) {
                         // the open column ends here: flush it
@@ -976,7 +1011,7 @@ __global__ __launch_bounds__(kBlock, (HOT && J == 1 ? 3 : 1)) void k_backward_p(
             for (int j = 0; j < CHB; ++j) {
                 const int ent = ch * CHB + j;             // entry index inside the super-group
                 const int g = ent / LPN, jl = ent % LPN;
-                rj[buf][j] = __shfl(rf[g], jl, LPN);
+                rj[buf][j] = slot_bcast<LPN>(rf[g], jl);
                 const bool live = sbase + ent < stop;
                 const uint32_t off = (rj[buf][j] & 0x7fffffffu) * (KP * 4u) + (uint32_t)l * 16u;
 #pragma unroll
@@ -1002,8 +1037,8 @@ __global__ __launch_bounds__(kBlock, (HOT && J == 1 ? 3 : 1)) void k_backward_p(
                 for (int j = 0; j < CHB; ++j) {
                     const int ent = ch * CHB + j;
                     const int g = ent / LPN, jl = ent % LPN;
-                    const float xj = __shfl(x[g], jl, LPN);
-                    const float ej = packed ? 0.f : __shfl(ee[g], jl, LPN);
+                    const float xj = slot_bcast<LPN>(x[g], jl);
+                    const float ej = packed ? 0.f : slot_bcast<LPN>(ee[g], jl);
 #pragma unroll
                     for (int jj = 0; jj < J; ++jj) f4fma(acc[jj], pv[buf][j][jj], xj);
                     if (packed) {
@@ -1022,8 +1057,8 @@ __global__ __launch_bounds__(kBlock, (HOT && J == 1 ? 3 : 1)) void k_backward_p(
             for (int j = 0; j < CHB; ++j) {
                 const int ent = ch * CHB + j;
                 const int g = ent / LPN, jl = ent % LPN;
-                const float xj = __shfl(x[g], jl, LPN);
-                const float ej = packed ? 0.f : __shfl(ee[g], jl, LPN);
+                const float xj = slot_bcast<LPN>(x[g], jl);
+                const float ej = packed ? 0.f : slot_bcast<LPN>(ee[g], jl);
                 if (sbase + ent < stop) {
                     if ((rj[buf][j] >> 31) && (sbase + ent != p0)) {
                         if (is_head) {
