@@ -1,17 +1,21 @@
 // fm_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the FM mini-batch SGD step.
 //
-// Work shapes (all HBM/L2-bound gather + stream; ~1 flop/B, so no MFMA):
-//   k_forward  CSR rows  : per stored nonzero gather one Kp-float row of V (128 B at Kp=32)
-//   k_backward CSC ranges: per stored nonzero gather one Kp-float row of P = e*q
-//   k_fixup    sums the partials of columns cut across ranges (fixed order -> deterministic)
-//   k_apply    dense SGD update fused with zeroing the packed gradient
+// Work shapes (HBM/L2-bound gather + stream at ~1 flop/B; the one GEMM-shaped piece, the gradient of
+// the dense hot block, is fp32 MFMA):
+//   k_forward  CSR rows  : per stored nonzero gather one Kp-float row of V (128 B at Kp=32); the
+//                          dense hot block's features come from LDS
+//   k_backward CSC ranges: per stored nonzero gather one Kp-float row of P = e*q; its first workgroups
+//                          form the hot block's gradient, xhot^T . P, instead
+//   k_fixup    sums the partials of columns cut across ranges and of the hot block (fixed order ->
+//              deterministic)
+//   k_apply    SGD update fused with zeroing the packed gradient (dense, or the touched rows only)
 //
 // Lane geometry: a "slot" = LPN consecutive lanes (8 at Kp = 32, 16 above) owning one CSR row
 // (forward) or one CSC range (backward); lane l of a slot holds factors 4*(l + jj*LPN) .. +3 for
 // jj < J, so one wave-instruction moves 64/LPN whole rows of Kp = 4*LPN*J floats (whole 128-B
 // lines: the texture addresser charges ~2 cycles per distinct line, whatever the bytes used), each
 // row a contiguous, 16-B-per-lane coalesced segment.  Index/value streams are read LPN entries at a time (one
-// per lane, contiguous) and broadcast inside the slot with ds_bpermute (__shfl width LPN).
+// per lane, contiguous) and broadcast inside the slot (two DPP moves for 8-lane slots, ds_bpermute above).
 //
 // Formulas restated from SparkFM (S/ = src/main/scala/io/edstud/spark/):
 //   forward   S/fm/FMModel.scala:34-63   yhat = w0 + sum w x + 0.5*sum_f[(sum v x)^2 - sum (v x)^2]
