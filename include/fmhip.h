@@ -93,7 +93,8 @@ int fmhip_device_count(int *count);
  *          none that occurs twice in a row or with a stored zero — leave the sparse streams for a dense
  *          [rows][16] fp32 array; their V rows are served from LDS in the forward and their gradient rows
  *          are a small dense product (MFMA) in the backward.  Invisible at this interface: batch_info,
- *          get_transpose, statistics and gradients report every stored nonzero. */
+ *          get_transpose, statistics and gradients report every stored nonzero.
+ *   key 6  cap on the forward's resident workgroups per CU (0 = all that fit, default): measurement knob */
 int fmhip_tune(int key, int value);
 
 /* ---- model: `new FMModel(num_attribute, num_factor)`  S/fm/FMModel.scala:9-22 -- */

@@ -12,7 +12,7 @@ constexpr int kScalars = 8;        // packed-gradient tail: {sum e, sum e^2, row
 constexpr int kGradHead = 32;      // floats reserved for them at the front of the packed gradient (one 128-B line)
 
 // runtime kernel-variant knobs (diagnostics / A-B benchmarking; fmhip_tune)
-enum { kTuneFwd = 0, kTuneBwd = 1, kTuneTile = 2, kTuneRowBlock = 3, kTuneXcd = 4, kTuneHot = 5, kTuneCount = 6 };
+enum { kTuneFwd = 0, kTuneBwd = 1, kTuneTile = 2, kTuneRowBlock = 3, kTuneXcd = 4, kTuneHot = 5, kTuneFwdOcc = 6, kTuneCount = 7 };
 constexpr int kHotT = 16;           // slots of the dense hot block (fp32 per row: one 64-B half line)
 extern int g_tune[kTuneCount];
 

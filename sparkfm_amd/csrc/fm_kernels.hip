@@ -29,7 +29,7 @@
 
 namespace fmhip {
 
-int g_tune[kTuneCount] = {60, 1, 0, 0, 0, 1};   // forward: w-tile kernel; backward: pipelined; tile rows: auto; row blocks, XCD placement: off; hot block: on
+int g_tune[kTuneCount] = {60, 1, 0, 0, 0, 1, 0};   // forward: w-tile kernel; backward: pipelined; tile rows: auto; row blocks, XCD placement: off; hot block: on
 
 int padded_factors(int k) {
     int kp = 32;   // a row is at least one 128-B line: the cost of a gather is per line, not per byte
@@ -43,7 +43,9 @@ int forward_blocks_wt(int Kp, int64_t n_rows) {
     // persistent: as many workgroups as the chip holds at once (24 KiB of LDS each; the register count
     // decides: 5 per CU at Kp = 32, fewer for wider rows), rows grid-strided
     const int64_t need = forward_blocks(Kp, n_rows);
-    const int64_t cap = (int64_t)256 * forward_wt_occupancy(Kp);
+    int occ = forward_wt_occupancy(Kp);
+    if (g_tune[kTuneFwdOcc] > 0 && g_tune[kTuneFwdOcc] < occ) occ = g_tune[kTuneFwdOcc];   // experiment knob: fewer resident workgroups
+    const int64_t cap = (int64_t)256 * occ;
     return (int)(need < cap ? need : cap);
 }
 
