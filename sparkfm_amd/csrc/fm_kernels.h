@@ -12,7 +12,7 @@ constexpr int kScalars = 8;        // packed-gradient tail: {sum e, sum e^2, row
 constexpr int kGradHead = 32;      // floats reserved for them at the front of the packed gradient (one 128-B line)
 
 // runtime kernel-variant knobs (diagnostics / A-B benchmarking; fmhip_tune)
-enum { kTuneFwd = 0, kTuneBwd = 1, kTuneTile = 2, kTuneRowBlock = 3, kTuneXcd = 4, kTuneHot = 5, kTuneFwdOcc = 6, kTuneCount = 7 };
+enum { kTuneFwd = 0, kTuneBwd = 1, kTuneTile = 2, kTuneRowBlock = 3, kTuneXcd = 4, kTuneHot = 5, kTuneFwdOcc = 6, kTuneRowOrder = 7, kTuneCount = 8 };
 constexpr int kHotT = 16;           // slots of the dense hot block (fp32 per row: one 64-B half line)
 extern int g_tune[kTuneCount];
 
@@ -37,6 +37,7 @@ struct FwdArgs {
     const float *w;   // [n+1]
     const float *w0;  // [1]
     int64_t row0;
+    const int32_t *order;  // [n_rows] batch-local row ids, longest row first (NULL = 0, 1, 2, ..)
     int32_t n_rows;
     float *P;     // train: [rows][Kp] = e*q ; q-mode: [rows][Kp] = q
     float *e;     // [rows] e = yhat - y   (residual / train)

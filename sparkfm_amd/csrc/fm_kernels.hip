@@ -29,7 +29,7 @@
 
 namespace fmhip {
 
-int g_tune[kTuneCount] = {60, 1, 0, 0, 0, 1, 0};   // forward: w-tile kernel; backward: pipelined; tile rows: auto; row blocks, XCD placement: off; hot block: on
+int g_tune[kTuneCount] = {60, 1, 0, 0, 0, 1, 0, 1};   // forward: w-tile kernel; backward: pipelined; tile rows: auto; row blocks, XCD placement: off; hot block: on
 
 int padded_factors(int k) {
     int kp = 32;   // a row is at least one 128-B line: the cost of a gather is per line, not per byte
@@ -231,6 +231,40 @@ __device__ __forceinline__ void hot_prologue(const float4 xq, const float *vh, c
     hot_group<LPN, J, WITH_LIN, MASKED, 3>(xq, vh, wh, l, q, s, lin);
 }
 
+// One step of a row walk: the slot's LPN entries (c, x: one per lane) are broadcast, their V rows
+// gathered CH at a time and accumulated in stored order (q_f: FMModel.scala:59, sum_sqr_f: :60).
+// MASKED = the row's last, partial step (entries >= cnt are dead); full steps carry no per-entry
+// compare/select — the vector ALU, not the memory path, is what the forward saturates
+// (profiles/r01_experiments.md, section 23).
+template <int LPN, int J, int CH, bool MASKED>
+__device__ __forceinline__ void fwd_step(const float *V, int c, float x, int cnt, int l, float4 (&q)[J], float4 (&s)[J]) {
+    constexpr int KP = 4 * LPN * J;
+#pragma unroll
+    for (int c0 = 0; c0 < LPN; c0 += CH) {
+        float4 t[CH][J];
+        float xs[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int cj = slot_bcast<LPN>(c, c0 + j);
+            xs[j] = slot_bcast<LPN>(x, c0 + j);
+            const float4 *vr = reinterpret_cast<const float4 *>(V + (size_t)(uint32_t)cj * KP) + l;
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) t[j][jj] = vr[jj * LPN];
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const bool live = c0 + j < cnt;
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) {
+                float4 tv = f4mul(t[j][jj], xs[j]);
+                if (MASKED && !live) tv = f4zero();
+                f4add(q[jj], tv);
+                f4sqacc(s[jj], tv);
+            }
+        }
+    }
+}
+
 template <int LPN, int J, int MODE>
 __global__ __launch_bounds__(kLdsBlock) void k_forward_lds(FwdArgs a) {
     constexpr int KP = 4 * LPN * J;
@@ -253,7 +287,11 @@ __global__ __launch_bounds__(kLdsBlock) void k_forward_lds(FwdArgs a) {
     const float w0 = *a.w0;
     const __amdgpu_buffer_rsrc_t vr = make_rsrc(a.V, a.v_bytes);
     float st1 = 0.f, st2 = 0.f, stbad = 0.f;
-    for (int r = blockIdx.x * SLOTS + slot; r < a.n_rows; r += gridDim.x * SLOTS) {
+    // rows are taken in the dataset's length-sorted order (longest first): the slots of a wave walk rows of
+    // (nearly) equal length, so no lane idles while a neighbour finishes a longer row, and every slot's
+    // share — one row per length stratum — weighs the same
+    for (int ri = blockIdx.x * SLOTS + slot; ri < a.n_rows; ri += gridDim.x * SLOTS) {
+        const int r = a.order ? a.order[ri] : ri;
         const int64_t p0 = a.row_ptr[a.row0 + r], p1 = a.row_ptr[a.row0 + r + 1];
         float4 q[J], s[J];
 #pragma unroll
@@ -365,7 +403,11 @@ __global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
     bool hot_plain = false;
     if (HOT) hot_plain = hot_stage<KP>(a, vh, wh);
     float st1 = 0.f, st2 = 0.f, stbad = 0.f;   // this thread's share of {sum e, sum e^2, nonfinite}
-    for (int r = blockIdx.x * SLOTS + slot; r < a.n_rows; r += gridDim.x * SLOTS) {
+    // rows are taken in the dataset's length-sorted order (longest first): the slots of a wave walk rows of
+    // (nearly) equal length, so no lane idles while a neighbour finishes a longer row, and every slot's
+    // share — one row per length stratum — weighs the same
+    for (int ri = blockIdx.x * SLOTS + slot; ri < a.n_rows; ri += gridDim.x * SLOTS) {
+        const int r = a.order ? a.order[ri] : ri;
         float4 xh = f4zero();
         if (HOT) xh = hot_load(a, r, l);
         const int64_t p0 = a.row_ptr[a.row0 + r], p1 = a.row_ptr[a.row0 + r + 1];
@@ -377,40 +419,26 @@ __global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
             if (hot_plain) hot_prologue<LPN, J, !PACKED, false>(xh, vh, wh, l, q, s, lin);
             else hot_prologue<LPN, J, !PACKED, true>(xh, vh, wh, l, q, s, lin);
         }
-        for (int64_t base = p0; base < p1; base += LPN) {
+        int64_t base = p0;
+        for (; base + LPN <= p1; base += LPN) {        // full steps
+            const int c = stream_load(a.col + base + l);
+            const float x = stream_load(a.val + base + l);
+            float wv = 0.f;
+            if (!packed) wv = a.w[c];
+            fwd_step<LPN, J, CH, false>(a.V, c, x, LPN, l, q, s);
+            if (!packed) lin = fmaf(wv, x, lin);
+        }
+        if (base < p1) {                               // the row's last, partial step
             const int64_t p = base + l;
             int c = 0;
-            float x = 0.f;
+            float x = 0.f, wv = 0.f;
             if (p < p1) {
                 c = stream_load(a.col + p);
                 x = stream_load(a.val + p);
-                if (!packed) lin = fmaf(a.w[c], x, lin);
+                if (!packed) wv = a.w[c];
             }
-            const int cnt = (int)((p1 - base) < (int64_t)LPN ? (p1 - base) : (int64_t)LPN);
-#pragma unroll
-            for (int c0 = 0; c0 < LPN; c0 += CH) {
-                float4 t[CH][J];
-                float xs[CH];
-#pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                    const int cj = slot_bcast<LPN>(c, c0 + j);
-                    xs[j] = slot_bcast<LPN>(x, c0 + j);
-                    const float4 *vr = reinterpret_cast<const float4 *>(a.V + (size_t)cj * KP) + l;
-#pragma unroll
-                    for (int jj = 0; jj < J; ++jj) t[j][jj] = vr[jj * LPN];
-                }
-#pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                    const bool live = c0 + j < cnt;
-#pragma unroll
-                    for (int jj = 0; jj < J; ++jj) {
-                        float4 tv = f4mul(t[j][jj], xs[j]);
-                        if (!live) tv = f4zero();
-                        f4add(q[jj], tv);       // q_f accumulates in stored order (FMModel.scala:59)
-                        f4sqacc(s[jj], tv);     // sum_sqr_f (FMModel.scala:60)
-                    }
-                }
-            }
+            fwd_step<LPN, J, CH, true>(a.V, c, x, (int)(p1 - base), l, q, s);
+            if (!packed) lin = fmaf(wv, x, lin);
         }
         float lin_all = 0.f;   // packed: the complete linear term, identical in every lane of the slot
         if (packed) {
@@ -499,7 +527,11 @@ __global__ __launch_bounds__(kBlock, (LPN * J <= 8 ? 5 : 1)) void k_forward_wt(F
     if (HOT) hot_plain = hot_stage<KP>(a, vh, wh);
     else __syncthreads();
     float st1 = 0.f, st2 = 0.f, stbad = 0.f;   // this thread's share of {sum e, sum e^2, nonfinite}
-    for (int r = blockIdx.x * SLOTS + slot; r < a.n_rows; r += gridDim.x * SLOTS) {
+    // rows are taken in the dataset's length-sorted order (longest first): the slots of a wave walk rows of
+    // (nearly) equal length, so no lane idles while a neighbour finishes a longer row, and every slot's
+    // share — one row per length stratum — weighs the same
+    for (int ri = blockIdx.x * SLOTS + slot; ri < a.n_rows; ri += gridDim.x * SLOTS) {
+        const int r = a.order ? a.order[ri] : ri;
         float4 xh = f4zero();
         if (HOT) xh = hot_load(a, r, l);
         const int64_t p0 = a.row_ptr[a.row0 + r], p1 = a.row_ptr[a.row0 + r + 1];
@@ -511,41 +543,25 @@ __global__ __launch_bounds__(kBlock, (LPN * J <= 8 ? 5 : 1)) void k_forward_wt(F
             if (hot_plain) hot_prologue<LPN, J, true, false>(xh, vh, wh, l, q, s, lin);
             else hot_prologue<LPN, J, true, true>(xh, vh, wh, l, q, s, lin);
         }
-        for (int64_t base = p0; base < p1; base += LPN) {
+        int64_t base = p0;
+        for (; base + LPN <= p1; base += LPN) {        // full steps
+            const int c = stream_load(a.col + base + l);
+            const float x = stream_load(a.val + base + l);
+            const float wv = c < T ? wt[c] : a.w[c];
+            fwd_step<LPN, J, CH, false>(a.V, c, x, LPN, l, q, s);
+            lin = fmaf(wv, x, lin);                    // consumed after the gathers are on their way
+        }
+        if (base < p1) {                               // the row's last, partial step
             const int64_t p = base + l;
             int c = 0;
-            float x = 0.f;
+            float x = 0.f, wv = 0.f;
             if (p < p1) {
                 c = stream_load(a.col + p);
                 x = stream_load(a.val + p);
-                const float wv = c < T ? wt[c] : a.w[c];
-                lin = fmaf(wv, x, lin);
+                wv = c < T ? wt[c] : a.w[c];
             }
-            const int cnt = (int)((p1 - base) < (int64_t)LPN ? (p1 - base) : (int64_t)LPN);
-#pragma unroll
-            for (int c0 = 0; c0 < LPN; c0 += CH) {
-                float4 t[CH][J];
-                float xs[CH];
-#pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                    const int cj = slot_bcast<LPN>(c, c0 + j);
-                    xs[j] = slot_bcast<LPN>(x, c0 + j);
-                    const float4 *vr = reinterpret_cast<const float4 *>(a.V + (size_t)cj * KP) + l;
-#pragma unroll
-                    for (int jj = 0; jj < J; ++jj) t[j][jj] = vr[jj * LPN];
-                }
-#pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                    const bool live = c0 + j < cnt;
-#pragma unroll
-                    for (int jj = 0; jj < J; ++jj) {
-                        float4 tv = f4mul(t[j][jj], xs[j]);
-                        if (!live) tv = f4zero();
-                        f4add(q[jj], tv);       // q_f accumulates in stored order (FMModel.scala:59)
-                        f4sqacc(s[jj], tv);     // sum_sqr_f (FMModel.scala:60)
-                    }
-                }
-            }
+            fwd_step<LPN, J, CH, true>(a.V, c, x, (int)(p1 - base), l, q, s);
+            lin = fmaf(wv, x, lin);
         }
         float u = 0.f;
 #pragma unroll

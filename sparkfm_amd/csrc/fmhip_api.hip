@@ -114,6 +114,7 @@ struct fmhip_dataset {
     DevBuf<float> val, y;
     DevBuf<uint32_t> crow;
     DevBuf<float> cval;
+    DevBuf<int32_t> row_order;   // per batch: its rows' local ids sorted by stored length, longest first (forward walk order)
     DevBuf<int32_t> cfeat, cptr, range_seg, split_seg, split_short, cdst, mp_feat, mp_ptr;
     std::vector<int32_t> h_cfeat, h_cptr, h_split, h_split_short;   // host copies (feature-chunked backward needs them)
     int64_t rb_rows = 0;       // rows per row block of the transposes (0 = not row-blocked)
@@ -382,6 +383,27 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
         bm.nnz = (int32_t)bn;
         d->max_rows = std::max(d->max_rows, bm.rows);
     }
+    // forward walk order of each batch: rows by (sparse) length, longest first, ties in row order
+    {
+        std::vector<int32_t> order((size_t)n_rows);
+        std::vector<int64_t> start;
+        for (const BatchMeta &bm : d->batches) {
+            int64_t maxlen = 0;
+            for (int64_t r = 0; r < bm.rows; ++r) maxlen = std::max(maxlen, row_ptr[bm.row0 + r + 1] - row_ptr[bm.row0 + r]);
+            start.assign((size_t)maxlen + 2, 0);
+            for (int64_t r = 0; r < bm.rows; ++r) ++start[(size_t)(maxlen - (row_ptr[bm.row0 + r + 1] - row_ptr[bm.row0 + r])) + 1];
+            for (size_t i = 1; i < start.size(); ++i) start[i] += start[i - 1];
+            for (int64_t r = 0; r < bm.rows; ++r) {
+                const size_t key = (size_t)(maxlen - (row_ptr[bm.row0 + r + 1] - row_ptr[bm.row0 + r]));
+                order[(size_t)(bm.row0 + start[key]++)] = (int32_t)r;
+            }
+        }
+        const int rc0 = upload(d->row_order, order.data(), order.size());
+        if (rc0) {
+            delete d;
+            return rc0;
+        }
+    }
     // fp32 copies of the streams (device arithmetic is fp32)
     std::vector<float> valf((size_t)nnz_s), yf((size_t)n_rows);
     for (int64_t p = 0; p < nnz_s; ++p) valf[(size_t)p] = split ? sp_val[(size_t)p] : (float)val[p];
@@ -565,6 +587,7 @@ FwdArgs fwd_args(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm) {
     a.w = m->w.p;
     a.w0 = m->w0.p;
     a.row0 = bm.row0;
+    a.order = g_tune[kTuneRowOrder] ? d->row_order.p + bm.row0 : nullptr;
     a.n_rows = (int32_t)bm.rows;
     a.P = m->P.p;
     a.e = m->e.p;

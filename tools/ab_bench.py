@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--row-block", type=int, default=0, help="rows per row block of the transposes (fmhip_tune key 3)")
     ap.add_argument("--xcd", type=int, default=0, help="XCD-aware workgroup placement in the backward (fmhip_tune key 4)")
     ap.add_argument("--fwd-occ", type=int, default=0, help="cap on the forward's resident workgroups per CU (fmhip_tune key 6; 0 = all that fit)")
+    ap.add_argument("--row-order", type=int, default=1, help="forward walks rows longest-first (fmhip_tune key 7)")
     ap.add_argument("--hot", type=int, default=0, help="dense hot block for the most frequent features (fmhip_tune key 5)")
     ap.add_argument("--tile", type=int, default=0, help="LDS V-tile rows for forward variant 20 (0 = auto: 128 KiB)")
     args = ap.parse_args()
@@ -42,6 +43,7 @@ def main():
         _ffi.load().fmhip_tune(3, args.row_block)
     _ffi.load().fmhip_tune(5, args.hot)
     _ffi.load().fmhip_tune(6, args.fwd_occ)
+    _ffi.load().fmhip_tune(7, args.row_order)
     ds = DataSet.from_arrays(d, batch_rows=min(args.batch_rows, rows)).cache()
     fm = FMModel(n1 - 1, k)
     fm.w0, fm.w, fm.v = w0, w, v

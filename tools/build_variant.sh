@@ -1,19 +1,20 @@
 #!/bin/bash
 # Builds the library from another git revision into sparkfm_amd/lib/libfmhip_<name>.so (A/B runs on one
 # GPU box: FMHIP_LIB=sparkfm_amd/lib/libfmhip_<name>.so python tools/ab_bench.py ...).
-#   tools/build_variant.sh <name> [git-rev, default HEAD]
+#   tools/build_variant.sh <name> [git-rev, default HEAD; WORK = the working tree]
+#   EXTRA_FLAGS="-DFOO=1" adds compiler flags (experiment macros)
 set -e
 name=$1; rev=${2:-HEAD}
 root=$(cd "$(dirname "$0")/.." && pwd)
 tmp=$(mktemp -d /tmp/fmhip_variant.XXXXXX)
 mkdir -p $tmp/sparkfm_amd/csrc $tmp/include
 for f in fm_kernels.hip fm_kernels.h als_kernels.hip als_kernels.h csc_build.hip csc_build.h fmhip_api.hip; do
-  git -C $root show $rev:sparkfm_amd/csrc/$f > $tmp/sparkfm_amd/csrc/$f
+  if [ "$rev" = WORK ]; then cp $root/sparkfm_amd/csrc/$f $tmp/sparkfm_amd/csrc/$f; else git -C $root show $rev:sparkfm_amd/csrc/$f > $tmp/sparkfm_amd/csrc/$f; fi
 done
-git -C $root show $rev:include/fmhip.h > $tmp/include/fmhip.h
+if [ "$rev" = WORK ]; then cp $root/include/fmhip.h $tmp/include/fmhip.h; else git -C $root show $rev:include/fmhip.h > $tmp/include/fmhip.h; fi
 objs=""
 for f in fm_kernels als_kernels csc_build fmhip_api; do
-  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -c $tmp/sparkfm_amd/csrc/$f.hip -o $tmp/$f.o &
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC $EXTRA_FLAGS -c $tmp/sparkfm_amd/csrc/$f.hip -o $tmp/$f.o &
   objs="$objs $tmp/$f.o"
 done
 wait
