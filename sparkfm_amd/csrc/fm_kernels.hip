@@ -55,7 +55,7 @@ int forward_blocks_lds(int64_t n_rows) {
 }
 
 int forward_blocks(int Kp, int64_t n_rows) {
-    const int lpn = Kp / 4 > 16 ? 16 : Kp / 4;
+    const int lpn = Kp <= 64 ? 8 : 16;      // the forward's slot width (launch_forward)
     const int slots = 256 / lpn;
     int64_t blocks = (n_rows + slots - 1) / slots;
     if (blocks > kMaxFwdBlocks) blocks = kMaxFwdBlocks;
@@ -1490,7 +1490,7 @@ int forward_wt_occupancy(int Kp) {
     if (!cache[idx]) {
         switch (Kp) {
             case 32: cache[idx] = wt_occupancy<8, 1>(); break;
-            case 64: cache[idx] = wt_occupancy<16, 1>(); break;
+            case 64: cache[idx] = wt_occupancy<8, 2>(); break;
             case 128: cache[idx] = wt_occupancy<16, 2>(); break;
             default: cache[idx] = wt_occupancy<16, 4>(); break;
         }
@@ -1498,10 +1498,17 @@ int forward_wt_occupancy(int Kp) {
     return cache[idx];
 }
 
+// The forward walks Kp = 64 rows with 8-lane slots holding two float4 per lane (DPP broadcasts, eight rows
+// per wave: 189 -> 177 us); the backward keeps 16-lane slots there (its pipelined kernel needs J = 1).
+// Row layouts in memory do not depend on the lane geometry, so the two may differ.
 hipError_t launch_forward(int Kp, FwdMode mode, const FwdArgs &a, hipStream_t s) {
-#define CALL(L_, J_) fwd_dispatch<L_, J_>(mode, a, s)
-    FMHIP_KP_SWITCH(Kp, CALL)
-#undef CALL
+    switch (Kp) {
+        case 32: return fwd_dispatch<8, 1>(mode, a, s);
+        case 64: return fwd_dispatch<8, 2>(mode, a, s);
+        case 128: return fwd_dispatch<16, 2>(mode, a, s);
+        case 256: return fwd_dispatch<16, 4>(mode, a, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_backward(int Kp, const BwdArgs &a, hipStream_t s) {
