@@ -661,6 +661,94 @@ def test_config_c1_fit_with_als(fmhip):
     assert abs(fm.computeMeanError(ds)) < fm.computeMAE(ds)
 
 
+def test_full_size_c3_properties(fmhip):
+    """BASELINE config 3 at its full size (1M rows x 100k features, k=32, 40M nonzeros; the bench
+    workload) — far beyond what the oracle walks in seconds, so parity is pinned by (1) the oracle on a
+    random SAMPLE of rows scored against the full model, (2) size-independent identities of the batch
+    gradient, (3) bit-identical repeats and chunked == whole backward, (4) the dense-hot-block and plain
+    layouts agreeing with each other."""
+    import ctypes as C
+    import torch
+    from sparkfm_amd import _ffi, synth
+    from sparkfm_amd.distributed import HipEngine
+    L = _ffi.load()
+    d = synth.make_config("C3")
+    n_rows, n1, k, br = len(d["row_ptr"]) - 1, synth.CONFIGS["C3"]["features"], 32, 250000
+    rng = np.random.default_rng(3)
+    w0, w, v = 0.05, rng.normal(0, 0.05, n1), rng.normal(0, 0.05, (k, n1))
+    row_ptr, col = d["row_ptr"], d["col"]
+    val, y = d["val"].astype(np.float64), d["y"].astype(np.float64)
+
+    def build(hot):
+        try:
+            L.fmhip_tune(5, hot)
+            ds = fmhip.DataSet.from_arrays(d, batch_rows=br).cache()
+        finally:
+            L.fmhip_tune(5, 1)
+        fm = fmhip.FMModel(n1 - 1, k)
+        fm.w0, fm.w, fm.v = w0, w, v
+        return ds, fm
+
+    ds, fm = build(1)
+    # (1) the oracle on 3000 sampled rows, full model
+    rows = np.sort(rng.choice(n_rows, 3000, replace=False))
+    lens = (row_ptr[rows + 1] - row_ptr[rows]).astype(np.int64)
+    sub_ptr = np.concatenate([[0], np.cumsum(lens)])
+    idx = np.concatenate([np.arange(row_ptr[r], row_ptr[r + 1]) for r in rows])
+    oy = oracle.predict(w0, w, v, sub_ptr, col[idx], val[idx])
+    yh = fm.predict(ds)
+    scale = term_scale(dict(y=oy, row_ptr=sub_ptr, col=col[idx], val=val[idx], w0=w0, w=w, v=v))
+    assert (np.abs(yh[rows] - oy) <= TOL_Y * scale).all()
+    # (2) identities of batch 0's gradient, from quantities computed independently of the backward
+    gv, gw, g0, st = fm.batchGradient(ds, 0)
+    e = (yh[:br] - y[:br])                                             # fp32 predictions, fp64 arithmetic from here on
+    p0, p1 = row_ptr[0], row_ptr[br]
+    assert st["nnz"] == p1 - p0 and st["rows"] == br
+    xs = val[p0:p1]
+    row_of = np.repeat(np.arange(br), np.diff(row_ptr[:br + 1]))
+    assert g0 == pytest.approx(e.sum(), rel=1e-4, abs=1e-3)            # h(w0) = 1
+    assert st["sse"] == pytest.approx((e * e).sum(), rel=1e-4)
+    ex = e[row_of] * xs
+    want_gw = np.bincount(col[p0:p1], weights=ex, minlength=n1)        # G_w[i] = sum_r e_r x_ri, an independent scatter
+    np.testing.assert_allclose(gw, want_gw, rtol=2e-4, atol=2e-4 * np.abs(want_gw).max())
+    lin = np.bincount(row_of, weights=w[col[p0:p1]] * xs, minlength=br)
+    inter = yh[:br] - w0 - lin                                         # 0.5 * sum_f (q_f^2 - s_f)
+    # Euler: the interaction is homogeneous of degree 2 in V, so sum_i <v_i, dL/dv_i> = sum_r e_r * 2 * inter_r
+    assert float((gv * v).sum()) == pytest.approx(float((e * 2.0 * inter).sum()), rel=2e-3, abs=1e-2)
+    # (3) determinism and chunked == whole, bit for bit
+    gv2, gw2, _, _ = fm.batchGradient(ds, 0)
+    np.testing.assert_array_equal(gv, gv2)
+    np.testing.assert_array_equal(gw, gw2)
+    eng = HipEngine(fm, ds)
+    eng.compute(1)
+    torch.cuda.synchronize()
+    want = eng.grad.clone()
+    eng.grad.zero_()
+    torch.cuda.synchronize()
+    _ffi.check(L.fmhip_grad_bind(fm.handle, C.c_void_p(eng.grad.data_ptr())))
+    eng.forward(1)
+    cuts = [0, 700, 20000, n1]
+    for i in range(len(cuts) - 1, 0, -1):
+        eng.backward(1, cuts[i - 1], cuts[i], finish=(i == 1))
+    torch.cuda.synchronize()
+    assert torch.equal(eng.grad, want)
+    eng.close()
+    # (4) the layout without the dense hot block computes the same gradient (different summation order only)
+    ds_p, fm_p = build(0)
+    gv_p, gw_p, g0_p, st_p = fm_p.batchGradient(ds_p, 0)
+    check_grad(gv, gw, gv_p, gw_p, np.abs(v).max())
+    assert st_p["sse"] == pytest.approx(st["sse"], rel=1e-6)
+    # and training moves the loss the same way on both
+    for m_, d_ in ((fm, ds), (fm_p, ds_p)):
+        fmhip.HipSGD(eta=0.02, regw=1e-4, regv=1e-4).learn(m_, d_)
+    r_hot, r_plain = fm.computeRMSE(ds), fm_p.computeRMSE(ds_p)
+    assert r_hot == pytest.approx(r_plain, rel=1e-5) and r_hot < math.sqrt(st["sse"] / br)
+    for o in (ds, ds_p):
+        o.unpersist()
+    fm.close()
+    fm_p.close()
+
+
 def test_fit_loop_like_the_reference(fmhip):
     """FM(dataset, numFactor, maxIteration).learnWith(learner) — S/fm/impl/FactorizationMachines.scala:30-51."""
     from sparkfm_amd import synth
