@@ -661,9 +661,10 @@ def test_config_c1_fit_with_als(fmhip):
     assert abs(fm.computeMeanError(ds)) < fm.computeMAE(ds)
 
 
-def test_full_size_c3_properties(fmhip):
-    """BASELINE config 3 at its full size (1M rows x 100k features, k=32, 40M nonzeros; the bench
-    workload) — far beyond what the oracle walks in seconds, so parity is pinned by (1) the oracle on a
+@pytest.mark.parametrize("config", ["C3", "C2"])
+def test_full_size_properties(fmhip, config):
+    """BASELINE configs 3 (k=32, the bench workload) and 2 (k=16: packed rows) at their full size (1M
+    rows x 100k features, 40M nonzeros) — far beyond what the oracle walks in seconds, so parity is pinned by (1) the oracle on a
     random SAMPLE of rows scored against the full model, (2) size-independent identities of the batch
     gradient, (3) bit-identical repeats and chunked == whole backward, (4) the dense-hot-block and plain
     layouts agreeing with each other."""
@@ -672,8 +673,8 @@ def test_full_size_c3_properties(fmhip):
     from sparkfm_amd import _ffi, synth
     from sparkfm_amd.distributed import HipEngine
     L = _ffi.load()
-    d = synth.make_config("C3")
-    n_rows, n1, k, br = len(d["row_ptr"]) - 1, synth.CONFIGS["C3"]["features"], 32, 250000
+    d = synth.make_config(config)
+    n_rows, n1, k, br = len(d["row_ptr"]) - 1, synth.CONFIGS[config]["features"], synth.CONFIGS[config]["k"], 250000
     rng = np.random.default_rng(3)
     w0, w, v = 0.05, rng.normal(0, 0.05, n1), rng.normal(0, 0.05, (k, n1))
     row_ptr, col = d["row_ptr"], d["col"]
