@@ -95,8 +95,9 @@ int fmhip_device_count(int *count);
  *          are a small dense product (MFMA) in the backward.  Invisible at this interface: batch_info,
  *          get_transpose, statistics and gradients report every stored nonzero.
  *   key 6  cap on the forward's resident workgroups per CU (0 = all that fit, default): measurement knob
- *   key 7  forward walks each batch's rows longest-first (1 = default; 0 = stored order): the slots of a
- *          wave then walk rows of equal length (k=64: 205 -> 190 us; no effect at k <= 32) */
+ *   key 7  models with k > 32: the forward walks each batch's rows longest-first (1 = default; 0 = stored
+ *          order), so the slots of a wave walk rows of equal length (k=64: 205 -> 190 us); narrower models
+ *          gain nothing from it and always walk in stored order */
 int fmhip_tune(int key, int value);
 
 /* ---- model: `new FMModel(num_attribute, num_factor)`  S/fm/FMModel.scala:9-22 -- */
