@@ -12,8 +12,8 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfmhip.so")
 SYNTH = os.path.join(LIBDIR, "libfmsynth.so")
 
-HIP_SOURCES = ["fm_kernels.hip", "als_kernels.hip", "csc_build.hip", "fmhip_api.hip"]
-HIP_DEPS = ["fm_kernels.h", "als_kernels.h", "csc_build.h", os.path.join("..", "..", "include", "fmhip.h")]
+HIP_SOURCES = ["fm_forward.hip", "fm_backward.hip", "fm_apply.hip", "als_kernels.hip", "csc_build.hip", "fmhip_api.hip"]
+HIP_DEPS = ["fm_kernels.h", "fm_device.h", "als_kernels.h", "csc_build.h", os.path.join("..", "..", "include", "fmhip.h")]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 
 
@@ -32,7 +32,7 @@ def build_lib(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     deps = [os.path.join(CSRC, f) for f in HIP_SOURCES + HIP_DEPS]
     objs, jobs = [], []
-    for src in HIP_SOURCES:     # the translation units compile side by side (fm_kernels.hip alone takes ~45 s)
+    for src in HIP_SOURCES:     # the translation units compile side by side (the two big kernel files take ~25 s each)
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, deps):

@@ -1,0 +1,155 @@
+// fm_device.h — device-side helpers shared by fm_forward.hip / fm_backward.hip / fm_apply.hip: the hand-written gfx950 (CDNA4, wave64) kernels of the FM mini-batch SGD step.
+//
+// Work shapes (HBM/L2-bound gather + stream at ~1 flop/B; the one GEMM-shaped piece, the gradient of
+// the dense hot block, is fp32 MFMA):
+//   k_forward  CSR rows  : per stored nonzero gather one Kp-float row of V (128 B at Kp=32); the
+//                          dense hot block's features come from LDS
+//   k_backward CSC ranges: per stored nonzero gather one Kp-float row of P = e*q; its first workgroups
+//                          form the hot block's gradient, xhot^T . P, instead
+//   k_fixup    sums the partials of columns cut across ranges and of the hot block (fixed order ->
+//              deterministic)
+//   k_apply    SGD update fused with zeroing the packed gradient (dense, or the touched rows only)
+//
+// Lane geometry: a "slot" = LPN consecutive lanes (8 at Kp = 32, 16 above) owning one CSR row
+// (forward) or one CSC range (backward); lane l of a slot holds factors 4*(l + jj*LPN) .. +3 for
+// jj < J, so one wave-instruction moves 64/LPN whole rows of Kp = 4*LPN*J floats (whole 128-B
+// lines: the texture addresser charges ~2 cycles per distinct line, whatever the bytes used), each
+// row a contiguous, 16-B-per-lane coalesced segment.  Index/value streams are read LPN entries at a time (one
+// per lane, contiguous) and broadcast inside the slot (two DPP moves for 8-lane slots, ds_bpermute above).
+//
+// Formulas restated from SparkFM (S/ = src/main/scala/io/edstud/spark/):
+//   forward   S/fm/FMModel.scala:34-63   yhat = w0 + sum w x + 0.5*sum_f[(sum v x)^2 - sum (v x)^2]
+//   residual  S/fm/lib/ALS.scala:142-144 e = yhat - y
+//   q         S/fm/lib/ALS.scala:146-150 q_f = sum_i v_fi x_i
+//   gradient  S/fm/lib/ALS.scala:56-58   h(v_fi) = x*q_f - x^2*v_fi ; :40 h(w_i) = x ; :21 h(w0) = 1
+#pragma once
+#include "fm_kernels.h"
+#ifndef FMHIP_DPP_BCAST
+#define FMHIP_DPP_BCAST 1
+#endif
+
+namespace fmhip {
+namespace {
+
+constexpr int kBlock = 256;
+
+// The CSR / CSC index and value streams are read exactly once per step: load them non-temporally
+// so they do not evict the gathered tables (V, P) from L2.
+template <typename T>
+__device__ __forceinline__ T stream_load(const T *p) {
+#ifdef FMHIP_STREAM_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4mul(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ void f4fma(float4 &acc, float4 a, float s) {
+    acc.x = fmaf(a.x, s, acc.x); acc.y = fmaf(a.y, s, acc.y); acc.z = fmaf(a.z, s, acc.z); acc.w = fmaf(a.w, s, acc.w);
+}
+__device__ __forceinline__ void f4add(float4 &acc, float4 a) { acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+__device__ __forceinline__ void f4sqacc(float4 &acc, float4 a) {
+    acc.x = fmaf(a.x, a.x, acc.x); acc.y = fmaf(a.y, a.y, acc.y); acc.z = fmaf(a.z, a.z, acc.z); acc.w = fmaf(a.w, a.w, acc.w);
+}
+// component c (0..3) of a float4 without dynamic register indexing
+__device__ __forceinline__ float f4pick(float4 v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+__device__ __forceinline__ void f4set(float4 &v, int c, float x) {
+    if (c == 0) v.x = x; else if (c == 1) v.y = x; else if (c == 2) v.z = x; else v.w = x;
+}
+
+// (q*q - s) with the product rounded BEFORE the subtraction (no fma contraction): for a
+// single-nonzero row q = v*x and s = round((v*x)^2), so this is exactly 0 (quirk Q6).
+// (HIP's __fmul_rn/__fsub_rn are plain operators that hipcc would still contract into one fma,
+// hence the explicit contract(off).)
+__device__ __forceinline__ float sq_minus(float q, float s) {
+#pragma clang fp contract(off)
+    const float qq = q * q;
+    return qq - s;
+}
+__device__ __forceinline__ float f4sqminus(float4 q, float4 s) {
+    return (sq_minus(q.x, s.x) + sq_minus(q.y, s.y)) + (sq_minus(q.z, s.z) + sq_minus(q.w, s.w));
+}
+
+// Raw buffer view of a row table (V or P): a load whose byte offset is >= `bytes` returns 0 and
+// fetches nothing, so padding entries of a lane group cost no memory traffic and need no mask.
+typedef float f4v __attribute__((ext_vector_type(4)));
+constexpr uint32_t kOob = 0xffffffffu;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    f4v v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+template <int G>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), G * 0x55, 0xf, 0xf, false));   // quad_perm:[G,G,G,G]
+}
+
+constexpr bool g_dpp_bcast = FMHIP_DPP_BCAST;
+// Broadcast of lane `SRC` of every 8-lane slot to the slot's lanes with two DPP moves on the vector ALU
+// (quad broadcast, then a 4-lane row shift into the other quad of the slot) instead of a ds_bpermute
+// through the one LDS crossbar per CU — the pipe the per-entry broadcasts used to keep 35-56 % busy.
+template <int SRC>
+__device__ __forceinline__ int slot8_bcast_i(int v) {
+    const int t = __builtin_amdgcn_update_dpp(0, v, (SRC & 3) * 0x55, 0xf, 0xf, false);       // quad_perm:[s,s,s,s]
+    if (SRC < 4) return __builtin_amdgcn_update_dpp(t, t, 0x114, 0xf, 0xa, false);             // row_shr:4 into quads 1,3
+    return __builtin_amdgcn_update_dpp(t, t, 0x104, 0xf, 0x5, false);                           // row_shl:4 into quads 0,2
+}
+
+template <int LPN>
+__device__ __forceinline__ int slot_bcast(int v, int src) {
+    if (LPN == 8 && g_dpp_bcast) {
+        switch (src) {
+            case 0: return slot8_bcast_i<0>(v);
+            case 1: return slot8_bcast_i<1>(v);
+            case 2: return slot8_bcast_i<2>(v);
+            case 3: return slot8_bcast_i<3>(v);
+            case 4: return slot8_bcast_i<4>(v);
+            case 5: return slot8_bcast_i<5>(v);
+            case 6: return slot8_bcast_i<6>(v);
+            default: return slot8_bcast_i<7>(v);
+        }
+    }
+    return __shfl(v, src, LPN);
+}
+template <int LPN>
+__device__ __forceinline__ float slot_bcast(float v, int src) { return __int_as_float(slot_bcast<LPN>(__float_as_int(v), src)); }
+template <int LPN>
+__device__ __forceinline__ uint32_t slot_bcast(uint32_t v, int src) { return (uint32_t)slot_bcast<LPN>((int)v, src); }
+
+// ------------------------------------------------------------------ reduce
+// one block, fixed order: sums the forward's per-block partials into
+// scal = {sum e, sum e^2, rows, nonfinite} (fp32, part of the packed gradient) and acc (fp64, +=)
+__device__ __forceinline__ void reduce_blocks_body(const double *bsum, int32_t nblocks, int32_t n_rows, float *scal,
+                                                   double *acc, double (*sh)[kBlock / 64]) {
+    double s1 = 0.0, s2 = 0.0, bad = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += kBlock) {
+        const double4 b = reinterpret_cast<const double4 *>(bsum)[i];
+        s1 += b.x;
+        s2 += b.y;
+        bad += b.z;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        s1 += __shfl_xor(s1, m, 64);
+        s2 += __shfl_xor(s2, m, 64);
+        bad += __shfl_xor(bad, m, 64);
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][wv] = s1; sh[1][wv] = s2; sh[2][wv] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t1 = 0.0, t2 = 0.0, tb = 0.0;
+        for (int i = 0; i < kBlock / 64; ++i) { t1 += sh[0][i]; t2 += sh[1][i]; tb += sh[2][i]; }
+        if (scal) { scal[0] = (float)t1; scal[1] = (float)t2; scal[2] = (float)n_rows; scal[3] = (float)tb; }
+        if (acc) { acc[0] += t1; acc[1] += t2; acc[2] += (double)n_rows; acc[3] += tb; }
+    }
+}
+
+
+}  // namespace
+}  // namespace fmhip

@@ -1,0 +1,615 @@
+// fm_forward.hip — the forward of the FM step: row walks over the CSR stream (k_forward, k_forward_wt,
+// k_forward_lds), the dense hot block's prologue, the per-block statistics reduction, and the launch
+// geometry that goes with them.  Lane geometry and formulas: fm_device.h.
+#include "fm_device.h"
+
+namespace fmhip {
+
+int g_tune[kTuneCount] = {60, 1, 0, 0, 0, 1, 0, 1};   // forward: w-tile kernel; backward: pipelined; tile rows: auto; row blocks, XCD placement: off; hot block: on
+
+int padded_factors(int k) {
+    int kp = 32;   // a row is at least one 128-B line: the cost of a gather is per line, not per byte
+    while (kp < k) kp <<= 1;
+    return kp;
+}
+
+int forward_wt_occupancy(int Kp);   // workgroups of k_forward_wt one CU holds (defined next to the kernel)
+
+int forward_blocks_wt(int Kp, int64_t n_rows) {
+    // persistent: as many workgroups as the chip holds at once (24 KiB of LDS each; the register count
+    // decides: 5 per CU at Kp = 32, fewer for wider rows), rows grid-strided
+    const int64_t need = forward_blocks(Kp, n_rows);
+    int occ = forward_wt_occupancy(Kp);
+    if (g_tune[kTuneFwdOcc] > 0 && g_tune[kTuneFwdOcc] < occ) occ = g_tune[kTuneFwdOcc];   // experiment knob: fewer resident workgroups
+    const int64_t cap = (int64_t)256 * occ;
+    return (int)(need < cap ? need : cap);
+}
+
+int forward_blocks_lds(int64_t n_rows) {
+    (void)n_rows;
+    return 256;   // one 1024-thread workgroup per CU, rows grid-strided
+}
+
+int forward_blocks(int Kp, int64_t n_rows) {
+    const int lpn = Kp <= 64 ? 8 : 16;      // the forward's slot width (launch_forward)
+    const int slots = 256 / lpn;
+    int64_t blocks = (n_rows + slots - 1) / slots;
+    if (blocks > kMaxFwdBlocks) blocks = kMaxFwdBlocks;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+namespace {
+
+// ------------------------------------------------------------------ forward
+// LDS V-tile variant: a 1024-thread workgroup (one per CU) first stages the rows of the T hottest
+// features — ids < T, i.e. frequency-ranked ids — of V (and of w) into LDS, then walks its rows
+// like k_forward_p.  A nonzero whose feature id is < T reads its factor row with ds_read_b128 and
+// issues NO global request (its buffer offset is out of range); only the colder ids go to L2.
+// With power-law ids the tile absorbs most gathers (58 % at T = 1024 on the C3 workload).
+constexpr int kLdsBlock = 1024;
+
+// ------------------------------------------------------------------ dense hot block (forward side)
+// The kHotT most frequent features of a dataset are not in its sparse streams: their values sit in
+// xhot[row][slot] (0 = absent) and their V rows / linear weights are staged in LDS once per
+// workgroup, so a hot nonzero costs an LDS read instead of a 128-B gather through the texture
+// addresser (profiles/r01_experiments.md §12/§15).  Contributions enter q, s and the linear term
+// exactly as a stored nonzero's would (FMModel.scala:41-46,57-63); an absent feature adds nothing.
+template <int KP>
+__device__ __forceinline__ bool hot_stage(const FwdArgs &a, float *vh, float *wh) {
+    int bad = 0;
+    for (int i = threadIdx.x; i < kHotT * (KP / 4); i += blockDim.x) {
+        const int h = i / (KP / 4), c = i % (KP / 4);
+        const int id = a.hot_ids[h];
+        const float4 t = id >= 0 ? reinterpret_cast<const float4 *>(a.V + (size_t)id * KP)[c] : f4zero();
+        reinterpret_cast<float4 *>(vh)[i] = t;
+        bad |= !(isfinite(t.x) && isfinite(t.y) && isfinite(t.z) && isfinite(t.w));
+    }
+    if (threadIdx.x < kHotT) {
+        const int id = a.hot_ids[threadIdx.x];
+        const float t = id >= 0 ? a.w[id] : 0.f;
+        wh[threadIdx.x] = t;
+        bad |= !isfinite(t);
+    }
+    // (also the barrier that publishes the tile) all staged parameters finite: 0 * v is exactly 0 and
+    // an absent slot needs no masking; otherwise the masked prologue keeps absent features out
+    return __syncthreads_or(bad) == 0;
+}
+
+// The row's kHotT values, issued together with the row's offsets so their latency is paid once.  Lane
+// l of the slot loads the float4 of hot slots 4*(l&3)..+3 — 16 B per lane: the texture path returns
+// 64 B/clk/CU whatever the coalescing, so every lane loading all 64 B would cost four times as much —
+// and the prologue broadcasts each value inside the quad with a DPP move (no LDS crossbar).
+__device__ __forceinline__ float4 hot_load(const FwdArgs &a, int r, int l) {
+    return reinterpret_cast<const float4 *>(a.xhot + (size_t)r * kHotT)[l & 3];
+}
+
+template <int LPN, int J, bool WITH_LIN, bool MASKED, int G>
+__device__ __forceinline__ void hot_group(const float4 xq, const float *vh, const float *wh, int l, float4 (&q)[J],
+                                          float4 (&s)[J], float &lin) {
+    constexpr int KP = 4 * LPN * J;
+    const float xs[4] = {quad_bcast<G>(xq.x), quad_bcast<G>(xq.y), quad_bcast<G>(xq.z), quad_bcast<G>(xq.w)};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int h = G * 4 + c;
+        const float x = xs[c];
+        const bool live = x != 0.f;
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) {
+            float4 tv = f4mul(reinterpret_cast<const float4 *>(vh + h * KP)[jj * LPN + l], x);
+            if (MASKED && !live) tv = f4zero();
+            f4add(q[jj], tv);
+            f4sqacc(s[jj], tv);
+        }
+        if (WITH_LIN && (h & (LPN - 1)) == l && (!MASKED || live)) lin = fmaf(wh[h], x, lin);
+    }
+    // four slots' LDS reads in flight at a time: the prologue must not raise the kernel's register count
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int LPN, int J, bool WITH_LIN, bool MASKED>
+__device__ __forceinline__ void hot_prologue(const float4 xq, const float *vh, const float *wh, int l,
+                                             float4 (&q)[J], float4 (&s)[J], float &lin) {
+    static_assert(kHotT == 16, "one float4 per quad lane");
+    hot_group<LPN, J, WITH_LIN, MASKED, 0>(xq, vh, wh, l, q, s, lin);
+    hot_group<LPN, J, WITH_LIN, MASKED, 1>(xq, vh, wh, l, q, s, lin);
+    hot_group<LPN, J, WITH_LIN, MASKED, 2>(xq, vh, wh, l, q, s, lin);
+    hot_group<LPN, J, WITH_LIN, MASKED, 3>(xq, vh, wh, l, q, s, lin);
+}
+
+// One step of a row walk: the slot's LPN entries (c, x: one per lane) are broadcast, their V rows
+// gathered CH at a time and accumulated in stored order (q_f: FMModel.scala:59, sum_sqr_f: :60).
+// MASKED = the row's last, partial step (entries >= cnt are dead); full steps carry no per-entry
+// compare/select — the vector ALU, not the memory path, is what the forward saturates
+// (profiles/r01_experiments.md, section 23).
+template <int LPN, int J, int CH, bool MASKED>
+__device__ __forceinline__ void fwd_step(const float *V, int c, float x, int cnt, int l, float4 (&q)[J], float4 (&s)[J]) {
+    constexpr int KP = 4 * LPN * J;
+#pragma unroll
+    for (int c0 = 0; c0 < LPN; c0 += CH) {
+        float4 t[CH][J];
+        float xs[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int cj = slot_bcast<LPN>(c, c0 + j);
+            xs[j] = slot_bcast<LPN>(x, c0 + j);
+            const float4 *vr = reinterpret_cast<const float4 *>(V + (size_t)(uint32_t)cj * KP) + l;
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) t[j][jj] = vr[jj * LPN];
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const bool live = c0 + j < cnt;
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) {
+                float4 tv = f4mul(t[j][jj], xs[j]);
+                if (MASKED && !live) tv = f4zero();
+                f4add(q[jj], tv);
+                f4sqacc(s[jj], tv);
+            }
+        }
+    }
+}
+
+template <int LPN, int J, int MODE>
+__global__ __launch_bounds__(kLdsBlock) void k_forward_lds(FwdArgs a) {
+    constexpr int KP = 4 * LPN * J;
+    constexpr int SLOTS = kLdsBlock / LPN;
+    constexpr int CH = (LPN * J > 8) ? ((8 / J) > 0 ? (8 / J) : 1) : LPN;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int T = a.tile_rows;
+    float *vt = lds;                    // [T][KP]
+    float *wt = lds + (size_t)T * KP;   // [T]
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.V);
+        float4 *dst = reinterpret_cast<float4 *>(vt);
+        const int n4 = T * (KP / 4);
+        for (int i = threadIdx.x; i < n4; i += kLdsBlock) dst[i] = src[i];
+        for (int i = threadIdx.x; i < T; i += kLdsBlock) wt[i] = a.w[i];
+    }
+    __syncthreads();
+    const int l = threadIdx.x & (LPN - 1);
+    const int slot = threadIdx.x / LPN;
+    const float w0 = *a.w0;
+    const __amdgpu_buffer_rsrc_t vr = make_rsrc(a.V, a.v_bytes);
+    float st1 = 0.f, st2 = 0.f, stbad = 0.f;
+    // rows are taken in the dataset's length-sorted order (longest first): the slots of a wave walk rows of
+    // (nearly) equal length, so no lane idles while a neighbour finishes a longer row, and every slot's
+    // share — one row per length stratum — weighs the same
+    for (int ri = blockIdx.x * SLOTS + slot; ri < a.n_rows; ri += gridDim.x * SLOTS) {
+        const int r = a.order ? a.order[ri] : ri;
+        const int64_t p0 = a.row_ptr[a.row0 + r], p1 = a.row_ptr[a.row0 + r + 1];
+        float4 q[J], s[J];
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) { q[jj] = f4zero(); s[jj] = f4zero(); }
+        float lin = 0.f;
+        for (int64_t base = p0; base < p1; base += LPN) {
+            const int64_t p = base + l;
+            int c = -1;
+            float x = 0.f;
+            if (p < p1) {
+                c = stream_load(a.col + p);
+                x = stream_load(a.val + p);
+                const float wv = c < T ? wt[c] : a.w[c];
+                lin = fmaf(wv, x, lin);
+            }
+#pragma unroll
+            for (int c0 = 0; c0 < LPN; c0 += CH) {
+                float4 tg[CH][J], tl[CH][J];
+                float xs[CH];
+                bool hot[CH];
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int cj = slot_bcast<LPN>(c, c0 + j);
+                    xs[j] = slot_bcast<LPN>(x, c0 + j);
+                    hot[j] = (unsigned)cj < (unsigned)T;            // false for dead entries (cj = -1)
+                    const uint32_t off = (uint32_t)cj * (KP * 4u) + (uint32_t)l * 16u;
+                    const float4 *lp = reinterpret_cast<const float4 *>(vt + (size_t)(hot[j] ? cj : 0) * KP) + l;
+#pragma unroll
+                    for (int jj = 0; jj < J; ++jj) {
+                        tg[j][jj] = buf_load4(vr, (hot[j] || cj < 0) ? kOob : off + jj * LPN * 16u);
+                        tl[j][jj] = lp[jj * LPN];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+#pragma unroll
+                    for (int jj = 0; jj < J; ++jj) {
+                        const float4 t = hot[j] ? tl[j][jj] : tg[j][jj];
+                        const float4 tv = f4mul(t, xs[j]);          // dead entries: 0 * 0
+                        f4add(q[jj], tv);
+                        f4sqacc(s[jj], tv);
+                    }
+                }
+            }
+        }
+        float u = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) u += f4sqminus(q[jj], s[jj]);
+        float tot = fmaf(0.5f, u, lin);
+#pragma unroll
+        for (int m = LPN >> 1; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, LPN);
+        const float yhat = w0 + tot;
+        const float e = yhat - a.y[a.row0 + r];
+        if (MODE == kFwdTrain) {
+            float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) pr[jj * LPN] = f4mul(q[jj], e);
+        } else if (MODE == kFwdQ) {
+            float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) pr[jj * LPN] = q[jj];
+        }
+        if (l == 0) {
+            if (a.e) a.e[r] = e;
+            if (a.yhat) a.yhat[r] = yhat;
+            st1 += e;
+            st2 = fmaf(e, e, st2);
+            if (!isfinite(e)) stbad += 1.f;
+        }
+    }
+    if (a.bsum) {
+        __shared__ double sh[3][kLdsBlock / 64];
+        double d1 = st1, d2 = st2, db = stbad;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            d1 += __shfl_xor(d1, m, 64);
+            d2 += __shfl_xor(d2, m, 64);
+            db += __shfl_xor(db, m, 64);
+        }
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { sh[0][wv] = d1; sh[1][wv] = d2; sh[2][wv] = db; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t1 = 0.0, t2 = 0.0, tb = 0.0;
+#pragma unroll
+            for (int i = 0; i < kLdsBlock / 64; ++i) { t1 += sh[0][i]; t2 += sh[1][i]; tb += sh[2][i]; }
+            double *o = a.bsum + (size_t)blockIdx.x * 4;
+            o[0] = t1; o[1] = t2; o[2] = tb; o[3] = 0.0;
+        }
+    }
+}
+
+template <int LPN, int J, int MODE, bool PACKED, bool HOT>
+__global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
+    constexpr int KP = 4 * LPN * J;
+    constexpr int SLOTS = kBlock / LPN;
+    constexpr int CH = (LPN * J > 16) ? (16 / J) : LPN;  // entries whose V rows are in flight together
+    const int l = threadIdx.x & (LPN - 1);
+    const int slot = threadIdx.x / LPN;
+    const float w0 = *a.w0;
+    // Packed rows (k < Kp): slot k of every V row holds the feature's linear weight w_i, so q_k
+    // accumulates sum w_i x_i — the linear term — for free and there is no separate w gather (a
+    // 64-lane scalar gather costs the texture addresser as much as the whole row gather); slot k of
+    // the P row carries e to the backward the same way.
+    constexpr bool packed = PACKED;
+    const int kl = packed ? (a.pack_k >> 2) & (LPN - 1) : 0, kj = packed ? (a.pack_k >> 2) / LPN : 0, kc = a.pack_k & 3;
+    __shared__ __attribute__((aligned(16))) float vh[HOT ? kHotT * KP : 4];
+    __shared__ float wh[HOT ? kHotT : 1];
+    bool hot_plain = false;
+    if (HOT) hot_plain = hot_stage<KP>(a, vh, wh);
+    float st1 = 0.f, st2 = 0.f, stbad = 0.f;   // this thread's share of {sum e, sum e^2, nonfinite}
+    // rows are taken in the dataset's length-sorted order (longest first): the slots of a wave walk rows of
+    // (nearly) equal length, so no lane idles while a neighbour finishes a longer row, and every slot's
+    // share — one row per length stratum — weighs the same
+    for (int ri = blockIdx.x * SLOTS + slot; ri < a.n_rows; ri += gridDim.x * SLOTS) {
+        const int r = a.order ? a.order[ri] : ri;
+        float4 xh = f4zero();
+        if (HOT) xh = hot_load(a, r, l);
+        const int64_t p0 = a.row_ptr[a.row0 + r], p1 = a.row_ptr[a.row0 + r + 1];
+        float4 q[J], s[J];
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) { q[jj] = f4zero(); s[jj] = f4zero(); }
+        float lin = 0.f;
+        if (HOT) {
+            if (hot_plain) hot_prologue<LPN, J, !PACKED, false>(xh, vh, wh, l, q, s, lin);
+            else hot_prologue<LPN, J, !PACKED, true>(xh, vh, wh, l, q, s, lin);
+        }
+        int64_t base = p0;
+        for (; base + LPN <= p1; base += LPN) {        // full steps
+            const int c = stream_load(a.col + base + l);
+            const float x = stream_load(a.val + base + l);
+            float wv = 0.f;
+            if (!packed) wv = a.w[c];
+            fwd_step<LPN, J, CH, false>(a.V, c, x, LPN, l, q, s);
+            if (!packed) lin = fmaf(wv, x, lin);
+        }
+        if (base < p1) {                               // the row's last, partial step
+            const int64_t p = base + l;
+            int c = 0;
+            float x = 0.f, wv = 0.f;
+            if (p < p1) {
+                c = stream_load(a.col + p);
+                x = stream_load(a.val + p);
+                if (!packed) wv = a.w[c];
+            }
+            fwd_step<LPN, J, CH, true>(a.V, c, x, (int)(p1 - base), l, q, s);
+            if (!packed) lin = fmaf(wv, x, lin);
+        }
+        float lin_all = 0.f;   // packed: the complete linear term, identical in every lane of the slot
+        if (packed) {
+            float lk = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj)
+                if (jj == kj) {
+                    lk = f4pick(q[jj], kc);
+                    if (l == kl) { f4set(q[jj], kc, 0.f); f4set(s[jj], kc, 0.f); }   // slot k is not a factor
+                }
+            lin_all = __shfl(lk, kl, LPN);
+        }
+        float u = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) u += f4sqminus(q[jj], s[jj]);
+        float tot = fmaf(0.5f, u, lin);
+#pragma unroll
+        for (int m = LPN >> 1; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, LPN);
+        const float yhat = w0 + (tot + lin_all);
+        const float e = yhat - a.y[a.row0 + r];
+        if (MODE == kFwdTrain) {
+            float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) {
+                float4 o = f4mul(q[jj], e);
+                if (packed && jj == kj && l == kl) f4set(o, kc, e);   // slot k of the P row carries e
+                pr[jj * LPN] = o;
+            }
+        } else if (MODE == kFwdQ) {
+            float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) pr[jj * LPN] = q[jj];
+        }
+        if (l == 0) {
+            if (a.e) a.e[r] = e;
+            if (a.yhat) a.yhat[r] = yhat;
+            st1 += e;
+            st2 = fmaf(e, e, st2);
+            if (!isfinite(e)) stbad += 1.f;
+        }
+    }
+    // block partial of the residual statistics (fixed order; k_reduce_blocks finishes the sum)
+    if (a.bsum) {
+        __shared__ double sh[3][kBlock / 64];
+        double d1 = st1, d2 = st2, db = stbad;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            d1 += __shfl_xor(d1, m, 64);
+            d2 += __shfl_xor(d2, m, 64);
+            db += __shfl_xor(db, m, 64);
+        }
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { sh[0][wv] = d1; sh[1][wv] = d2; sh[2][wv] = db; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t1 = 0.0, t2 = 0.0, tb = 0.0;
+#pragma unroll
+            for (int i = 0; i < kBlock / 64; ++i) { t1 += sh[0][i]; t2 += sh[1][i]; tb += sh[2][i]; }
+            double *o = a.bsum + (size_t)blockIdx.x * 4;
+            o[0] = t1; o[1] = t2; o[2] = tb; o[3] = 0.0;
+        }
+    }
+}
+
+// k_forward with an LDS-resident tile of the hot linear weights (see the comment in the body)
+// (second launch bound = waves per SIMD: the persistent grid of forward_blocks_wt is sized for 5, and a
+// register count that admits only 4 would run it in two rounds)
+template <int LPN, int J, int MODE, bool HOT>
+__global__ __launch_bounds__(kBlock, (LPN * J <= 8 ? 5 : 1)) void k_forward_wt(FwdArgs a) {
+    constexpr int KP = 4 * LPN * J;
+    constexpr int SLOTS = kBlock / LPN;
+    constexpr int CH = (LPN * J > 16) ? (16 / J) : LPN;  // entries whose V rows are in flight together
+    const int l = threadIdx.x & (LPN - 1);
+    const int slot = threadIdx.x / LPN;
+    const float w0 = *a.w0;
+    // w-tile: the linear weights of the wt_rows lowest (= hottest, for frequency-ranked ids) feature
+    // ids live in LDS.  A 64-lane gather of w costs ~2 TA cycles per distinct line touched — as much
+    // per nonzero as the whole 128-B V-row gather (profiles/r01_experiments.md §13); lanes whose id is
+    // in the tile read LDS instead and drop out of the global gather.
+    extern __shared__ __attribute__((aligned(16))) float wt[];
+    const int T = a.wt_rows;
+    __shared__ __attribute__((aligned(16))) float vh[HOT ? kHotT * KP : 4];
+    __shared__ float wh[HOT ? kHotT : 1];
+    for (int i = threadIdx.x; i < T; i += kBlock) wt[i] = a.w[i];
+    bool hot_plain = false;
+    if (HOT) hot_plain = hot_stage<KP>(a, vh, wh);
+    else __syncthreads();
+    float st1 = 0.f, st2 = 0.f, stbad = 0.f;   // this thread's share of {sum e, sum e^2, nonfinite}
+    // rows are taken in the dataset's length-sorted order (longest first): the slots of a wave walk rows of
+    // (nearly) equal length, so no lane idles while a neighbour finishes a longer row, and every slot's
+    // share — one row per length stratum — weighs the same
+    for (int ri = blockIdx.x * SLOTS + slot; ri < a.n_rows; ri += gridDim.x * SLOTS) {
+        const int r = a.order ? a.order[ri] : ri;
+        float4 xh = f4zero();
+        if (HOT) xh = hot_load(a, r, l);
+        const int64_t p0 = a.row_ptr[a.row0 + r], p1 = a.row_ptr[a.row0 + r + 1];
+        float4 q[J], s[J];
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) { q[jj] = f4zero(); s[jj] = f4zero(); }
+        float lin = 0.f;
+        if (HOT) {
+            if (hot_plain) hot_prologue<LPN, J, true, false>(xh, vh, wh, l, q, s, lin);
+            else hot_prologue<LPN, J, true, true>(xh, vh, wh, l, q, s, lin);
+        }
+        int64_t base = p0;
+        for (; base + LPN <= p1; base += LPN) {        // full steps
+            const int c = stream_load(a.col + base + l);
+            const float x = stream_load(a.val + base + l);
+            const float wv = c < T ? wt[c] : a.w[c];
+            fwd_step<LPN, J, CH, false>(a.V, c, x, LPN, l, q, s);
+            lin = fmaf(wv, x, lin);                    // consumed after the gathers are on their way
+        }
+        if (base < p1) {                               // the row's last, partial step
+            const int64_t p = base + l;
+            int c = 0;
+            float x = 0.f, wv = 0.f;
+            if (p < p1) {
+                c = stream_load(a.col + p);
+                x = stream_load(a.val + p);
+                wv = c < T ? wt[c] : a.w[c];
+            }
+            fwd_step<LPN, J, CH, true>(a.V, c, x, (int)(p1 - base), l, q, s);
+            lin = fmaf(wv, x, lin);
+        }
+        float u = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) u += f4sqminus(q[jj], s[jj]);
+        float tot = fmaf(0.5f, u, lin);
+#pragma unroll
+        for (int m = LPN >> 1; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, LPN);
+        const float yhat = w0 + tot;
+        const float e = yhat - a.y[a.row0 + r];
+        if (MODE == kFwdTrain) {
+            float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) pr[jj * LPN] = f4mul(q[jj], e);
+        } else if (MODE == kFwdQ) {
+            float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) pr[jj * LPN] = q[jj];
+        }
+        if (l == 0) {
+            if (a.e) a.e[r] = e;
+            if (a.yhat) a.yhat[r] = yhat;
+            st1 += e;
+            st2 = fmaf(e, e, st2);
+            if (!isfinite(e)) stbad += 1.f;
+        }
+    }
+    // block partial of the residual statistics (fixed order; k_reduce_blocks finishes the sum)
+    if (a.bsum) {
+        __shared__ double sh[3][kBlock / 64];
+        double d1 = st1, d2 = st2, db = stbad;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            d1 += __shfl_xor(d1, m, 64);
+            d2 += __shfl_xor(d2, m, 64);
+            db += __shfl_xor(db, m, 64);
+        }
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { sh[0][wv] = d1; sh[1][wv] = d2; sh[2][wv] = db; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t1 = 0.0, t2 = 0.0, tb = 0.0;
+#pragma unroll
+            for (int i = 0; i < kBlock / 64; ++i) { t1 += sh[0][i]; t2 += sh[1][i]; tb += sh[2][i]; }
+            double *o = a.bsum + (size_t)blockIdx.x * 4;
+            o[0] = t1; o[1] = t2; o[2] = tb; o[3] = 0.0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_reduce_blocks(const double *bsum, int32_t nblocks, int32_t n_rows, float *scal,
+                                                         double *acc) {
+    __shared__ double sh[3][kBlock / 64];
+    reduce_blocks_body(bsum, nblocks, n_rows, scal, acc, sh);
+}
+
+template <int LPN, int J>
+hipError_t fwd_dispatch(FwdMode mode, const FwdArgs &a, hipStream_t s) {
+    int64_t blocks = forward_blocks(4 * LPN * J, a.n_rows);
+    dim3 g((unsigned)blocks), b(kBlock);
+    int var = g_tune[kTuneFwd];
+    if (a.pack_k >= 0) var = 0;              // packed rows carry w in the row: only the plain kernel handles them
+    if (var == 20 && (!a.v_bytes || a.hot_T)) var = a.hot_T ? 60 : 0;   // the LDS V-tile kernel needs V to fit a 32-bit buffer view; it has no hot-block prologue
+    if (var == 60 && a.wt_rows > 0) {
+        const size_t lds_bytes = (size_t)a.wt_rows * sizeof(float);
+        int64_t nb = forward_blocks_wt(4 * LPN * J, a.n_rows);
+        dim3 gw((unsigned)nb);
+#define FMHIP_WT(MODE_)                                                                                  \
+    if (a.hot_T) hipLaunchKernelGGL((k_forward_wt<LPN, J, MODE_, true>), gw, b, lds_bytes, s, a);         \
+    else hipLaunchKernelGGL((k_forward_wt<LPN, J, MODE_, false>), gw, b, lds_bytes, s, a)
+        switch (mode) {
+            case kFwdTrain: FMHIP_WT(kFwdTrain); break;
+            case kFwdResidual: FMHIP_WT(kFwdResidual); break;
+            case kFwdQ: FMHIP_WT(kFwdQ); break;
+        }
+#undef FMHIP_WT
+        return hipGetLastError();
+    }
+    if (var == 20 && a.tile_rows > 0) {
+        const size_t lds_bytes = (size_t)a.tile_rows * (4 * LPN * J + 1) * sizeof(float);
+        dim3 gl((unsigned)forward_blocks_lds(a.n_rows)), bl(kLdsBlock);
+        hipError_t e = hipSuccess;
+        switch (mode) {
+            case kFwdTrain:
+                e = hipFuncSetAttribute((const void *)k_forward_lds<LPN, J, kFwdTrain>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                if (e == hipSuccess) hipLaunchKernelGGL((k_forward_lds<LPN, J, kFwdTrain>), gl, bl, lds_bytes, s, a);
+                break;
+            case kFwdResidual:
+                e = hipFuncSetAttribute((const void *)k_forward_lds<LPN, J, kFwdResidual>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                if (e == hipSuccess) hipLaunchKernelGGL((k_forward_lds<LPN, J, kFwdResidual>), gl, bl, lds_bytes, s, a);
+                break;
+            case kFwdQ:
+                e = hipFuncSetAttribute((const void *)k_forward_lds<LPN, J, kFwdQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                if (e == hipSuccess) hipLaunchKernelGGL((k_forward_lds<LPN, J, kFwdQ>), gl, bl, lds_bytes, s, a);
+                break;
+        }
+        return e != hipSuccess ? e : hipGetLastError();
+    }
+#define FMHIP_FW(MODE_)                                                                                   \
+    if (a.pack_k >= 0) {                                                                                  \
+        if (a.hot_T) hipLaunchKernelGGL((k_forward<LPN, J, MODE_, true, true>), g, b, 0, s, a);           \
+        else hipLaunchKernelGGL((k_forward<LPN, J, MODE_, true, false>), g, b, 0, s, a);                  \
+    } else {                                                                                              \
+        if (a.hot_T) hipLaunchKernelGGL((k_forward<LPN, J, MODE_, false, true>), g, b, 0, s, a);          \
+        else hipLaunchKernelGGL((k_forward<LPN, J, MODE_, false, false>), g, b, 0, s, a);                 \
+    }
+    switch (mode) {
+        case kFwdTrain: FMHIP_FW(kFwdTrain) break;
+        case kFwdResidual: FMHIP_FW(kFwdResidual) break;
+        case kFwdQ: FMHIP_FW(kFwdQ) break;
+    }
+#undef FMHIP_FW
+    return hipGetLastError();
+}
+
+}  // namespace
+
+template <int LPN, int J>
+static int wt_occupancy() {
+    // the training-mode kernels decide (the scoring modes need no more registers); w-tile of 6144 floats
+    int n0 = 0, n1 = 0;
+    const size_t lds = 6144 * sizeof(float);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, (const void *)k_forward_wt<LPN, J, kFwdTrain, false>, kBlock, lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, (const void *)k_forward_wt<LPN, J, kFwdTrain, true>, kBlock, lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return 1;
+    }
+    const int n = n0 < n1 ? n0 : n1;
+    return n < 1 ? 1 : (n > 5 ? 5 : n);
+}
+
+int forward_wt_occupancy(int Kp) {
+    static int cache[4] = {0, 0, 0, 0};
+    const int idx = Kp == 32 ? 0 : Kp == 64 ? 1 : Kp == 128 ? 2 : 3;
+    if (!cache[idx]) {
+        switch (Kp) {
+            case 32: cache[idx] = wt_occupancy<8, 1>(); break;
+            case 64: cache[idx] = wt_occupancy<8, 2>(); break;
+            case 128: cache[idx] = wt_occupancy<16, 2>(); break;
+            default: cache[idx] = wt_occupancy<16, 4>(); break;
+        }
+    }
+    return cache[idx];
+}
+
+// The forward walks Kp = 64 rows with 8-lane slots holding two float4 per lane (DPP broadcasts, eight rows
+// per wave: 189 -> 177 us); the backward keeps 16-lane slots there (its pipelined kernel needs J = 1).
+// Row layouts in memory do not depend on the lane geometry, so the two may differ.
+hipError_t launch_forward(int Kp, FwdMode mode, const FwdArgs &a, hipStream_t s) {
+    switch (Kp) {
+        case 32: return fwd_dispatch<8, 1>(mode, a, s);
+        case 64: return fwd_dispatch<8, 2>(mode, a, s);
+        case 128: return fwd_dispatch<16, 2>(mode, a, s);
+        case 256: return fwd_dispatch<16, 4>(mode, a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_reduce_blocks(const double *bsum, int32_t nblocks, int32_t n_rows, float *scal, double *acc,
+                                hipStream_t s) {
+    hipLaunchKernelGGL(k_reduce_blocks, dim3(1), dim3(kBlock), 0, s, bsum, nblocks, n_rows, scal, acc);
+    return hipGetLastError();
+}
+
+
+}  // namespace fmhip
