@@ -1,4 +1,5 @@
-// fm_device.h — device-side helpers shared by fm_forward.hip / fm_backward.hip / fm_apply.hip: the hand-written gfx950 (CDNA4, wave64) kernels of the FM mini-batch SGD step.
+// fm_device.h — device-side helpers shared by fm_forward.hip / fm_backward.hip / fm_apply.hip, the
+// hand-written gfx950 (CDNA4, wave64) kernels of the FM mini-batch SGD step.
 //
 // Work shapes (HBM/L2-bound gather + stream at ~1 flop/B; the one GEMM-shaped piece, the gradient of
 // the dense hot block, is fp32 MFMA):
@@ -10,7 +11,7 @@
 //              deterministic)
 //   k_apply    SGD update fused with zeroing the packed gradient (dense, or the touched rows only)
 //
-// Lane geometry: a "slot" = LPN consecutive lanes (8 at Kp = 32, 16 above) owning one CSR row
+// Lane geometry: a "slot" = LPN consecutive lanes (8 at Kp = 32 and in the Kp = 64 forward, 16 otherwise) owning one CSR row
 // (forward) or one CSC range (backward); lane l of a slot holds factors 4*(l + jj*LPN) .. +3 for
 // jj < J, so one wave-instruction moves 64/LPN whole rows of Kp = 4*LPN*J floats (whole 128-B
 // lines: the texture addresser charges ~2 cycles per distinct line, whatever the bytes used), each
