@@ -277,6 +277,45 @@ def test_dense_hot_block(fmhip, k, n_hot, dup, zero):
     fm.close()
 
 
+@pytest.mark.parametrize("k", [4, 32])
+def test_dense_hot_block_takes_every_feature(fmhip, k):
+    """A dataset whose every feature is frequent (10 features, each in roughly half of the rows): the
+    sparse streams of its batches are EMPTY and the whole step runs through the dense block."""
+    rng = np.random.default_rng(17 + k)
+    n_rows, n1 = 900, 10
+    rows = [np.sort(rng.choice(n1, size=int(rng.integers(1, 9)), replace=False)).astype(np.int32) for _ in range(n_rows)]
+    rows[5] = np.zeros(0, np.int32)                                  # and an empty row
+    row_ptr = np.zeros(n_rows + 1, np.int64)
+    row_ptr[1:] = np.cumsum([len(r) for r in rows])
+    col = np.concatenate(rows)
+    a = dict(k=k, n1=n1, w0=0.1, w=rng.normal(0, 0.2, n1), v=rng.normal(0, 0.2, (k, n1)), row_ptr=row_ptr, col=col,
+             val=rng.uniform(0.2, 1.5, len(col)), y=rng.normal(0, 1, n_rows))
+    ds, fm = make(fmhip, a, batch_rows=250)
+    yh = fm.predict(ds)
+    oy = oracle.predict(a["w0"], a["w"], a["v"], row_ptr, col, a["val"])
+    assert (np.abs(yh - oy) <= TOL_Y * term_scale(a)).all()
+    for j in range(ds.n_batches):
+        lo, hi = j * 250, min(n_rows, (j + 1) * 250)
+        bi = ds.batch_info(j)
+        assert bi["nnz"] == row_ptr[hi] - row_ptr[lo] and bi["n_columns"] == len(np.unique(col[row_ptr[lo]:row_ptr[hi]]))
+        gv, gw, g0, st = fm.batchGradient(ds, j)
+        ogv, ogw, og0, osse, _ = oracle.batch_grad(a["w0"], a["w"], a["v"], lo, hi, row_ptr, col, a["val"], a["y"])
+        check_grad(gv, gw, ogv, ogw, np.abs(a["v"]).max())
+        feat, ptr, trows, tvals = ds.transposeInput(j)
+        assert ptr[-1] == bi["nnz"] and len(feat) == bi["n_columns"]
+    eta, regs = 0.05, (0.01, 1e-3, 1e-3)
+    sgd = fmhip.HipSGD(eta=eta, reg0=regs[0], regw=regs[1], regv=regs[2])
+    w0, w, v = a["w0"], a["w"], a["v"]
+    for _ in range(4):
+        fm = sgd.learn(fm, ds)
+        w0, w, v, sse = oracle.sgd_epoch(w0, w, v, 250, row_ptr, col, a["val"], a["y"], eta, *regs)
+        assert sgd.last_stats["sse"] == pytest.approx(sse, rel=1e-5)
+    assert np.linalg.norm(fm.v - v) <= 1e-4 * np.linalg.norm(v)
+    assert np.linalg.norm(fm.w - w) <= 1e-4 * np.linalg.norm(w)
+    ds.unpersist()
+    fm.close()
+
+
 def test_dense_hot_block_chunked_backward(fmhip):
     """The feature-interval backward on a dataset with a dense hot block: the hot rows are complete
     after the first interval's call, whatever interval their ids fall into."""
