@@ -24,8 +24,12 @@
  *  - device arithmetic is fp32, indices int32; host I/O is fp64 (as the reference) or
  *    fp32 (the *_f32 entry points).
  *  - one model/dataset lives on ONE GPU.  Data-parallel training runs one process per
- *    GPU; the packed gradient is exposed (fmhip_grad_*) so the host all-reduces it
- *    (RCCL) between fmhip_step_compute and fmhip_step_apply.
+ *    GPU: fmhip_comm_create joins the ranks into an RCCL communicator and fmhip_dp_step
+ *    runs forward -> backward -> all-reduce of the packed gradient (overlapped with the
+ *    backward) -> update entirely inside the library — the reduction the reference's
+ *    learner does itself inside `learn` (S/fm/lib/ALS.scala:153 `error.reduce(_+_)`).
+ *    The packed gradient is also exposed (fmhip_grad_*) for a host that brings its own
+ *    collective (fmhip_step_compute -> host all-reduce -> fmhip_step_apply).
  *  - a handle must not be used from two threads at once.
  */
 #ifndef FMHIP_H
@@ -36,7 +40,7 @@
 extern "C" {
 #endif
 
-#define FMHIP_VERSION 100 /* 0.1.0 */
+#define FMHIP_VERSION 200 /* 0.2.0 */
 
 enum {
     FMHIP_OK = 0,
@@ -44,7 +48,8 @@ enum {
     FMHIP_ERR_HIP = -2,          /* a HIP runtime call failed; message has hipGetErrorString */
     FMHIP_ERR_NOMEM = -3,        /* host or device allocation failed */
     FMHIP_ERR_SHAPE = -4,        /* dataset has a feature index > model.num_attribute */
-    FMHIP_ERR_UNSUPPORTED = -5   /* num_factor > FMHIP_MAX_FACTORS, batch too large ... */
+    FMHIP_ERR_UNSUPPORTED = -5,  /* num_factor > FMHIP_MAX_FACTORS, batch too large ... */
+    FMHIP_ERR_COMM = -6          /* RCCL could not be loaded, or a collective call failed */
 };
 
 #define FMHIP_MAX_FACTORS 256
@@ -53,6 +58,7 @@ enum {
 
 typedef struct fmhip_model *fmhip_model_t;
 typedef struct fmhip_dataset *fmhip_dataset_t;
+typedef struct fmhip_comm *fmhip_comm_t;
 
 typedef struct fmhip_stats {
     double sse;        /* sum over processed rows of e^2, e = yhat - y (S/fm/lib/ALS.scala:143) */
@@ -97,7 +103,15 @@ int fmhip_device_count(int *count);
  *   key 6  cap on the forward's resident workgroups per CU (0 = all that fit, default): measurement knob
  *   key 7  models with k > 32: the forward walks each batch's rows longest-first (1 = default; 0 = stored
  *          order), so the slots of a wave walk rows of equal length (k=64: 205 -> 190 us); narrower models
- *          gain nothing from it and always walk in stored order */
+ *          gain nothing from it and always walk in stored order
+ *   key 8  1 = take the flat 64-bit-address kernels that tables of 4 GiB and more need (V in the forward,
+ *          P in the backward) whatever the size; 0 = by size (default).  Test knob: reaches the paths of
+ *          Criteo-width models on small inputs
+ *   key 9  lazy weight decay (1 = on, default): the fused step (fmhip_sgd_step / _epoch) updates only the
+ *          rows a batch touched even with regw/regv > 0 — the decay of every row rides in a scale factor
+ *          of the tables (fm_apply.hip); 0 = dense update whenever there is decay.  Equal up to fp32 rounding.
+ * Keys 3 and 5 are read by fmhip_dataset_create at the time of the call (they decide the layout of the
+ * dataset being built and nothing else); every other key is read by the next launch. */
 int fmhip_tune(int key, int value);
 
 /* ---- model: `new FMModel(num_attribute, num_factor)`  S/fm/FMModel.scala:9-22 -- */
@@ -109,6 +123,10 @@ int fmhip_model_destroy(fmhip_model_t m);
 /* padded_factors: floats per device row (whole 128-B lines: 32, 64, 128 or 256) */
 int fmhip_model_info(fmhip_model_t m, int64_t *num_attribute, int32_t *num_factor, int32_t *padded_factors);
 /* w: n+1 doubles, v: k*(n+1) doubles at v[f + i*k]  (FMModel.w0 / .w / .v, S/fm/FMModel.scala:17-19) */
+/* The reference's own initialisation, drawn on the device: w0 = 0, w = 0, v ~ N(mean, stdev)
+ * (S/fm/FMModel.scala:17-22; its draw is unseeded — quirk Q2 — here `seed` makes it reproducible: element
+ * (f, i) depends only on (seed, f, i)).  For models too wide to stage on the host (2^25 x 64: 17 GB fp64). */
+int fmhip_model_init_normal(fmhip_model_t m, uint64_t seed, double mean, double stdev);
 int fmhip_model_set_params(fmhip_model_t m, double w0, const double *w, const double *v);
 int fmhip_model_get_params(fmhip_model_t m, double *w0, double *w, double *v);
 int fmhip_model_set_params_f32(fmhip_model_t m, float w0, const float *w, const float *v);
@@ -123,6 +141,12 @@ int fmhip_dataset_create(int device, int64_t n_rows, const int64_t *row_ptr, con
                          const double *val, const double *y, int64_t batch_rows, fmhip_dataset_t *out);
 int fmhip_dataset_create_f32(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col,
                              const float *val, const float *y, int64_t batch_rows, fmhip_dataset_t *out);
+/* Rows + labels only, for scoring held-out data (`fm.computeRMSE(test)`, S/driver.scala:100-112): no
+ * transposes, no mini-batches; y may be NULL (labels = 0: predict only).  Training calls refuse it. */
+int fmhip_rows_create(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const double *val,
+                      const double *y, fmhip_dataset_t *out);
+int fmhip_rows_create_f32(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const float *val,
+                          const float *y, fmhip_dataset_t *out);
 int fmhip_dataset_destroy(fmhip_dataset_t d);
 /* size = rdd.count (S/DataSet.scala:23-25); dimension = max feature index (:27-29) */
 int fmhip_dataset_info(fmhip_dataset_t d, int64_t *n_rows, int64_t *nnz, int64_t *dimension,
@@ -138,6 +162,9 @@ int fmhip_dataset_get_transpose(fmhip_dataset_t d, int64_t batch, int32_t *feat,
 /* ---- scoring ------------------------------------------------------------------ */
 /* FMModel.predict mapped over the rows (S/fm/FMModel.scala:34-63; dataset.rdd.mapValues(predict)) */
 int fmhip_predict(fmhip_model_t m, fmhip_dataset_t d, double *yhat /* n_rows */);
+/* FMModel.predict(SparseVector) for ad-hoc host rows (S/fm/FMModel.scala:34): uploads, scores, frees */
+int fmhip_predict_rows(fmhip_model_t m, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const double *val,
+                       double *yhat /* n_rows */);
 /* Model.computeRMSE (S/Model.scala:13-19) */
 int fmhip_rmse(fmhip_model_t m, fmhip_dataset_t d, double *rmse, fmhip_stats *stats /* nullable */);
 /* ALS.precomputeTermE (S/fm/lib/ALS.scala:142-144): e_r = yhat_r - y_r */
@@ -197,6 +224,50 @@ int fmhip_grad_layout(fmhip_model_t m, int64_t *row_floats, int64_t *gv_offset);
 int fmhip_step_apply(fmhip_model_t m, double eta, double reg0, double regw, double regv);
 /* scalars of the packed gradient as last computed/all-reduced (synchronises) */
 int fmhip_step_stats(fmhip_model_t m, fmhip_stats *stats);
+
+/* ---- data-parallel training inside the library (RCCL over xGMI) ------------------------------------
+ * One process (or host thread) per GPU, each with its own model replica and its own row shard.  The
+ * reference's learner reduces inside `learn` (S/fm/lib/ALS.scala:153, :34, :139) and is called once per
+ * iteration by the driver (S/fm/impl/FactorizationMachines.scala:45); likewise a `HipSGD.learn` on N GPUs
+ * calls fmhip_dp_epoch on every rank and nothing else.  RCCL (librccl.so.1) is loaded on first use;
+ * single-GPU users never need it.
+ *
+ *   rank 0:    fmhip_comm_unique_id(id)          -> ship the 128 bytes to every rank (Spark broadcast, ...)
+ *   each rank: fmhip_comm_create(m, id, rank, world, &c)
+ *              fmhip_dp_epoch(m, d, c, ...)  or  fmhip_dp_step(m, d, batch, c, ...) in lock-step
+ *
+ * A step: forward of this rank's mini-batch; backward of the cold (high-id) feature interval; its slice
+ * of the packed gradient is all-reduced on a second stream while the hot interval's backward runs; the
+ * rest (head + hot interval) follows; every rank applies the identical update with |B| = the summed row
+ * count, so the replicas stay bit-identical.  `batch` < 0: this rank has run out of rows and contributes
+ * zeros.  All ranks must call with the same (eta, reg*) and the same cut (fmhip_dp_plan). */
+#define FMHIP_UNIQUE_ID_BYTES 128
+int fmhip_comm_unique_id(void *id /* FMHIP_UNIQUE_ID_BYTES out */);
+int fmhip_comm_create(fmhip_model_t m, const void *id, int rank, int world, fmhip_comm_t *out);
+int fmhip_comm_destroy(fmhip_comm_t c);
+int fmhip_comm_info(fmhip_comm_t c, int *rank, int *world);
+/* Chooses the feature id that cuts the backward in two (about `upper_fraction` of rank 0's stored
+ * nonzeros lie at or above it; <= 0: no cut, one all-reduce after the whole backward) and broadcasts
+ * it from rank 0.  Collective.  cut (nullable) receives the id (0 = no cut). */
+int fmhip_dp_plan(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double upper_fraction, int64_t *cut);
+int fmhip_dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0,
+                  double regw, double regv);
+/* max over ranks of the local batch count steps, ascending batches; stats (nullable) = the GLOBAL
+ * sums over all ranks of the last step {sse, sum_e, rows, nonfinite} and steps taken */
+int fmhip_dp_epoch(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double eta, double reg0, double regw,
+                   double regv, fmhip_stats *stats);
+/* device time of the exchange as the compute stream saw it (HIP events, summed over the steps since
+ * _begin): exposed_ms = time the update waited for the last collective after the backward had finished;
+ * comm_ms = busy time of the collectives on their own stream; bytes = payload all-reduced per rank */
+typedef struct fmhip_comm_profile {
+    double exposed_ms, comm_ms;
+    int64_t steps, bytes;
+} fmhip_comm_profile;
+int fmhip_comm_profile_begin(fmhip_comm_t c);
+int fmhip_comm_profile_end(fmhip_comm_t c, fmhip_comm_profile *p);
+/* Contiguous row shard [lo, hi) of `rank`, balanced by stored nonzeros (not by row count): the
+ * partitioning a data-parallel caller applies before fmhip_dataset_create (pure host arithmetic). */
+int fmhip_shard_rows(int64_t n_rows, const int64_t *row_ptr, int world, int rank, int64_t *lo, int64_t *hi);
 
 /* ---- measurement ------------------------------------------------------------------ */
 int fmhip_profile_begin(fmhip_model_t m);                  /* start recording HIP events around every kernel */

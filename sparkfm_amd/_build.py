@@ -12,8 +12,10 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfmhip.so")
 SYNTH = os.path.join(LIBDIR, "libfmsynth.so")
 
-HIP_SOURCES = ["fm_forward.hip", "fm_backward.hip", "fm_apply.hip", "als_kernels.hip", "csc_build.hip", "fmhip_api.hip"]
-HIP_DEPS = ["fm_kernels.h", "fm_device.h", "als_kernels.h", "csc_build.h", os.path.join("..", "..", "include", "fmhip.h")]
+HIP_SOURCES = ["fm_forward.hip", "fm_backward.hip", "fm_apply.hip", "als_kernels.hip", "csc_build.hip", "fmhip_api.hip",
+               "fmhip_comm.hip"]
+HIP_DEPS = ["fm_kernels.h", "fm_device.h", "als_kernels.h", "csc_build.h", "fmhip_internal.h",
+            os.path.join("..", "..", "include", "fmhip.h")]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 
 
@@ -44,7 +46,7 @@ def build_lib(force=False, verbose=False):
         if job.wait() != 0:
             raise subprocess.CalledProcessError(job.returncode, cmd)
     if force or _stale(LIB, objs):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -26,7 +26,11 @@ SYMBOLS = (
     "fmhip_grad_floats", "fmhip_grad_bind", "fmhip_grad_ptr", "fmhip_grad_layout", "fmhip_step_compute",
     "fmhip_step_forward", "fmhip_step_backward", "fmhip_step_apply",
     "fmhip_step_stats", "fmhip_profile_begin", "fmhip_profile_begin_rotating", "fmhip_profile_end",
+    "fmhip_rows_create", "fmhip_rows_create_f32", "fmhip_predict_rows", "fmhip_model_init_normal",
+    "fmhip_comm_unique_id", "fmhip_comm_create", "fmhip_comm_destroy", "fmhip_comm_info", "fmhip_dp_plan",
+    "fmhip_dp_step", "fmhip_dp_epoch", "fmhip_comm_profile_begin", "fmhip_comm_profile_end", "fmhip_shard_rows",
 )
+UNIQUE_ID_BYTES = 128
 
 
 class Stats(C.Structure):
@@ -44,6 +48,13 @@ class Profile(C.Structure):
     def as_dict(self):
         return {KERNEL_NAMES[i]: dict(ms=self.ms[i], launches=self.launches[i], nnz=self.nnz[i], rows=self.rows[i])
                 for i in range(K_COUNT)}
+
+
+class CommProfile(C.Structure):
+    _fields_ = [("exposed_ms", C.c_double), ("comm_ms", C.c_double), ("steps", C.c_int64), ("bytes", C.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class FmhipError(RuntimeError):
@@ -111,6 +122,20 @@ def load():
     L.fmhip_profile_begin.argtypes = [vp]
     L.fmhip_profile_begin_rotating.argtypes = [vp]
     L.fmhip_profile_end.argtypes = [vp, P(Profile)]
+    L.fmhip_model_init_normal.argtypes = [vp, C.c_uint64, dbl, dbl]
+    L.fmhip_rows_create.argtypes = [C.c_int, i64, vp, vp, vp, vp, P(vp)]
+    L.fmhip_rows_create_f32.argtypes = [C.c_int, i64, vp, vp, vp, vp, P(vp)]
+    L.fmhip_predict_rows.argtypes = [vp, i64, vp, vp, vp, vp]
+    L.fmhip_comm_unique_id.argtypes = [vp]
+    L.fmhip_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, P(vp)]
+    L.fmhip_comm_destroy.argtypes = [vp]
+    L.fmhip_comm_info.argtypes = [vp, P(C.c_int), P(C.c_int)]
+    L.fmhip_dp_plan.argtypes = [vp, vp, vp, dbl, P(i64)]
+    L.fmhip_dp_step.argtypes = [vp, vp, i64, vp, dbl, dbl, dbl, dbl]
+    L.fmhip_dp_epoch.argtypes = [vp, vp, vp, dbl, dbl, dbl, dbl, P(Stats)]
+    L.fmhip_comm_profile_begin.argtypes = [vp]
+    L.fmhip_comm_profile_end.argtypes = [vp, P(CommProfile)]
+    L.fmhip_shard_rows.argtypes = [i64, vp, C.c_int, C.c_int, P(i64), P(i64)]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("fmhip_version", "fmhip_last_error"):

@@ -85,6 +85,17 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t o
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// P rows are written once by the forward and read by OTHER compute units in the backward (never from
+// this XCD's L2, which is not coherent with theirs): optionally stored non-temporally so they do not
+// displace the gathered V rows from L2 on their way out.
+__device__ __forceinline__ void p_store(float4 *dst, float4 v) {
+#ifdef FMHIP_P_NT
+    __builtin_nontemporal_store((f4v){v.x, v.y, v.z, v.w}, reinterpret_cast<f4v *>(dst));
+#else
+    *dst = v;
+#endif
+}
+
 template <int G>
 __device__ __forceinline__ float quad_bcast(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), G * 0x55, 0xf, 0xf, false));   // quad_perm:[G,G,G,G]

@@ -5,7 +5,7 @@
 
 namespace fmhip {
 
-int g_tune[kTuneCount] = {60, 1, 0, 0, 0, 1, 0, 1};   // forward: w-tile kernel; backward: pipelined; tile rows: auto; row blocks, XCD placement: off; hot block: on
+int g_tune[kTuneCount] = {60, 1, 0, 0, 0, 1, 0, 1, 0, 1};   // forward: w-tile kernel; backward: pipelined; tile rows: auto; row blocks, XCD placement: off; hot block: on; row order: on; forced flat loads: off; lazy decay: on
 
 int padded_factors(int k) {
     int kp = 32;   // a row is at least one 128-B line: the cost of a gather is per line, not per byte
@@ -122,8 +122,12 @@ __device__ __forceinline__ void hot_prologue(const float4 xq, const float *vh, c
 // MASKED = the row's last, partial step (entries >= cnt are dead); full steps carry no per-entry
 // compare/select — the vector ALU, not the memory path, is what the forward saturates
 // (profiles/r01_experiments.md, section 23).
-template <int LPN, int J, int CH, bool MASKED>
-__device__ __forceinline__ void fwd_step(const float *V, int c, float x, int cnt, int l, float4 (&q)[J], float4 (&s)[J]) {
+// BUF: V fits a 32-bit buffer view (< 4 GiB): a row's address is ONE 32-bit shift-add per entry (the
+// descriptor lives in scalar registers) instead of a 64-bit multiply-add pair, and the dead entries of a
+// partial step fetch nothing (out-of-range offset).  Wider tables take flat 64-bit addresses.
+template <int LPN, int J, int CH, bool MASKED, bool BUF>
+__device__ __forceinline__ void fwd_step(const float *V, __amdgpu_buffer_rsrc_t vr, int c, float x, int cnt, int l, float4 (&q)[J],
+                                         float4 (&s)[J]) {
     constexpr int KP = 4 * LPN * J;
 #pragma unroll
     for (int c0 = 0; c0 < LPN; c0 += CH) {
@@ -133,9 +137,15 @@ __device__ __forceinline__ void fwd_step(const float *V, int c, float x, int cnt
         for (int j = 0; j < CH; ++j) {
             const int cj = slot_bcast<LPN>(c, c0 + j);
             xs[j] = slot_bcast<LPN>(x, c0 + j);
-            const float4 *vr = reinterpret_cast<const float4 *>(V + (size_t)(uint32_t)cj * KP) + l;
+            if (BUF) {
+                const uint32_t off = (uint32_t)cj * (KP * 4u) + (uint32_t)l * 16u;
 #pragma unroll
-            for (int jj = 0; jj < J; ++jj) t[j][jj] = vr[jj * LPN];
+                for (int jj = 0; jj < J; ++jj) t[j][jj] = buf_load4(vr, (MASKED && c0 + j >= cnt) ? kOob : off + jj * LPN * 16u);
+            } else {
+                const float4 *vp = reinterpret_cast<const float4 *>(V + (size_t)(uint32_t)cj * KP) + l;
+#pragma unroll
+                for (int jj = 0; jj < J; ++jj) t[j][jj] = vp[jj * LPN];
+            }
         }
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
@@ -148,6 +158,85 @@ __device__ __forceinline__ void fwd_step(const float *V, int c, float x, int cnt
                 f4sqacc(s[jj], tv);
             }
         }
+    }
+}
+
+// What every forward kernel does once a row's sums are complete (FMModel.scala:48-55): the prediction, the
+// residual (ALS.scala:143), the row of P for the backward (or q itself, ALS.scala:146-150) and this
+// thread's share of the residual statistics.  q, s and lin are in units of the STORED tables; the scales
+// of a lazily decayed model (FwdArgs.sv / .sw; both 1 otherwise, and multiplying by 1 is exact) enter here:
+// the interaction is homogeneous of degree 2 in V, so a single-nonzero row still gives exactly 0 (quirk Q6).
+template <int LPN, int J, int MODE, bool PACKED>
+__device__ __forceinline__ void row_finish(const FwdArgs &a, int r, int l, float4 (&q)[J], float4 (&s)[J], float lin, float w0,
+                                           float &st1, float &st2, float &stbad) {
+    constexpr int KP = 4 * LPN * J;
+    // Packed rows (k < Kp): slot k of every V row holds the feature's linear weight w_i, so q_k
+    // accumulated sum w_i x_i — the linear term — and there was no separate w gather; slot k of the P row
+    // carries e to the backward the same way.
+    const int kl = PACKED ? (a.pack_k >> 2) & (LPN - 1) : 0, kj = PACKED ? (a.pack_k >> 2) / LPN : 0, kc = a.pack_k & 3;
+    float lin_all = 0.f;   // packed: the complete linear term, identical in every lane of the slot
+    if (PACKED) {
+        float lk = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj)
+            if (jj == kj) {
+                lk = f4pick(q[jj], kc);
+                if (l == kl) { f4set(q[jj], kc, 0.f); f4set(s[jj], kc, 0.f); }   // slot k is not a factor
+            }
+        lin_all = a.sw * __shfl(lk, kl, LPN);
+    }
+    float u = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) u += f4sqminus(q[jj], s[jj]);
+    float tot = fmaf(0.5f * a.sv * a.sv, u, a.sw * lin);
+#pragma unroll
+    for (int m = LPN >> 1; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, LPN);
+    const float yhat = w0 + (tot + lin_all);
+    const float e = yhat - a.y[a.row0 + r];
+    if (MODE == kFwdTrain) {
+        float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
+        const float es = e * a.sv;
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) {
+            float4 o = f4mul(q[jj], es);
+            if (PACKED && jj == kj && l == kl) f4set(o, kc, e);   // slot k of the P row carries e
+            p_store(pr + jj * LPN, o);
+        }
+    } else if (MODE == kFwdQ) {
+        float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) pr[jj * LPN] = f4mul(q[jj], a.sv);
+    }
+    if (l == 0) {
+        if (a.e) a.e[r] = e;
+        if (a.yhat) a.yhat[r] = yhat;
+        st1 += e;
+        st2 = fmaf(e, e, st2);
+        if (!isfinite(e)) stbad += 1.f;
+    }
+}
+
+// block partial of the residual statistics (fixed order; the fixup launch / k_reduce_blocks finishes the sum)
+template <int NT>
+__device__ __forceinline__ void block_stats(double *bsum, float st1, float st2, float stbad) {
+    if (!bsum) return;
+    __shared__ double sh[3][NT / 64];
+    double d1 = st1, d2 = st2, db = stbad;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        d1 += __shfl_xor(d1, m, 64);
+        d2 += __shfl_xor(d2, m, 64);
+        db += __shfl_xor(db, m, 64);
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][wv] = d1; sh[1][wv] = d2; sh[2][wv] = db; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t1 = 0.0, t2 = 0.0, tb = 0.0;
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) { t1 += sh[0][i]; t2 += sh[1][i]; tb += sh[2][i]; }
+        double *o = bsum + (size_t)blockIdx.x * 4;
+        o[0] = t1; o[1] = t2; o[2] = tb; o[3] = 0.0;
     }
 }
 
@@ -173,9 +262,6 @@ __global__ __launch_bounds__(kLdsBlock) void k_forward_lds(FwdArgs a) {
     const float w0 = *a.w0;
     const __amdgpu_buffer_rsrc_t vr = make_rsrc(a.V, a.v_bytes);
     float st1 = 0.f, st2 = 0.f, stbad = 0.f;
-    // rows are taken in the dataset's length-sorted order (longest first): the slots of a wave walk rows of
-    // (nearly) equal length, so no lane idles while a neighbour finishes a longer row, and every slot's
-    // share — one row per length stratum — weighs the same
     for (int ri = blockIdx.x * SLOTS + slot; ri < a.n_rows; ri += gridDim.x * SLOTS) {
         const int r = a.order ? a.order[ri] : ri;
         const int64_t p0 = a.row_ptr[a.row0 + r], p1 = a.row_ptr[a.row0 + r + 1];
@@ -223,75 +309,27 @@ __global__ __launch_bounds__(kLdsBlock) void k_forward_lds(FwdArgs a) {
                 }
             }
         }
-        float u = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < J; ++jj) u += f4sqminus(q[jj], s[jj]);
-        float tot = fmaf(0.5f, u, lin);
-#pragma unroll
-        for (int m = LPN >> 1; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, LPN);
-        const float yhat = w0 + tot;
-        const float e = yhat - a.y[a.row0 + r];
-        if (MODE == kFwdTrain) {
-            float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
-#pragma unroll
-            for (int jj = 0; jj < J; ++jj) pr[jj * LPN] = f4mul(q[jj], e);
-        } else if (MODE == kFwdQ) {
-            float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
-#pragma unroll
-            for (int jj = 0; jj < J; ++jj) pr[jj * LPN] = q[jj];
-        }
-        if (l == 0) {
-            if (a.e) a.e[r] = e;
-            if (a.yhat) a.yhat[r] = yhat;
-            st1 += e;
-            st2 = fmaf(e, e, st2);
-            if (!isfinite(e)) stbad += 1.f;
-        }
+        row_finish<LPN, J, MODE, false>(a, r, l, q, s, lin, w0, st1, st2, stbad);
     }
-    if (a.bsum) {
-        __shared__ double sh[3][kLdsBlock / 64];
-        double d1 = st1, d2 = st2, db = stbad;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            d1 += __shfl_xor(d1, m, 64);
-            d2 += __shfl_xor(d2, m, 64);
-            db += __shfl_xor(db, m, 64);
-        }
-        const int wv = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) { sh[0][wv] = d1; sh[1][wv] = d2; sh[2][wv] = db; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double t1 = 0.0, t2 = 0.0, tb = 0.0;
-#pragma unroll
-            for (int i = 0; i < kLdsBlock / 64; ++i) { t1 += sh[0][i]; t2 += sh[1][i]; tb += sh[2][i]; }
-            double *o = a.bsum + (size_t)blockIdx.x * 4;
-            o[0] = t1; o[1] = t2; o[2] = tb; o[3] = 0.0;
-        }
-    }
+    block_stats<kLdsBlock>(a.bsum, st1, st2, stbad);
 }
 
-template <int LPN, int J, int MODE, bool PACKED, bool HOT>
-__global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
-    constexpr int KP = 4 * LPN * J;
+// The row walk of k_forward / k_forward_wt.  Rows are taken in the dataset's length-sorted order when one
+// is given (longest first): the slots of a wave then walk rows of (nearly) equal length, so no lane idles
+// while a neighbour finishes a longer row.  WT: the linear weights of the wt_rows lowest (= hottest, for
+// frequency-ranked ids) feature ids are read from the LDS tile `wt` — a 64-lane gather of w costs ~2 TA
+// cycles per distinct line touched, as much per nonzero as the whole 128-B V-row gather
+// (profiles/r01_experiments.md §13); lanes whose id is in the tile drop out of the global gather.
+template <int LPN, int J, int MODE, bool PACKED, bool HOT, bool WT, bool BUF>
+__device__ __forceinline__ void forward_rows(const FwdArgs &a, const float *wt, const float *vh, const float *wh, bool hot_plain) {
     constexpr int SLOTS = kBlock / LPN;
     constexpr int CH = (LPN * J > 16) ? (16 / J) : LPN;  // entries whose V rows are in flight together
     const int l = threadIdx.x & (LPN - 1);
     const int slot = threadIdx.x / LPN;
     const float w0 = *a.w0;
-    // Packed rows (k < Kp): slot k of every V row holds the feature's linear weight w_i, so q_k
-    // accumulates sum w_i x_i — the linear term — for free and there is no separate w gather (a
-    // 64-lane scalar gather costs the texture addresser as much as the whole row gather); slot k of
-    // the P row carries e to the backward the same way.
-    constexpr bool packed = PACKED;
-    const int kl = packed ? (a.pack_k >> 2) & (LPN - 1) : 0, kj = packed ? (a.pack_k >> 2) / LPN : 0, kc = a.pack_k & 3;
-    __shared__ __attribute__((aligned(16))) float vh[HOT ? kHotT * KP : 4];
-    __shared__ float wh[HOT ? kHotT : 1];
-    bool hot_plain = false;
-    if (HOT) hot_plain = hot_stage<KP>(a, vh, wh);
+    const int T = WT ? a.wt_rows : 0;
+    const __amdgpu_buffer_rsrc_t vr = make_rsrc(a.V, a.v_bytes);
     float st1 = 0.f, st2 = 0.f, stbad = 0.f;   // this thread's share of {sum e, sum e^2, nonfinite}
-    // rows are taken in the dataset's length-sorted order (longest first): the slots of a wave walk rows of
-    // (nearly) equal length, so no lane idles while a neighbour finishes a longer row, and every slot's
-    // share — one row per length stratum — weighs the same
     for (int ri = blockIdx.x * SLOTS + slot; ri < a.n_rows; ri += gridDim.x * SLOTS) {
         const int r = a.order ? a.order[ri] : ri;
         float4 xh = f4zero();
@@ -310,9 +348,9 @@ __global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
             const int c = stream_load(a.col + base + l);
             const float x = stream_load(a.val + base + l);
             float wv = 0.f;
-            if (!packed) wv = a.w[c];
-            fwd_step<LPN, J, CH, false>(a.V, c, x, LPN, l, q, s);
-            if (!packed) lin = fmaf(wv, x, lin);
+            if (!PACKED) wv = (WT && c < T) ? wt[c] : a.w[c];
+            fwd_step<LPN, J, CH, false, BUF>(a.V, vr, c, x, LPN, l, q, s);
+            if (!PACKED) lin = fmaf(wv, x, lin);       // consumed after the gathers are on their way
         }
         if (base < p1) {                               // the row's last, partial step
             const int64_t p = base + l;
@@ -321,180 +359,40 @@ __global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
             if (p < p1) {
                 c = stream_load(a.col + p);
                 x = stream_load(a.val + p);
-                if (!packed) wv = a.w[c];
+                if (!PACKED) wv = (WT && c < T) ? wt[c] : a.w[c];
             }
-            fwd_step<LPN, J, CH, true>(a.V, c, x, (int)(p1 - base), l, q, s);
-            if (!packed) lin = fmaf(wv, x, lin);
+            fwd_step<LPN, J, CH, true, BUF>(a.V, vr, c, x, (int)(p1 - base), l, q, s);
+            if (!PACKED) lin = fmaf(wv, x, lin);
         }
-        float lin_all = 0.f;   // packed: the complete linear term, identical in every lane of the slot
-        if (packed) {
-            float lk = 0.f;
-#pragma unroll
-            for (int jj = 0; jj < J; ++jj)
-                if (jj == kj) {
-                    lk = f4pick(q[jj], kc);
-                    if (l == kl) { f4set(q[jj], kc, 0.f); f4set(s[jj], kc, 0.f); }   // slot k is not a factor
-                }
-            lin_all = __shfl(lk, kl, LPN);
-        }
-        float u = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < J; ++jj) u += f4sqminus(q[jj], s[jj]);
-        float tot = fmaf(0.5f, u, lin);
-#pragma unroll
-        for (int m = LPN >> 1; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, LPN);
-        const float yhat = w0 + (tot + lin_all);
-        const float e = yhat - a.y[a.row0 + r];
-        if (MODE == kFwdTrain) {
-            float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
-#pragma unroll
-            for (int jj = 0; jj < J; ++jj) {
-                float4 o = f4mul(q[jj], e);
-                if (packed && jj == kj && l == kl) f4set(o, kc, e);   // slot k of the P row carries e
-                pr[jj * LPN] = o;
-            }
-        } else if (MODE == kFwdQ) {
-            float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
-#pragma unroll
-            for (int jj = 0; jj < J; ++jj) pr[jj * LPN] = q[jj];
-        }
-        if (l == 0) {
-            if (a.e) a.e[r] = e;
-            if (a.yhat) a.yhat[r] = yhat;
-            st1 += e;
-            st2 = fmaf(e, e, st2);
-            if (!isfinite(e)) stbad += 1.f;
-        }
+        row_finish<LPN, J, MODE, PACKED>(a, r, l, q, s, lin, w0, st1, st2, stbad);
     }
-    // block partial of the residual statistics (fixed order; k_reduce_blocks finishes the sum)
-    if (a.bsum) {
-        __shared__ double sh[3][kBlock / 64];
-        double d1 = st1, d2 = st2, db = stbad;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            d1 += __shfl_xor(d1, m, 64);
-            d2 += __shfl_xor(d2, m, 64);
-            db += __shfl_xor(db, m, 64);
-        }
-        const int wv = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) { sh[0][wv] = d1; sh[1][wv] = d2; sh[2][wv] = db; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double t1 = 0.0, t2 = 0.0, tb = 0.0;
-#pragma unroll
-            for (int i = 0; i < kBlock / 64; ++i) { t1 += sh[0][i]; t2 += sh[1][i]; tb += sh[2][i]; }
-            double *o = a.bsum + (size_t)blockIdx.x * 4;
-            o[0] = t1; o[1] = t2; o[2] = tb; o[3] = 0.0;
-        }
-    }
+    block_stats<kBlock>(a.bsum, st1, st2, stbad);
 }
 
-// k_forward with an LDS-resident tile of the hot linear weights (see the comment in the body)
-// (second launch bound = waves per SIMD: the persistent grid of forward_blocks_wt is sized for 5, and a
-// register count that admits only 4 would run it in two rounds)
-template <int LPN, int J, int MODE, bool HOT>
-__global__ __launch_bounds__(kBlock, (LPN * J <= 8 ? 5 : 1)) void k_forward_wt(FwdArgs a) {
+template <int LPN, int J, int MODE, bool PACKED, bool HOT, bool BUF>
+__global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
     constexpr int KP = 4 * LPN * J;
-    constexpr int SLOTS = kBlock / LPN;
-    constexpr int CH = (LPN * J > 16) ? (16 / J) : LPN;  // entries whose V rows are in flight together
-    const int l = threadIdx.x & (LPN - 1);
-    const int slot = threadIdx.x / LPN;
-    const float w0 = *a.w0;
-    // w-tile: the linear weights of the wt_rows lowest (= hottest, for frequency-ranked ids) feature
-    // ids live in LDS.  A 64-lane gather of w costs ~2 TA cycles per distinct line touched — as much
-    // per nonzero as the whole 128-B V-row gather (profiles/r01_experiments.md §13); lanes whose id is
-    // in the tile read LDS instead and drop out of the global gather.
-    extern __shared__ __attribute__((aligned(16))) float wt[];
-    const int T = a.wt_rows;
     __shared__ __attribute__((aligned(16))) float vh[HOT ? kHotT * KP : 4];
     __shared__ float wh[HOT ? kHotT : 1];
-    for (int i = threadIdx.x; i < T; i += kBlock) wt[i] = a.w[i];
+    bool hot_plain = false;
+    if (HOT) hot_plain = hot_stage<KP>(a, vh, wh);
+    forward_rows<LPN, J, MODE, PACKED, HOT, false, BUF>(a, nullptr, vh, wh, hot_plain);
+}
+
+// k_forward with an LDS-resident tile of the hot linear weights.  (Second launch bound = waves per SIMD:
+// the persistent grid of forward_blocks_wt is sized for 5, and a register count that admits only 4 would
+// run it in two rounds.)
+template <int LPN, int J, int MODE, bool HOT, bool BUF>
+__global__ __launch_bounds__(kBlock, (LPN * J <= 8 ? 5 : 1)) void k_forward_wt(FwdArgs a) {
+    constexpr int KP = 4 * LPN * J;
+    extern __shared__ __attribute__((aligned(16))) float wt[];
+    __shared__ __attribute__((aligned(16))) float vh[HOT ? kHotT * KP : 4];
+    __shared__ float wh[HOT ? kHotT : 1];
+    for (int i = threadIdx.x; i < a.wt_rows; i += kBlock) wt[i] = a.w[i];
     bool hot_plain = false;
     if (HOT) hot_plain = hot_stage<KP>(a, vh, wh);
     else __syncthreads();
-    float st1 = 0.f, st2 = 0.f, stbad = 0.f;   // this thread's share of {sum e, sum e^2, nonfinite}
-    // rows are taken in the dataset's length-sorted order (longest first): the slots of a wave walk rows of
-    // (nearly) equal length, so no lane idles while a neighbour finishes a longer row, and every slot's
-    // share — one row per length stratum — weighs the same
-    for (int ri = blockIdx.x * SLOTS + slot; ri < a.n_rows; ri += gridDim.x * SLOTS) {
-        const int r = a.order ? a.order[ri] : ri;
-        float4 xh = f4zero();
-        if (HOT) xh = hot_load(a, r, l);
-        const int64_t p0 = a.row_ptr[a.row0 + r], p1 = a.row_ptr[a.row0 + r + 1];
-        float4 q[J], s[J];
-#pragma unroll
-        for (int jj = 0; jj < J; ++jj) { q[jj] = f4zero(); s[jj] = f4zero(); }
-        float lin = 0.f;
-        if (HOT) {
-            if (hot_plain) hot_prologue<LPN, J, true, false>(xh, vh, wh, l, q, s, lin);
-            else hot_prologue<LPN, J, true, true>(xh, vh, wh, l, q, s, lin);
-        }
-        int64_t base = p0;
-        for (; base + LPN <= p1; base += LPN) {        // full steps
-            const int c = stream_load(a.col + base + l);
-            const float x = stream_load(a.val + base + l);
-            const float wv = c < T ? wt[c] : a.w[c];
-            fwd_step<LPN, J, CH, false>(a.V, c, x, LPN, l, q, s);
-            lin = fmaf(wv, x, lin);                    // consumed after the gathers are on their way
-        }
-        if (base < p1) {                               // the row's last, partial step
-            const int64_t p = base + l;
-            int c = 0;
-            float x = 0.f, wv = 0.f;
-            if (p < p1) {
-                c = stream_load(a.col + p);
-                x = stream_load(a.val + p);
-                wv = c < T ? wt[c] : a.w[c];
-            }
-            fwd_step<LPN, J, CH, true>(a.V, c, x, (int)(p1 - base), l, q, s);
-            lin = fmaf(wv, x, lin);
-        }
-        float u = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < J; ++jj) u += f4sqminus(q[jj], s[jj]);
-        float tot = fmaf(0.5f, u, lin);
-#pragma unroll
-        for (int m = LPN >> 1; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, LPN);
-        const float yhat = w0 + tot;
-        const float e = yhat - a.y[a.row0 + r];
-        if (MODE == kFwdTrain) {
-            float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
-#pragma unroll
-            for (int jj = 0; jj < J; ++jj) pr[jj * LPN] = f4mul(q[jj], e);
-        } else if (MODE == kFwdQ) {
-            float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
-#pragma unroll
-            for (int jj = 0; jj < J; ++jj) pr[jj * LPN] = q[jj];
-        }
-        if (l == 0) {
-            if (a.e) a.e[r] = e;
-            if (a.yhat) a.yhat[r] = yhat;
-            st1 += e;
-            st2 = fmaf(e, e, st2);
-            if (!isfinite(e)) stbad += 1.f;
-        }
-    }
-    // block partial of the residual statistics (fixed order; k_reduce_blocks finishes the sum)
-    if (a.bsum) {
-        __shared__ double sh[3][kBlock / 64];
-        double d1 = st1, d2 = st2, db = stbad;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            d1 += __shfl_xor(d1, m, 64);
-            d2 += __shfl_xor(d2, m, 64);
-            db += __shfl_xor(db, m, 64);
-        }
-        const int wv = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) { sh[0][wv] = d1; sh[1][wv] = d2; sh[2][wv] = db; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double t1 = 0.0, t2 = 0.0, tb = 0.0;
-#pragma unroll
-            for (int i = 0; i < kBlock / 64; ++i) { t1 += sh[0][i]; t2 += sh[1][i]; tb += sh[2][i]; }
-            double *o = a.bsum + (size_t)blockIdx.x * 4;
-            o[0] = t1; o[1] = t2; o[2] = tb; o[3] = 0.0;
-        }
-    }
+    forward_rows<LPN, J, MODE, false, HOT, true, BUF>(a, wt, vh, wh, hot_plain);
 }
 
 __global__ __launch_bounds__(kBlock) void k_reduce_blocks(const double *bsum, int32_t nblocks, int32_t n_rows, float *scal,
@@ -503,63 +401,80 @@ __global__ __launch_bounds__(kBlock) void k_reduce_blocks(const double *bsum, in
     reduce_blocks_body(bsum, nblocks, n_rows, scal, acc, sh);
 }
 
+// dense V *= sv, w *= sw (lazily decayed tables back to scale 1)
+template <int KP>
+__global__ __launch_bounds__(kBlock) void k_rescale(float *V, float *w, int64_t n1, int32_t pack_k, float sv, float sw) {
+    constexpr int LPR = KP / 4;
+    const int64_t total = n1 * LPR;
+    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = idx / LPR;
+        const int c = (int)(idx % LPR);
+        float4 *p = reinterpret_cast<float4 *>(V) + idx;
+        float4 v = *p;
+        const float keep = f4pick(v, pack_k & 3);
+        v = f4mul(v, sv);
+        if (pack_k >= 0 && c == (pack_k >> 2)) f4set(v, pack_k & 3, keep * sw);
+        *p = v;
+        if (c == 0) w[i] *= sw;
+    }
+}
+
+// The one place that decides which forward kernel runs and how large its grid is (the number of
+// per-block statistic partials the launch writes): packed rows carry w in the row, so only the plain
+// kernel handles them; the LDS V-tile kernel needs V to fit a 32-bit buffer view and has no hot-block
+// prologue.
+struct FwdPlan { int var; int blocks; };
 template <int LPN, int J>
-hipError_t fwd_dispatch(FwdMode mode, const FwdArgs &a, hipStream_t s) {
-    int64_t blocks = forward_blocks(4 * LPN * J, a.n_rows);
-    dim3 g((unsigned)blocks), b(kBlock);
+FwdPlan fwd_plan(const FwdArgs &a) {
+    constexpr int KP = 4 * LPN * J;
     int var = g_tune[kTuneFwd];
-    if (a.pack_k >= 0) var = 0;              // packed rows carry w in the row: only the plain kernel handles them
-    if (var == 20 && (!a.v_bytes || a.hot_T)) var = a.hot_T ? 60 : 0;   // the LDS V-tile kernel needs V to fit a 32-bit buffer view; it has no hot-block prologue
-    if (var == 60 && a.wt_rows > 0) {
+    if (a.pack_k >= 0) var = 0;
+    if (var == 20 && (!a.v_bytes || a.hot_T || a.tile_rows < 1)) var = a.hot_T ? 60 : 0;
+    if (var == 60 && a.wt_rows < 1) var = 0;
+    if (var != 20 && var != 60) var = 0;
+    const int blocks = var == 60 ? forward_blocks_wt(KP, a.n_rows) : var == 20 ? forward_blocks_lds(a.n_rows) : forward_blocks(KP, a.n_rows);
+    return {var, blocks};
+}
+
+template <int LPN, int J, int MODE>
+hipError_t fwd_launch(const FwdArgs &a, hipStream_t s, int *n_partials) {
+    const FwdPlan pl = fwd_plan<LPN, J>(a);
+    if (n_partials) *n_partials = pl.blocks;
+    const dim3 g((unsigned)pl.blocks), b(kBlock);
+    const bool buf = a.v_bytes != 0;
+    if (pl.var == 60) {
         const size_t lds_bytes = (size_t)a.wt_rows * sizeof(float);
-        int64_t nb = forward_blocks_wt(4 * LPN * J, a.n_rows);
-        dim3 gw((unsigned)nb);
-#define FMHIP_WT(MODE_)                                                                                  \
-    if (a.hot_T) hipLaunchKernelGGL((k_forward_wt<LPN, J, MODE_, true>), gw, b, lds_bytes, s, a);         \
-    else hipLaunchKernelGGL((k_forward_wt<LPN, J, MODE_, false>), gw, b, lds_bytes, s, a)
-        switch (mode) {
-            case kFwdTrain: FMHIP_WT(kFwdTrain); break;
-            case kFwdResidual: FMHIP_WT(kFwdResidual); break;
-            case kFwdQ: FMHIP_WT(kFwdQ); break;
-        }
+#define FMHIP_WT(HOT_, BUF_) hipLaunchKernelGGL((k_forward_wt<LPN, J, MODE, HOT_, BUF_>), g, b, lds_bytes, s, a)
+        if (a.hot_T) { if (buf) FMHIP_WT(true, true); else FMHIP_WT(true, false); }
+        else { if (buf) FMHIP_WT(false, true); else FMHIP_WT(false, false); }
 #undef FMHIP_WT
         return hipGetLastError();
     }
-    if (var == 20 && a.tile_rows > 0) {
+    if (pl.var == 20) {
         const size_t lds_bytes = (size_t)a.tile_rows * (4 * LPN * J + 1) * sizeof(float);
-        dim3 gl((unsigned)forward_blocks_lds(a.n_rows)), bl(kLdsBlock);
-        hipError_t e = hipSuccess;
-        switch (mode) {
-            case kFwdTrain:
-                e = hipFuncSetAttribute((const void *)k_forward_lds<LPN, J, kFwdTrain>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-                if (e == hipSuccess) hipLaunchKernelGGL((k_forward_lds<LPN, J, kFwdTrain>), gl, bl, lds_bytes, s, a);
-                break;
-            case kFwdResidual:
-                e = hipFuncSetAttribute((const void *)k_forward_lds<LPN, J, kFwdResidual>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-                if (e == hipSuccess) hipLaunchKernelGGL((k_forward_lds<LPN, J, kFwdResidual>), gl, bl, lds_bytes, s, a);
-                break;
-            case kFwdQ:
-                e = hipFuncSetAttribute((const void *)k_forward_lds<LPN, J, kFwdQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-                if (e == hipSuccess) hipLaunchKernelGGL((k_forward_lds<LPN, J, kFwdQ>), gl, bl, lds_bytes, s, a);
-                break;
-        }
-        return e != hipSuccess ? e : hipGetLastError();
+        hipError_t e = hipFuncSetAttribute((const void *)k_forward_lds<LPN, J, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_forward_lds<LPN, J, MODE>), g, dim3(kLdsBlock), lds_bytes, s, a);
+        return hipGetLastError();
     }
-#define FMHIP_FW(MODE_)                                                                                   \
-    if (a.pack_k >= 0) {                                                                                  \
-        if (a.hot_T) hipLaunchKernelGGL((k_forward<LPN, J, MODE_, true, true>), g, b, 0, s, a);           \
-        else hipLaunchKernelGGL((k_forward<LPN, J, MODE_, true, false>), g, b, 0, s, a);                  \
-    } else {                                                                                              \
-        if (a.hot_T) hipLaunchKernelGGL((k_forward<LPN, J, MODE_, false, true>), g, b, 0, s, a);          \
-        else hipLaunchKernelGGL((k_forward<LPN, J, MODE_, false, false>), g, b, 0, s, a);                 \
-    }
-    switch (mode) {
-        case kFwdTrain: FMHIP_FW(kFwdTrain) break;
-        case kFwdResidual: FMHIP_FW(kFwdResidual) break;
-        case kFwdQ: FMHIP_FW(kFwdQ) break;
-    }
+#define FMHIP_FW(PACKED_, HOT_)                                                                   \
+    do {                                                                                          \
+        if (buf) hipLaunchKernelGGL((k_forward<LPN, J, MODE, PACKED_, HOT_, true>), g, b, 0, s, a);  \
+        else hipLaunchKernelGGL((k_forward<LPN, J, MODE, PACKED_, HOT_, false>), g, b, 0, s, a);     \
+    } while (0)
+    if (a.pack_k >= 0) { if (a.hot_T) FMHIP_FW(true, true); else FMHIP_FW(true, false); }
+    else { if (a.hot_T) FMHIP_FW(false, true); else FMHIP_FW(false, false); }
 #undef FMHIP_FW
     return hipGetLastError();
+}
+
+template <int LPN, int J>
+hipError_t fwd_dispatch(FwdMode mode, const FwdArgs &a, hipStream_t s, int *n_partials) {
+    switch (mode) {
+        case kFwdTrain: return fwd_launch<LPN, J, kFwdTrain>(a, s, n_partials);
+        case kFwdResidual: return fwd_launch<LPN, J, kFwdResidual>(a, s, n_partials);
+        default: return fwd_launch<LPN, J, kFwdQ>(a, s, n_partials);
+    }
 }
 
 }  // namespace
@@ -567,15 +482,19 @@ hipError_t fwd_dispatch(FwdMode mode, const FwdArgs &a, hipStream_t s) {
 template <int LPN, int J>
 static int wt_occupancy() {
     // the training-mode kernels decide (the scoring modes need no more registers); w-tile of 6144 floats
-    int n0 = 0, n1 = 0;
+    int n = 5;
     const size_t lds = 6144 * sizeof(float);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, (const void *)k_forward_wt<LPN, J, kFwdTrain, false>, kBlock, lds) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, (const void *)k_forward_wt<LPN, J, kFwdTrain, true>, kBlock, lds) != hipSuccess) {
-        (void)hipGetLastError();
-        return 1;
+    const void *fns[4] = {(const void *)k_forward_wt<LPN, J, kFwdTrain, false, false>, (const void *)k_forward_wt<LPN, J, kFwdTrain, true, false>,
+                          (const void *)k_forward_wt<LPN, J, kFwdTrain, false, true>, (const void *)k_forward_wt<LPN, J, kFwdTrain, true, true>};
+    for (const void *fn : fns) {
+        int ni = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&ni, fn, kBlock, lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return 1;
+        }
+        if (ni < n) n = ni;
     }
-    const int n = n0 < n1 ? n0 : n1;
-    return n < 1 ? 1 : (n > 5 ? 5 : n);
+    return n < 1 ? 1 : n;
 }
 
 int forward_wt_occupancy(int Kp) {
@@ -595,12 +514,12 @@ int forward_wt_occupancy(int Kp) {
 // The forward walks Kp = 64 rows with 8-lane slots holding two float4 per lane (DPP broadcasts, eight rows
 // per wave: 189 -> 177 us); the backward keeps 16-lane slots there (its pipelined kernel needs J = 1).
 // Row layouts in memory do not depend on the lane geometry, so the two may differ.
-hipError_t launch_forward(int Kp, FwdMode mode, const FwdArgs &a, hipStream_t s) {
+hipError_t launch_forward(int Kp, FwdMode mode, const FwdArgs &a, hipStream_t s, int *n_partials) {
     switch (Kp) {
-        case 32: return fwd_dispatch<8, 1>(mode, a, s);
-        case 64: return fwd_dispatch<8, 2>(mode, a, s);
-        case 128: return fwd_dispatch<16, 2>(mode, a, s);
-        case 256: return fwd_dispatch<16, 4>(mode, a, s);
+        case 32: return fwd_dispatch<8, 1>(mode, a, s, n_partials);
+        case 64: return fwd_dispatch<8, 2>(mode, a, s, n_partials);
+        case 128: return fwd_dispatch<16, 2>(mode, a, s, n_partials);
+        case 256: return fwd_dispatch<16, 4>(mode, a, s, n_partials);
         default: return hipErrorInvalidValue;
     }
 }
@@ -611,5 +530,19 @@ hipError_t launch_reduce_blocks(const double *bsum, int32_t nblocks, int32_t n_r
     return hipGetLastError();
 }
 
+hipError_t launch_rescale(int Kp, float *V, float *w, int64_t n1, int32_t pack_k, float sv, float sw, hipStream_t s) {
+    int64_t blocks = (n1 * (Kp / 4) + kBlock - 1) / kBlock;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    const dim3 g((unsigned)blocks), b(kBlock);
+    switch (Kp) {
+        case 32: hipLaunchKernelGGL(k_rescale<32>, g, b, 0, s, V, w, n1, pack_k, sv, sw); break;
+        case 64: hipLaunchKernelGGL(k_rescale<64>, g, b, 0, s, V, w, n1, pack_k, sv, sw); break;
+        case 128: hipLaunchKernelGGL(k_rescale<128>, g, b, 0, s, V, w, n1, pack_k, sv, sw); break;
+        case 256: hipLaunchKernelGGL(k_rescale<256>, g, b, 0, s, V, w, n1, pack_k, sv, sw); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
 
 }  // namespace fmhip

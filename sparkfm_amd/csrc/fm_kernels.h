@@ -12,7 +12,8 @@ constexpr int kScalars = 8;        // packed-gradient tail: {sum e, sum e^2, row
 constexpr int kGradHead = 32;      // floats reserved for them at the front of the packed gradient (one 128-B line)
 
 // runtime kernel-variant knobs (diagnostics / A-B benchmarking; fmhip_tune)
-enum { kTuneFwd = 0, kTuneBwd = 1, kTuneTile = 2, kTuneRowBlock = 3, kTuneXcd = 4, kTuneHot = 5, kTuneFwdOcc = 6, kTuneRowOrder = 7, kTuneCount = 8 };
+enum { kTuneFwd = 0, kTuneBwd = 1, kTuneTile = 2, kTuneRowBlock = 3, kTuneXcd = 4, kTuneHot = 5, kTuneFwdOcc = 6, kTuneRowOrder = 7,
+       kTuneFlat = 8, kTuneLazy = 9, kTuneCount = 10 };
 constexpr int kHotT = 16;           // slots of the dense hot block (fp32 per row: one 64-B half line)
 extern int g_tune[kTuneCount];
 
@@ -21,9 +22,8 @@ int padded_factors(int k);
 // grid of k_forward for a batch (also the number of per-block statistic partials it writes)
 constexpr int kMaxFwdBlocks = 16384;
 int forward_blocks(int Kp, int64_t n_rows);
-int forward_blocks_lds(int64_t n_rows);
+int forward_blocks_lds(int64_t n_rows);           // grid of the LDS V-tile forward
 int forward_blocks_wt(int Kp, int64_t n_rows);    // grid of the w-tile forward
-int forward_blocks_r(int Kp, int64_t n_rows, int rows_per_slot);   // grid of the rolling-prefetch forward   // grid of the LDS V-tile forward
 
 enum FwdMode { kFwdTrain = 0, kFwdResidual = 1, kFwdQ = 2 };
 
@@ -50,6 +50,9 @@ struct FwdArgs {
     int32_t hot_T;           // 0 = none
     const float *xhot;       // [n_rows][kHotT], this batch's slice
     const int32_t *hot_ids;  // [kHotT], -1 = unused slot
+    // lazy weight decay: the stored tables hold U with V = sv * U and w = sw * (stored w) (both 1 unless
+    // rows-only updates with decay are pending, fm_apply.hip); the row epilogue applies them
+    float sv, sw;
 };
 
 // dense hot block, gradient side: G rows of the hot features = xhot^T . P (plus their two scalar sums)
@@ -109,6 +112,10 @@ struct ApplyArgs {
     int64_t n1;         // n+1 (rows of V actually used)
     int32_t pack_k;     // >= 0: packed rows — slot pack_k of a V row is the linear weight
     float eta, reg0, regw, regv;
+    // scale of the stored tables on entry (V = sv_in * stored, w = sw_in * stored; fm_apply.hip).  The dense
+    // pass leaves them at scale 1; the rows-only pass leaves them at sv_in * (1 - eta*regv) (resp. w) and
+    // uses eta_v = eta / that (eta_w likewise) as its step on the stored values
+    float sv_in, sw_in, eta_v, eta_w;
     // rows-only variant (feat != NULL): just the listed distinct features and the hot block's ids
     const int32_t *feat;     // [n_feat] distinct feature ids of the batch
     int32_t n_feat;
@@ -118,7 +125,13 @@ struct ApplyArgs {
 
 int hot_blocks(int Kp, int64_t n_rows);
 
-hipError_t launch_forward(int Kp, FwdMode mode, const FwdArgs &a, hipStream_t s);
+// n_partials (optional): the number of per-block statistic partials the launch writes to a.bsum
+hipError_t launch_forward(int Kp, FwdMode mode, const FwdArgs &a, hipStream_t s, int *n_partials = nullptr);
+// V[i][f] = mean + stdev * N(0,1) for f < k (a hash of (seed, i, f) through Box-Muller), padding and w = 0
+hipError_t launch_init_normal(int Kp, float *V, float *w, float *w0, int64_t n1, int64_t n1p, int32_t k, uint64_t seed, float mean,
+                              float stdev, hipStream_t s);
+// dense V *= sv, w *= sw (packed rows: the w slot of a V row by sw): brings lazily decayed tables back to scale 1
+hipError_t launch_rescale(int Kp, float *V, float *w, int64_t n1, int32_t pack_k, float sv, float sw, hipStream_t s);
 hipError_t launch_backward(int Kp, const BwdArgs &a, hipStream_t s);
 hipError_t launch_fixup(int Kp, const BwdArgs &a, hipStream_t s);
 hipError_t launch_fixup2(int Kp, const BwdArgs &a, hipStream_t s);   // sums the pieces of multi-piece features

@@ -3,8 +3,7 @@
 // Owns device memory, the per-batch transposes and the launch sequence of one mini-batch
 // SGD step:   k_forward -> k_backward -> k_fixup (+ statistics) -> [host all-reduce] -> k_apply
 // Everything here is plumbing; the arithmetic lives in fm_kernels.hip.
-#include "../../include/fmhip.h"
-#include "fm_kernels.h"
+#include "fmhip_internal.h"
 #include "als_kernels.h"
 #include "csc_build.h"
 
@@ -15,13 +14,16 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
+#include <type_traits>
 #include <vector>
 
 using namespace fmhip;
 
 static_assert(FMHIP_RANGE_LEN == kRangeLen, "header and kernels disagree on the CSC range length");
 
-namespace {
+namespace fmhip {
+namespace host {
 
 thread_local std::string g_err;
 
@@ -35,142 +37,13 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
-#define HIP_TRY(expr)                                                                        \
-    do {                                                                                     \
-        hipError_t _e = (expr);                                                              \
-        if (_e != hipSuccess)                                                                \
-            return fail(_e == hipErrorOutOfMemory ? FMHIP_ERR_NOMEM : FMHIP_ERR_HIP,         \
-                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
-    } while (0)
+}  // namespace host
+}  // namespace fmhip
 
-#define TRY(expr)               \
-    do {                        \
-        int _r = (expr);        \
-        if (_r != FMHIP_OK) return _r; \
-    } while (0)
+using namespace fmhip::host;
 
-template <typename T>
-struct DevBuf {
-    T *p = nullptr;
-    size_t n = 0;
-    int alloc(size_t count) {
-        release();
-        if (count == 0) return FMHIP_OK;
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
-        if (e != hipSuccess) {
-            p = nullptr;
-            return fail(FMHIP_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
-        }
-        n = count;
-        return FMHIP_OK;
-    }
-    int ensure(size_t count) { return count <= n ? FMHIP_OK : alloc(count); }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        n = 0;
-    }
-    ~DevBuf() { release(); }
-};
-
-constexpr int64_t kAlsMaxNnz = (int64_t)1 << 27;
-
-struct BatchMeta {
-    int64_t row0 = 0, rows = 0;
-    int64_t nnz0 = 0;   // offset of the batch in the global CSR/CSC entry arrays
-    int32_t nnz = 0;
-    int32_t n_cols = 0;     // compressed columns (features present in the batch)
-    int64_t col_off = 0;    // offset into cfeat; cptr offset is col_off + batch index
-    int32_t n_ranges = 0;
-    int64_t range_off = 0;
-    int32_t n_split = 0;          // cut columns spanning > 8 ranges
-    int64_t split_off = 0;
-    int32_t n_split_short = 0;    // cut columns spanning <= 8 ranges
-    int64_t split_short_off = 0;
-    int32_t n_feats = 0;    // distinct features present (== n_cols unless the stream is row-blocked)
-    int32_t n_mp = 0;       // features cut into several pieces (one per row block they occur in)
-    int64_t mp_off = 0;     // offset into mp_feat; mp_ptr offset is mp_off + batch index
-    int32_t n_pieces = 0;   // piece rows those features need
-    int64_t nnz_total = 0;  // stored nonzeros of the batch incl. those held in the dense hot block
-    uint32_t hot_mask = 0;  // hot slots with at least one nonzero in this batch
-};
-
-struct ProfRec {
-    int kind;
-    hipEvent_t a, b;
-    int64_t nnz, rows;
-};
-
-}  // namespace
-
-struct fmhip_dataset {
-    int device = 0;
-    int64_t n_rows = 0, nnz = 0, dimension = 0, batch_rows = 0;
-    int64_t max_rows = 0;
-    int32_t max_ranges = 0;
-    std::vector<BatchMeta> batches;
-    DevBuf<int64_t> row_ptr;
-    DevBuf<int32_t> col;
-    DevBuf<float> val, y;
-    DevBuf<uint32_t> crow;
-    DevBuf<float> cval;
-    DevBuf<int32_t> row_order;   // per batch: its rows' local ids sorted by stored length, longest first (forward walk order)
-    DevBuf<int32_t> cfeat, cptr, range_seg, split_seg, split_short, cdst, mp_feat, mp_ptr;
-    std::vector<int32_t> h_cfeat, h_cptr, h_split, h_split_short;   // host copies (feature-chunked backward needs them)
-    int64_t rb_rows = 0;       // rows per row block of the transposes (0 = not row-blocked)
-    int32_t max_pieces = 0;
-    // dense hot block: the entries of the (up to kHotT) most frequent features are held as a dense
-    // [n_rows][kHotT] fp32 array instead of in the sparse streams (0 where the feature is absent)
-    int32_t hot_T = 0;                 // 0 = no hot block
-    std::vector<int32_t> hot_ids;      // [kHotT] feature id per slot, -1 = unused slot
-    DevBuf<float> xhot;
-    DevBuf<int32_t> d_hot_ids;
-    int64_t nnz_sparse = 0;
-    // fp64 copies of the values (CSR order, CSC order) and labels for the fp64 ALS learner; kept only
-    // for single-batch datasets of at most kAlsMaxNnz stored nonzeros
-    DevBuf<double> val64, cval64, y64;
-};
-
-struct fmhip_model {
-    int device = 0;
-    int64_t n = 0, n1 = 0, n1p = 0;
-    int32_t k = 0, Kp = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    DevBuf<float> V, w, w0;
-    DevBuf<float> grad_own;
-    float *grad = nullptr;        // packed gradient in use (own or bound)
-    bool grad_dirty = false;      // holds a gradient that has not been applied/zeroed
-    DevBuf<float> P, e, part, pieces, hot_part;
-    bool hot_pending = false;   // the dense hot block's gradient of the current step is still to be formed
-    DevBuf<double> acc;           // {sum e, sum e^2, rows, nonfinite}
-    DevBuf<double> bsum;          // k_forward's per-block statistic partials
-    int64_t last_nnz = 0, last_rows = 0;
-    int64_t bw_next_hi = -1;      // feature-chunked backward: the next interval must end here (-1: none pending)
-    // fp64 master copy of the parameters (reference layout): exact round trip of what the caller set,
-    // and the state the fp64 ALS learner trains; stale once an fp32 SGD step has run
-    std::vector<double> h_w, h_v;
-    double h_w0 = 0.0;
-    bool host64_fresh = false;
-    DevBuf<double> als_w0, als_w, als_v, als_e, als_q;
-    bool profiling = false;
-    bool prof_rotate = false;     // time one kernel kind per step, rotating
-    int64_t prof_step = 0;
-    std::vector<ProfRec> prof;
-
-    // packed gradient: [ scalars (kGradHead floats, 8 used) | G_w (n1p) | G_b (n1p) | pad | G_V (n1p*Kp) ]: the
-    // small head sits next to the G_V rows of the LOWEST feature ids, which the feature-chunked backward
-    // finishes last, so a data-parallel host moves head + last interval in one collective
-    size_t head_floats() const { return ((size_t)kGradHead + 2 * (size_t)n1p + 31) / 32 * 32; }
-    float *scal() const { return grad; }
-    float *Gw() const { return grad + kGradHead; }
-    float *Gb() const { return grad + kGradHead + n1p; }
-    float *GV() const { return grad + head_floats(); }
-    int32_t pack_k() const { return k < Kp ? k : -1; }   // packed rows: slot k of a V row holds w_i
-    size_t grad_floats() const { return head_floats() + (size_t)n1p * Kp; }
-};
-
-namespace {
+namespace fmhip {
+namespace host {
 
 struct ProfScope {
     fmhip_model *m;
@@ -265,23 +138,69 @@ int upload(DevBuf<T> &dst, const T *src, size_t n) {
     return FMHIP_OK;
 }
 
+// Host-side passes of the dataset build (validation, dense-hot-block split, forward row order, fp32
+// re-pack) run over row chunks on all host cores: they are what `DataSet.cache()` costs before the
+// device takes over (single-threaded they took 3.9 s for C4's 10 M rows).
+int host_threads(int64_t work_items) {
+    unsigned hc = std::thread::hardware_concurrency();
+    int64_t t = hc ? (int64_t)hc : 4;
+    if (const char *e = getenv("FMHIP_HOST_THREADS")) t = atoi(e);
+    t = std::min<int64_t>({t, 32, work_items / 65536 + 1});
+    return (int)std::max<int64_t>(t, 1);
+}
+
+// f(tid, lo, hi) over [0, n) cut into one contiguous chunk per thread
+template <class F>
+void parallel_chunks(int64_t n, int threads, F f) {
+    if (threads <= 1 || n <= 0) { f(0, (int64_t)0, n); return; }
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)threads);
+    for (int t = 0; t < threads; ++t) {
+        const int64_t lo = n * t / threads, hi = n * (t + 1) / threads;
+        pool.emplace_back([=]() { f(t, lo, hi); });
+    }
+    for (auto &th : pool) th.join();
+}
+
+// scoring = true: rows + labels only (FMModel.predict / Model.computeRMSE on held-out data,
+// S/driver.scala:100-112) — no transposes, no hot block, nothing a training step needs
 template <typename FT>
 int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const FT *val,
-                        const FT *y, int64_t batch_rows, fmhip_dataset_t *out) {
+                        const FT *y, int64_t batch_rows, bool scoring, fmhip_dataset_t *out) {
     if (!out) return fail(FMHIP_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (n_rows < 0) return fail(FMHIP_ERR_INVALID, "n_rows < 0");
     if (!row_ptr) return fail(FMHIP_ERR_INVALID, "row_ptr is NULL");
     if (row_ptr[0] != 0) return fail(FMHIP_ERR_INVALID, "row_ptr[0] must be 0");
-    for (int64_t r = 0; r < n_rows; ++r)
-        if (row_ptr[r + 1] < row_ptr[r]) return fail(FMHIP_ERR_INVALID, "row_ptr decreases at row %lld", (long long)r);
+    const int T = host_threads(n_rows);
+    {
+        std::vector<int64_t> bad((size_t)T, -1);
+        parallel_chunks(n_rows, T, [&](int t, int64_t lo, int64_t hi) {
+            for (int64_t r = lo; r < hi; ++r)
+                if (row_ptr[r + 1] < row_ptr[r]) { bad[(size_t)t] = r; break; }
+        });
+        for (int64_t r : bad)
+            if (r >= 0) return fail(FMHIP_ERR_INVALID, "row_ptr decreases at row %lld", (long long)r);
+    }
     const int64_t nnz = row_ptr[n_rows];
     if (nnz > 0 && (!col || !val)) return fail(FMHIP_ERR_INVALID, "col/val is NULL");
-    if (n_rows > 0 && !y) return fail(FMHIP_ERR_INVALID, "y is NULL");
+    if (n_rows > 0 && !y && !scoring) return fail(FMHIP_ERR_INVALID, "y is NULL");
     int32_t dim = 0;
-    for (int64_t p = 0; p < nnz; ++p) {
-        if (col[p] < 0) return fail(FMHIP_ERR_INVALID, "negative feature index at entry %lld", (long long)p);
-        dim = std::max(dim, col[p]);
+    {
+        const int Tn = host_threads(nnz);
+        std::vector<int64_t> bad((size_t)Tn, -1);
+        std::vector<int32_t> mx((size_t)Tn, 0);
+        parallel_chunks(nnz, Tn, [&](int t, int64_t lo, int64_t hi) {
+            int32_t m = 0;
+            for (int64_t p = lo; p < hi; ++p) {
+                if (col[p] < 0) { bad[(size_t)t] = p; break; }
+                m = std::max(m, col[p]);
+            }
+            mx[(size_t)t] = m;
+        });
+        for (int64_t p : bad)
+            if (p >= 0) return fail(FMHIP_ERR_INVALID, "negative feature index at entry %lld", (long long)p);
+        for (int32_t m : mx) dim = std::max(dim, m);
     }
     TRY(set_device(device));
     fmhip_dataset *d = new (std::nothrow) fmhip_dataset();
@@ -290,6 +209,8 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     d->n_rows = n_rows;
     d->nnz = nnz;
     d->dimension = dim;  // S/DataSet.scala:27-29
+    d->scoring_only = scoring;
+    if (scoring) batch_rows = 262144;   // bounds the forward's workspace; invisible to the caller
     if (batch_rows <= 0 || batch_rows > n_rows) batch_rows = std::max<int64_t>(n_rows, 1);
     d->batch_rows = batch_rows;
     const int64_t nb = n_rows > 0 ? (n_rows + batch_rows - 1) / batch_rows : 0;
@@ -303,59 +224,88 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     std::vector<float> sp_val, xhot;
     std::vector<uint32_t> hot_masks;
     bool split = false;
-    if (g_tune[kTuneHot] > 0 && nb > 1 && nnz > 0) {
-        std::vector<int64_t> cnt((size_t)dim + 1, 0);
-        for (int64_t p = 0; p < nnz; ++p) ++cnt[(size_t)col[p]];
+    if (g_tune[kTuneHot] > 0 && nb > 1 && nnz > 0 && !scoring) {
+        // Frequencies: exact for datasets of up to 8 M nonzeros; beyond that from every s-th row (the
+        // choice of hot features is a layout decision — any set that passes the checks below is valid —
+        // and a feature in >= 10 % of the rows cannot hide from a sample of millions of entries).
+        const int64_t stride = nnz > ((int64_t)8 << 20) ? std::max<int64_t>(1, nnz / ((int64_t)4 << 20)) : 1;
+        std::vector<int32_t> cnt((size_t)dim + 1, 0);
+        int64_t sampled_rows = 0;
+        for (int64_t r = 0; r < n_rows; r += stride, ++sampled_rows)
+            for (int64_t p = row_ptr[r]; p < row_ptr[r + 1]; ++p) ++cnt[(size_t)col[p]];
         std::vector<int32_t> cand;
         for (int32_t f = 0; f <= dim; ++f)
-            if (cnt[(size_t)f] * 10 >= n_rows) cand.push_back(f);
+            if ((int64_t)cnt[(size_t)f] * 10 >= sampled_rows) cand.push_back(f);
         std::sort(cand.begin(), cand.end(), [&](int32_t x, int32_t y) { return cnt[(size_t)x] != cnt[(size_t)y] ? cnt[(size_t)x] > cnt[(size_t)y] : x < y; });
         if (cand.size() > (size_t)kHotT) cand.resize(kHotT);
-        {
+        std::vector<int32_t>().swap(cnt);
+        std::vector<int8_t> slot((size_t)dim + 1, -1);
+        if (!cand.empty()) {
             // a candidate that occurs twice in one row, or is stored with an explicit zero, keeps the
             // sparse path (its G row must have exactly one writer)
-            std::vector<int8_t> cslot((size_t)dim + 1, -1);
-            for (size_t h = 0; h < cand.size(); ++h) cslot[(size_t)cand[h]] = (int8_t)h;
-            uint32_t bad = 0;
-            for (int64_t r = 0; r < n_rows; ++r) {
-                uint32_t seen = 0;
-                for (int64_t p = row_ptr[r]; p < row_ptr[r + 1]; ++p) {
-                    const int8_t h = cslot[(size_t)col[p]];
-                    if (h < 0) continue;
-                    if ((seen >> h & 1u) || (float)val[p] == 0.f) bad |= 1u << h;
-                    seen |= 1u << h;
+            for (size_t h = 0; h < cand.size(); ++h) slot[(size_t)cand[h]] = (int8_t)h;
+            std::vector<uint32_t> badv((size_t)T, 0u);
+            parallel_chunks(n_rows, T, [&](int t, int64_t lo, int64_t hi) {
+                uint32_t bad = 0;
+                for (int64_t r = lo; r < hi; ++r) {
+                    uint32_t seen = 0;
+                    for (int64_t p = row_ptr[r]; p < row_ptr[r + 1]; ++p) {
+                        const int8_t h = slot[(size_t)col[p]];
+                        if (h < 0) continue;
+                        if ((seen >> h & 1u) || (float)val[p] == 0.f) bad |= 1u << h;
+                        seen |= 1u << h;
+                    }
                 }
-            }
+                badv[(size_t)t] = bad;
+            });
+            uint32_t bad = 0;
+            for (uint32_t x : badv) bad |= x;
             std::vector<int32_t> ok;
-            for (size_t h = 0; h < cand.size(); ++h)
+            for (size_t h = 0; h < cand.size(); ++h) {
+                slot[(size_t)cand[h]] = -1;
                 if (!(bad >> h & 1u)) ok.push_back(cand[h]);
+            }
             cand.swap(ok);
         }
         if (cand.size() >= 2) {
             std::sort(cand.begin(), cand.end());
             d->hot_ids.assign(kHotT, -1);
-            std::vector<int8_t> slot((size_t)dim + 1, -1);
             for (size_t h = 0; h < cand.size(); ++h) { d->hot_ids[h] = cand[h]; slot[(size_t)cand[h]] = (int8_t)h; }
             xhot.assign((size_t)n_rows * kHotT, 0.f);
             sp_ptr.assign((size_t)n_rows + 1, 0);
-            sp_col.reserve((size_t)nnz);
-            sp_val.reserve((size_t)nnz);
             hot_masks.assign((size_t)nb, 0u);
-            for (int64_t r = 0; r < n_rows; ++r) {
-                uint32_t seen = 0;
-                for (int64_t p = row_ptr[r]; p < row_ptr[r + 1]; ++p) {
-                    const int8_t h = slot[(size_t)col[p]];
-                    if (h >= 0) {
-                        seen |= 1u << h;
-                        xhot[(size_t)r * kHotT + h] = (float)val[p];
-                    } else {
-                        sp_col.push_back(col[p]);
-                        sp_val.push_back((float)val[p]);
-                    }
+            // pass 1: sparse length of every row; pass 2 (after the prefix sum): fill
+            parallel_chunks(n_rows, T, [&](int, int64_t lo, int64_t hi) {
+                for (int64_t r = lo; r < hi; ++r) {
+                    int64_t keep = 0;
+                    for (int64_t p = row_ptr[r]; p < row_ptr[r + 1]; ++p) keep += slot[(size_t)col[p]] < 0;
+                    sp_ptr[(size_t)r + 1] = keep;
                 }
-                hot_masks[(size_t)(r / batch_rows)] |= seen;
-                sp_ptr[(size_t)r + 1] = (int64_t)sp_col.size();
-            }
+            });
+            for (int64_t r = 0; r < n_rows; ++r) sp_ptr[(size_t)r + 1] += sp_ptr[(size_t)r];
+            sp_col.resize((size_t)sp_ptr[(size_t)n_rows]);
+            sp_val.resize((size_t)sp_ptr[(size_t)n_rows]);
+            std::vector<std::vector<uint32_t>> tmask((size_t)T, std::vector<uint32_t>((size_t)nb, 0u));
+            parallel_chunks(n_rows, T, [&](int t, int64_t lo, int64_t hi) {
+                for (int64_t r = lo; r < hi; ++r) {
+                    uint32_t seen = 0;
+                    int64_t o = sp_ptr[(size_t)r];
+                    for (int64_t p = row_ptr[r]; p < row_ptr[r + 1]; ++p) {
+                        const int8_t h = slot[(size_t)col[p]];
+                        if (h >= 0) {
+                            seen |= 1u << h;
+                            xhot[(size_t)r * kHotT + h] = (float)val[p];
+                        } else {
+                            sp_col[(size_t)o] = col[p];
+                            sp_val[(size_t)o] = (float)val[p];
+                            ++o;
+                        }
+                    }
+                    tmask[(size_t)t][(size_t)(r / batch_rows)] |= seen;
+                }
+            });
+            for (const auto &tm : tmask)
+                for (int64_t b = 0; b < nb; ++b) hot_masks[(size_t)b] |= tm[(size_t)b];
             split = true;
             d->hot_T = kHotT;
         }
@@ -386,18 +336,21 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     // forward walk order of each batch: rows by (sparse) length, longest first, ties in row order
     {
         std::vector<int32_t> order((size_t)n_rows);
-        std::vector<int64_t> start;
-        for (const BatchMeta &bm : d->batches) {
-            int64_t maxlen = 0;
-            for (int64_t r = 0; r < bm.rows; ++r) maxlen = std::max(maxlen, row_ptr[bm.row0 + r + 1] - row_ptr[bm.row0 + r]);
-            start.assign((size_t)maxlen + 2, 0);
-            for (int64_t r = 0; r < bm.rows; ++r) ++start[(size_t)(maxlen - (row_ptr[bm.row0 + r + 1] - row_ptr[bm.row0 + r])) + 1];
-            for (size_t i = 1; i < start.size(); ++i) start[i] += start[i - 1];
-            for (int64_t r = 0; r < bm.rows; ++r) {
-                const size_t key = (size_t)(maxlen - (row_ptr[bm.row0 + r + 1] - row_ptr[bm.row0 + r]));
-                order[(size_t)(bm.row0 + start[key]++)] = (int32_t)r;
+        parallel_chunks(nb, std::min<int>(T, (int)std::max<int64_t>(nb, 1)), [&](int, int64_t blo, int64_t bhi) {
+            std::vector<int64_t> start;
+            for (int64_t b = blo; b < bhi; ++b) {
+                const BatchMeta &bm = d->batches[(size_t)b];
+                int64_t maxlen = 0;
+                for (int64_t r = 0; r < bm.rows; ++r) maxlen = std::max(maxlen, row_ptr[bm.row0 + r + 1] - row_ptr[bm.row0 + r]);
+                start.assign((size_t)maxlen + 2, 0);
+                for (int64_t r = 0; r < bm.rows; ++r) ++start[(size_t)(maxlen - (row_ptr[bm.row0 + r + 1] - row_ptr[bm.row0 + r])) + 1];
+                for (size_t i = 1; i < start.size(); ++i) start[i] += start[i - 1];
+                for (int64_t r = 0; r < bm.rows; ++r) {
+                    const size_t key = (size_t)(maxlen - (row_ptr[bm.row0 + r + 1] - row_ptr[bm.row0 + r]));
+                    order[(size_t)(bm.row0 + start[key]++)] = (int32_t)r;
+                }
             }
-        }
+        });
         const int rc0 = upload(d->row_order, order.data(), order.size());
         if (rc0) {
             delete d;
@@ -405,17 +358,35 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
         }
     }
     // fp32 copies of the streams (device arithmetic is fp32)
-    std::vector<float> valf((size_t)nnz_s), yf((size_t)n_rows);
-    for (int64_t p = 0; p < nnz_s; ++p) valf[(size_t)p] = split ? sp_val[(size_t)p] : (float)val[p];
-    for (int64_t r = 0; r < n_rows; ++r) yf[(size_t)r] = (float)y[r];
-    const bool keep64 = !split && nb == 1 && nnz <= kAlsMaxNnz;
+    std::vector<float> valf, yf((size_t)n_rows, 0.f);
+    const float *val_up = nullptr;
+    if (split) {
+        val_up = sp_val.data();
+    } else if (std::is_same<FT, float>::value) {
+        val_up = reinterpret_cast<const float *>(val);
+    } else {
+        valf.resize((size_t)nnz_s);
+        parallel_chunks(nnz_s, host_threads(nnz_s), [&](int, int64_t lo, int64_t hi) {
+            for (int64_t p = lo; p < hi; ++p) valf[(size_t)p] = (float)val[p];
+        });
+        val_up = valf.data();
+    }
+    if (y)
+        for (int64_t r = 0; r < n_rows; ++r) yf[(size_t)r] = (float)y[r];
+    const bool keep64 = !split && !scoring && nb == 1 && nnz <= kAlsMaxNnz;
     int rc = FMHIP_OK;
     if ((rc = upload(d->row_ptr, row_ptr, (size_t)n_rows + 1)) || (rc = upload(d->col, col, (size_t)nnz_s)) ||
-        (rc = upload(d->val, valf.data(), (size_t)nnz_s)) || (rc = upload(d->y, yf.data(), (size_t)n_rows)) ||
-        (rc = d->crow.alloc((size_t)nnz_s)) || (rc = d->cval.alloc((size_t)nnz_s)) ||
+        (rc = upload(d->val, val_up, (size_t)nnz_s)) || (rc = upload(d->y, yf.data(), (size_t)n_rows)) ||
+        (!scoring && ((rc = d->crow.alloc((size_t)nnz_s)) || (rc = d->cval.alloc((size_t)nnz_s)))) ||
         (split && ((rc = upload(d->xhot, xhot.data(), xhot.size())) || (rc = upload(d->d_hot_ids, d->hot_ids.data(), d->hot_ids.size()))))) {
         delete d;
         return rc;
+    }
+    std::vector<float>().swap(valf);
+    std::vector<float>().swap(xhot);
+    if (scoring) {
+        *out = d;
+        return FMHIP_OK;
     }
     if (keep64) {
         std::vector<double> val64((size_t)nnz), y64((size_t)n_rows);
@@ -545,6 +516,14 @@ int check_pair(fmhip_model_t m, fmhip_dataset_t d) {
     return set_device(m->device);
 }
 
+// training calls need the transposes a scoring-only dataset does not have
+int check_train(fmhip_model_t m, fmhip_dataset_t d) {
+    TRY(check_pair(m, d));
+    if (d->scoring_only)
+        return fail(FMHIP_ERR_UNSUPPORTED, "dataset was created with fmhip_rows_create (scoring only): it has no transposes to train on");
+    return FMHIP_OK;
+}
+
 int check_batch(fmhip_dataset_t d, int64_t batch) {
     if (batch < 0 || batch >= (int64_t)d->batches.size())
         return fail(FMHIP_ERR_INVALID, "batch %lld out of range [0, %zu)", (long long)batch, d->batches.size());
@@ -561,18 +540,6 @@ int ensure_workspace(fmhip_model_t m, fmhip_dataset_t d) {
     return FMHIP_OK;
 }
 
-// number of per-block statistic partials the forward launch writes: must mirror the kernel choice
-// made by launch_forward (packed rows -> plain kernel; the LDS V-tile needs a 32-bit view of V)
-int fwd_partials(fmhip_model_t m, int64_t rows) {
-    const uint64_t vb = (uint64_t)m->n1p * m->Kp * sizeof(float);
-    int var = g_tune[kTuneFwd];
-    if (m->pack_k() >= 0) var = 0;
-    if (var == 20 && vb >= 0xffffffffull) var = 0;
-    if (var == 20) return forward_blocks_lds(rows);
-    if (var == 60) return forward_blocks_wt(m->Kp, rows);
-    return forward_blocks(m->Kp, rows);
-}
-
 FwdArgs fwd_args(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm) {
     FwdArgs a{};
     a.row_ptr = d->row_ptr.p;
@@ -581,9 +548,13 @@ FwdArgs fwd_args(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm) {
     a.y = d->y.p;
     a.V = m->V.p;
     {
+        // tables of 4 GiB and more do not fit a 32-bit buffer view and take the flat-address kernels
+        // (fmhip_tune key 8 forces those for any size, so that tests reach them on small inputs)
         const uint64_t vb = (uint64_t)m->n1p * m->Kp * sizeof(float);
-        a.v_bytes = vb < 0xffffffffull ? (uint32_t)vb : 0u;
+        a.v_bytes = (vb < 0xffffffffull && !g_tune[kTuneFlat]) ? (uint32_t)vb : 0u;
     }
+    a.sv = (float)m->sv;
+    a.sw = (float)m->sw;
     a.w = m->w.p;
     a.w0 = m->w0.p;
     a.row0 = bm.row0;
@@ -635,7 +606,7 @@ BwdArgs bwd_args(fmhip_model_t m, fmhip_dataset_t d, int64_t b) {
     a.P = m->P.p;
     {
         const uint64_t pb = (uint64_t)bm.rows * m->Kp * sizeof(float);
-        a.p_bytes = pb < 0xffffffffull ? (uint32_t)pb : 0u;
+        a.p_bytes = (pb < 0xffffffffull && !g_tune[kTuneFlat]) ? (uint32_t)pb : 0u;
     }
     a.e = m->e.p;
     a.GV = m->GV();
@@ -655,7 +626,7 @@ int step_forward(fmhip_model_t m, fmhip_dataset_t d, int64_t b) {
     }
     {
         ProfScope ps(m, FMHIP_K_FORWARD, bm.nnz_total, bm.rows);
-        HIP_TRY(launch_forward(m->Kp, kFwdTrain, fwd_args(m, d, bm), m->stream));
+        HIP_TRY(launch_forward(m->Kp, kFwdTrain, fwd_args(m, d, bm), m->stream, &m->fwd_parts));
     }
     m->grad_dirty = true;
     m->last_nnz = bm.nnz_total;
@@ -703,7 +674,7 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
     if (whole) {   // the common case needs no host-side searches
         if (finish) {
             ba.red_bsum = m->bsum.p;
-            ba.red_nblocks = fwd_partials(m, bm.rows);
+            ba.red_nblocks = m->fwd_parts;
             ba.red_rows = (int32_t)bm.rows;
             ba.red_scal = m->scal();
             ba.red_acc = acc;
@@ -739,7 +710,7 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
     }
     if (finish) {
         ba.red_bsum = m->bsum.p;
-        ba.red_nblocks = fwd_partials(m, bm.rows);
+        ba.red_nblocks = m->fwd_parts;
         ba.red_rows = (int32_t)bm.rows;
         ba.red_scal = m->scal();
         ba.red_acc = acc;
@@ -762,21 +733,39 @@ int step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double *acc) {
     return step_backward(m, d, b, 0, INT64_MAX, true, acc);
 }
 
-// `d`/`b` given: the gradient in the buffer is exactly batch b's (no exchange happened), so with no
-// weight decay the update may be restricted to the rows that batch touched
-int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double regv, fmhip_dataset_t d = nullptr,
-               int64_t b = -1) {
+// brings lazily decayed tables back to scale 1 (dense pass)
+int fold_scales(fmhip_model_t m) {
+    if (m->sv == 1.0 && m->sw == 1.0) return FMHIP_OK;
+    HIP_TRY(launch_rescale(m->Kp, m->V.p, m->w.p, m->n1, m->pack_k(), (float)m->sv, (float)m->sw, m->stream));
+    m->sv = m->sw = 1.0;
+    return FMHIP_OK;
+}
+
+// `d`/`b` given: the gradient in the buffer is exactly batch b's (no exchange happened), so the update
+// may be restricted to the rows that batch touched — their decay, and everyone else's, rides in the
+// tables' scale (lazy weight decay, fm_apply.hip).  Otherwise the dense pass, which also folds a pending
+// scale back to 1.
+int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double regv, fmhip_dataset_t d, int64_t b) {
     ApplyArgs a{};
-    if (d && b >= 0 && regw == 0.0 && regv == 0.0 && d->rb_rows == 0) {
+    a.sv_in = (float)m->sv;
+    a.sw_in = (float)m->sw;
+    double sv_out = 1.0, sw_out = 1.0;
+    const double dv = 1.0 - eta * regv, dw = 1.0 - eta * regw;
+    const bool decay = regw != 0.0 || regv != 0.0;
+    if (d && b >= 0 && d->rb_rows == 0 && (!decay || (g_tune[kTuneLazy] && dv >= 0.5 && dw >= 0.5 && dv <= 1.0 && dw <= 1.0))) {
         const BatchMeta &bm = d->batches[(size_t)b];
         const int64_t touched = (int64_t)bm.n_cols + (d->hot_T ? kHotT : 0);
-        if (touched * 4 <= m->n1) {     // otherwise the dense, perfectly coalesced pass is as cheap
+        if (touched * 2 <= m->n1) {     // otherwise the dense, perfectly coalesced pass is as cheap
             a.feat = d->cfeat.p + bm.col_off;
             a.n_feat = bm.n_cols;
             a.hot_ids = d->d_hot_ids.p;
             a.n_hot = d->hot_T ? kHotT : 0;
+            sv_out = m->sv * dv;
+            sw_out = m->sw * dw;
         }
     }
+    a.eta_v = (float)(eta / sv_out);
+    a.eta_w = (float)(eta / sw_out);
     a.V = m->V.p;
     a.w = m->w.p;
     a.w0 = m->w0.p;
@@ -794,6 +783,10 @@ int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double reg
         ProfScope ps(m, FMHIP_K_APPLY, m->last_nnz, m->last_rows);
         HIP_TRY(launch_apply(m->Kp, a, m->stream));
     }
+    m->sv = sv_out;
+    m->sw = sw_out;
+    // fp32 tables lose nothing to a small scale until their values approach the denormal range; fold long before
+    if (m->sv < 0x1p-24 || m->sw < 0x1p-24) TRY(fold_scales(m));
     m->grad_dirty = false;
     m->host64_fresh = false;
     ++m->prof_step;
@@ -839,6 +832,7 @@ int set_params_impl(fmhip_model_t m, FT w0, const FT *w, const FT *v) {
     for (int64_t i = 0; i < m->n1; ++i) m->h_w[(size_t)i] = (double)w[i];
     for (int64_t j = 0; j < m->n1 * m->k; ++j) m->h_v[(size_t)j] = (double)v[j];
     m->host64_fresh = true;
+    m->sv = m->sw = 1.0;
     HIP_TRY(hipMemcpyAsync(m->V.p, hV.data(), hV.size() * sizeof(float), hipMemcpyHostToDevice, m->stream));
     HIP_TRY(hipMemcpyAsync(m->w.p, hw.data(), hw.size() * sizeof(float), hipMemcpyHostToDevice, m->stream));
     HIP_TRY(hipMemcpyAsync(m->w0.p, &hw0, sizeof(float), hipMemcpyHostToDevice, m->stream));
@@ -863,15 +857,17 @@ int get_params_impl(fmhip_model_t m, FT *w0, FT *w, FT *v) {
     HIP_TRY(hipMemcpyAsync(&hw0, m->w0.p, sizeof(float), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
     if (w0) *w0 = (FT)hw0;
+    // a lazily decayed model stores U with V = sv*U (fm_apply.hip); with sv = sw = 1 the products are exact
     for (int64_t i = 0; i < m->n1; ++i) {
-        if (w) w[i] = (FT)(m->pack_k() >= 0 ? hV[(size_t)i * m->Kp + m->k] : hw[(size_t)i]);
+        if (w) w[i] = (FT)((double)(m->pack_k() >= 0 ? hV[(size_t)i * m->Kp + m->k] : hw[(size_t)i]) * m->sw);
         if (v)
-            for (int f = 0; f < m->k; ++f) v[f + i * (int64_t)m->k] = (FT)hV[(size_t)i * m->Kp + f];
+            for (int f = 0; f < m->k; ++f) v[f + i * (int64_t)m->k] = (FT)((double)hV[(size_t)i * m->Kp + f] * m->sv);
     }
     return FMHIP_OK;
 }
 
-}  // namespace
+}  // namespace host
+}  // namespace fmhip
 
 // =================================================================== C ABI
 
@@ -964,6 +960,18 @@ int fmhip_model_info(fmhip_model_t m, int64_t *num_attribute, int32_t *num_facto
     return FMHIP_OK;
 }
 
+int fmhip_model_init_normal(fmhip_model_t m, uint64_t seed, double mean, double stdev) {
+    if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
+    TRY(set_device(m->device));
+    HIP_TRY(launch_init_normal(m->Kp, m->V.p, m->w.p, m->w0.p, m->n1, m->n1p, m->k, seed, (float)mean, (float)stdev, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    m->sv = m->sw = 1.0;
+    m->host64_fresh = false;     // the device holds the parameters; the fp64 masters are refreshed on demand
+    std::vector<double>().swap(m->h_w);
+    std::vector<double>().swap(m->h_v);
+    return FMHIP_OK;
+}
+
 int fmhip_model_set_params(fmhip_model_t m, double w0, const double *w, const double *v) { return set_params_impl<double>(m, w0, w, v); }
 int fmhip_model_get_params(fmhip_model_t m, double *w0, double *w, double *v) { return get_params_impl<double>(m, w0, w, v); }
 int fmhip_model_set_params_f32(fmhip_model_t m, float w0, const float *w, const float *v) { return set_params_impl<float>(m, w0, w, v); }
@@ -978,12 +986,22 @@ int fmhip_synchronize(fmhip_model_t m) {
 
 int fmhip_dataset_create(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const double *val,
                          const double *y, int64_t batch_rows, fmhip_dataset_t *out) {
-    return dataset_create_impl<double>(device, n_rows, row_ptr, col, val, y, batch_rows, out);
+    return dataset_create_impl<double>(device, n_rows, row_ptr, col, val, y, batch_rows, false, out);
+}
+
+int fmhip_rows_create(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const double *val,
+                      const double *y, fmhip_dataset_t *out) {
+    return dataset_create_impl<double>(device, n_rows, row_ptr, col, val, y, 0, true, out);
+}
+
+int fmhip_rows_create_f32(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const float *val,
+                          const float *y, fmhip_dataset_t *out) {
+    return dataset_create_impl<float>(device, n_rows, row_ptr, col, val, y, 0, true, out);
 }
 
 int fmhip_dataset_create_f32(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const float *val,
                              const float *y, int64_t batch_rows, fmhip_dataset_t *out) {
-    return dataset_create_impl<float>(device, n_rows, row_ptr, col, val, y, batch_rows, out);
+    return dataset_create_impl<float>(device, n_rows, row_ptr, col, val, y, batch_rows, false, out);
 }
 
 int fmhip_dataset_destroy(fmhip_dataset_t d) {
@@ -1020,6 +1038,7 @@ int fmhip_dataset_get_transpose(fmhip_dataset_t d, int64_t batch, int32_t *feat,
                                 float *vals) {
     if (!d) return fail(FMHIP_ERR_INVALID, "dataset is NULL");
     TRY(check_batch(d, batch));
+    if (d->scoring_only) return fail(FMHIP_ERR_UNSUPPORTED, "a scoring-only dataset has no transposes");
     TRY(set_device(d->device));
     const BatchMeta &bm = d->batches[(size_t)batch];
     // read the stream back and merge the pieces of a feature (one per row block, in row-block = row
@@ -1092,8 +1111,9 @@ static int score_pass(fmhip_model_t m, fmhip_dataset_t d, double *yhat, double *
         const BatchMeta &bm = d->batches[b];
         FwdArgs a = fwd_args(m, d, bm);
         a.yhat = dy.p;
-        HIP_TRY(launch_forward(m->Kp, q_out ? kFwdQ : kFwdResidual, a, m->stream));
-        HIP_TRY(launch_reduce_blocks(m->bsum.p, fwd_partials(m, bm.rows), (int32_t)bm.rows, nullptr, m->acc.p, m->stream));
+        int parts = 0;
+        HIP_TRY(launch_forward(m->Kp, q_out ? kFwdQ : kFwdResidual, a, m->stream, &parts));
+        HIP_TRY(launch_reduce_blocks(m->bsum.p, parts, (int32_t)bm.rows, nullptr, m->acc.p, m->stream));
         if (yhat || e_out) {
             hbuf.resize((size_t)bm.rows);
             if (yhat) {
@@ -1128,6 +1148,17 @@ int fmhip_predict(fmhip_model_t m, fmhip_dataset_t d, double *yhat) {
     return score_pass(m, d, yhat, nullptr, nullptr, nullptr);
 }
 
+int fmhip_predict_rows(fmhip_model_t m, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const double *val,
+                       double *yhat) {
+    if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
+    if (n_rows > 0 && !yhat) return fail(FMHIP_ERR_INVALID, "yhat is NULL");
+    fmhip_dataset_t d = nullptr;
+    TRY(dataset_create_impl<double>(m->device, n_rows, row_ptr, col, val, nullptr, 0, true, &d));
+    const int rc = n_rows > 0 ? score_pass(m, d, yhat, nullptr, nullptr, nullptr) : FMHIP_OK;
+    fmhip_dataset_destroy(d);
+    return rc;
+}
+
 int fmhip_residual(fmhip_model_t m, fmhip_dataset_t d, double *e) {
     if (!e) return fail(FMHIP_ERR_INVALID, "e is NULL");
     return score_pass(m, d, nullptr, e, nullptr, nullptr);
@@ -1152,7 +1183,7 @@ int fmhip_rmse(fmhip_model_t m, fmhip_dataset_t d, double *rmse, fmhip_stats *st
 
 int fmhip_sgd_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double eta, double reg0, double regw,
                    double regv, fmhip_stats *stats) {
-    TRY(check_pair(m, d));
+    TRY(check_train(m, d));
     TRY(check_batch(d, batch));
     TRY(step_compute(m, d, batch, nullptr));
     if (stats) {
@@ -1166,7 +1197,7 @@ int fmhip_sgd_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double eta
 
 int fmhip_sgd_epoch(fmhip_model_t m, fmhip_dataset_t d, double eta, double reg0, double regw, double regv,
                     const int64_t *order, fmhip_stats *stats) {
-    TRY(check_pair(m, d));
+    TRY(check_train(m, d));
     const int64_t nb = (int64_t)d->batches.size();
     if (order)
         for (int64_t j = 0; j < nb; ++j) TRY(check_batch(d, order[j]));
@@ -1187,7 +1218,7 @@ int fmhip_sgd_epoch(fmhip_model_t m, fmhip_dataset_t d, double eta, double reg0,
 
 int fmhip_batch_grad(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double *gv, double *gw, double *gw0,
                      fmhip_stats *stats) {
-    TRY(check_pair(m, d));
+    TRY(check_train(m, d));
     TRY(check_batch(d, batch));
     TRY(step_compute(m, d, batch, nullptr));
     std::vector<float> hG(m->grad_floats()), hV((size_t)m->n1p * m->Kp);
@@ -1201,7 +1232,7 @@ int fmhip_batch_grad(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double *
         if (gw) gw[i] = m->pack_k() >= 0 ? GV[(size_t)i * m->Kp + m->k] : Gw[i];
         if (gv)
             for (int f = 0; f < m->k; ++f)
-                gv[f + i * (int64_t)m->k] = (double)GV[(size_t)i * m->Kp + f] - (double)hV[(size_t)i * m->Kp + f] * (double)Gb[i];
+                gv[f + i * (int64_t)m->k] = (double)GV[(size_t)i * m->Kp + f] - (double)hV[(size_t)i * m->Kp + f] * m->sv * (double)Gb[i];
     }
     if (gw0) *gw0 = sc[0];
     if (stats) {
@@ -1218,7 +1249,7 @@ int fmhip_batch_grad(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double *
 // ---- ALS (the reference's own learner), fp64
 
 int fmhip_als_epoch(fmhip_model_t m, fmhip_dataset_t d, double reg0, double regw, double regv) {
-    TRY(check_pair(m, d));
+    TRY(check_train(m, d));
     if (d->batches.size() > 1 || (d->nnz > 0 && !d->val64.p))
         return fail(FMHIP_ERR_UNSUPPORTED, "ALS walks the whole-dataset transpose: create the dataset with batch_rows <= 0 "
                                            "(single batch, at most 2^27 stored nonzeros)");
@@ -1299,19 +1330,19 @@ int fmhip_grad_ptr(fmhip_model_t m, void **device_ptr) {
 }
 
 int fmhip_step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t batch) {
-    TRY(check_pair(m, d));
+    TRY(check_train(m, d));
     TRY(check_batch(d, batch));
     return step_compute(m, d, batch, nullptr);
 }
 
 int fmhip_step_forward(fmhip_model_t m, fmhip_dataset_t d, int64_t batch) {
-    TRY(check_pair(m, d));
+    TRY(check_train(m, d));
     TRY(check_batch(d, batch));
     return step_forward(m, d, batch);
 }
 
 int fmhip_step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, int64_t feat_lo, int64_t feat_hi, int finish) {
-    TRY(check_pair(m, d));
+    TRY(check_train(m, d));
     TRY(check_batch(d, batch));
     if (feat_lo < 0 || feat_hi < feat_lo) return fail(FMHIP_ERR_INVALID, "bad feature interval [%lld, %lld)", (long long)feat_lo, (long long)feat_hi);
     // intervals must come in DESCENDING order and tile [0, n+1): a range straddling two intervals is

@@ -1,0 +1,356 @@
+// fmhip_comm.hip — the data-parallel step of libfmhip.so: rows sharded over one process per GPU, the
+// packed gradient summed across ranks with RCCL (xGMI on an MI355X node) INSIDE the library.
+//
+// The reference's learner does its own reduction inside `learn` — `error.reduce(_+_)`
+// (S/fm/lib/ALS.scala:153), `collectAsMap` (:34, :139) — and the driver just calls
+// `fm = fml.learn(fm, dataset)` (S/fm/impl/FactorizationMachines.scala:45).  Same here: a JVM-side
+// `HipSGD.learn` on N GPUs calls fmhip_dp_epoch on every rank; the exchange is not its business.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1), not at link time: single-GPU users never load it,
+// and inside a process that already carries a copy (PyTorch bundles one under the same soname) the
+// loader hands back that copy instead of a second runtime.
+//
+// Schedule of one step (two streams, no host synchronisation):
+//   compute stream  forward | backward(cold ids) | backward(hot ids) + statistics |      wait | apply
+//   comm stream                                  | all-reduce(cold slice)         | all-reduce(head + hot slice)
+// The CSC stream is sorted by feature id, so the backward can deliver the gradient rows of an interval of
+// ids at a time; the cold interval is nearly all of the gradient's volume and under half of the work.
+#include "fmhip_internal.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+
+using namespace fmhip;
+using namespace fmhip::host;
+
+static_assert(sizeof(ncclUniqueId) == FMHIP_UNIQUE_ID_BYTES, "fmhip.h and RCCL disagree on the unique-id size");
+
+namespace {
+
+struct Rccl {
+    void *handle = nullptr;
+    std::string why;    // why loading failed
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {getenv("FMHIP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            if (!n || !*n) continue;
+            r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (r.handle) break;
+            r.why = dlerror();
+        }
+        if (!r.handle) return;
+        bool ok = true;
+        auto sym = [&](const char *name) {
+            void *p = dlsym(r.handle, name);
+            if (!p) { ok = false; r.why = std::string("missing symbol ") + name; }
+            return p;
+        };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+        r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!ok) {
+            dlclose(r.handle);
+            r.handle = nullptr;
+        }
+    });
+    return r;
+}
+
+int need_rccl() {
+    Rccl &r = rccl();
+    if (!r.handle) return fail(FMHIP_ERR_COMM, "RCCL could not be loaded (librccl.so.1): %s", r.why.c_str());
+    return FMHIP_OK;
+}
+
+#define NCCL_TRY(expr)                                                                                      \
+    do {                                                                                                    \
+        ncclResult_t _r = (expr);                                                                           \
+        if (_r != ncclSuccess)                                                                              \
+            return fail(FMHIP_ERR_COMM, "%s failed: %s (%s:%d)", #expr, rccl().GetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
+
+struct CommProf {
+    hipEvent_t wait_a = nullptr, wait_b = nullptr;   // compute stream: around its wait for the last collective
+    hipEvent_t c0[2] = {nullptr, nullptr}, c1[2] = {nullptr, nullptr};   // comm stream: around each collective
+    int n_coll = 0;
+};
+
+}  // namespace
+
+struct fmhip_comm {
+    int device = 0, rank = 0, world = 1;
+    ncclComm_t comm = nullptr;
+    hipStream_t cs = nullptr;                 // the collectives' stream
+    hipEvent_t ev_cold = nullptr, ev_hot = nullptr, ev_done = nullptr;
+    int64_t cut = 0;                          // feature id cutting the backward in two (0 = whole backward, one collective)
+    int64_t *scratch = nullptr;               // device int64[2] for the small control collectives
+    bool profiling = false;
+    std::vector<CommProf> prof;
+    int64_t prof_bytes = 0;
+};
+
+namespace {
+
+void destroy_events(CommProf &p) {
+    for (hipEvent_t e : {p.wait_a, p.wait_b, p.c0[0], p.c0[1], p.c1[0], p.c1[1]})
+        if (e) (void)hipEventDestroy(e);
+}
+
+int check_comm(fmhip_model_t m, fmhip_comm_t c) {
+    if (!m || !c) return fail(FMHIP_ERR_INVALID, "model or communicator is NULL");
+    if (m->device != c->device) return fail(FMHIP_ERR_INVALID, "model on device %d, communicator on device %d", m->device, c->device);
+    return set_device(m->device);
+}
+
+// one collective on the comm stream behind `after` (an event of the compute stream)
+int reduce_slice(fmhip_model_t m, fmhip_comm_t c, float *buf, size_t count, hipEvent_t after, CommProf *pr) {
+    HIP_TRY(hipEventRecord(after, m->stream));
+    HIP_TRY(hipStreamWaitEvent(c->cs, after, 0));
+    if (pr) {
+        const int i = pr->n_coll++;
+        HIP_TRY(hipEventCreate(&pr->c0[i]));
+        HIP_TRY(hipEventCreate(&pr->c1[i]));
+        HIP_TRY(hipEventRecord(pr->c0[i], c->cs));
+        NCCL_TRY(rccl().AllReduce(buf, buf, count, ncclFloat, ncclSum, c->comm, c->cs));
+        HIP_TRY(hipEventRecord(pr->c1[i], c->cs));
+    } else {
+        NCCL_TRY(rccl().AllReduce(buf, buf, count, ncclFloat, ncclSum, c->comm, c->cs));
+    }
+    c->prof_bytes += c->profiling ? (int64_t)(count * sizeof(float)) : 0;
+    return FMHIP_OK;
+}
+
+int dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0, double regw, double regv) {
+    const bool live = batch >= 0;
+    if (live) {
+        TRY(step_forward(m, d, batch));
+    } else {
+        // out of rows: contribute zeros (row count 0 included)
+        HIP_TRY(hipMemsetAsync(m->grad, 0, m->grad_floats() * sizeof(float), m->stream));
+        m->grad_dirty = true;
+        m->last_nnz = m->last_rows = 0;
+    }
+    CommProf *pr = nullptr;
+    if (c->profiling) {
+        c->prof.emplace_back();
+        pr = &c->prof.back();
+    }
+    const int64_t cut = (c->cut > 0 && c->cut < m->n1 && d->rb_rows == 0) ? c->cut : 0;
+    if (cut > 0) {
+        if (live) TRY(step_backward(m, d, batch, cut, m->n1, false, nullptr));
+        TRY(reduce_slice(m, c, m->GV() + (size_t)cut * m->Kp, (size_t)(m->n1p - cut) * m->Kp, c->ev_cold, pr));
+        if (live) TRY(step_backward(m, d, batch, 0, cut, true, nullptr));
+        // the head (scalars | G_w | G_b) lies right in front of feature 0's row: one message with the hot interval
+        TRY(reduce_slice(m, c, m->grad, m->head_floats() + (size_t)cut * m->Kp, c->ev_hot, pr));
+    } else {
+        if (live) TRY(step_backward(m, d, batch, 0, INT64_MAX, true, nullptr));
+        TRY(reduce_slice(m, c, m->grad, m->grad_floats(), c->ev_hot, pr));
+    }
+    m->bw_next_hi = -1;
+    HIP_TRY(hipEventRecord(c->ev_done, c->cs));
+    if (pr) {
+        HIP_TRY(hipEventCreate(&pr->wait_a));
+        HIP_TRY(hipEventCreate(&pr->wait_b));
+        HIP_TRY(hipEventRecord(pr->wait_a, m->stream));
+    }
+    HIP_TRY(hipStreamWaitEvent(m->stream, c->ev_done, 0));
+    if (pr) HIP_TRY(hipEventRecord(pr->wait_b, m->stream));
+    return step_apply(m, eta, reg0, regw, regv);   // dense: after the exchange every row may carry a gradient
+}
+
+// small control collectives (a count, a cut) through a device scratch word
+int control_i64(fmhip_model_t m, fmhip_comm_t c, int64_t *value, bool broadcast_from_0) {
+    HIP_TRY(hipMemcpyAsync(c->scratch, value, sizeof(int64_t), hipMemcpyHostToDevice, m->stream));
+    if (broadcast_from_0) NCCL_TRY(rccl().Broadcast(c->scratch, c->scratch, 1, ncclInt64, 0, c->comm, m->stream));
+    else NCCL_TRY(rccl().AllReduce(c->scratch, c->scratch, 1, ncclInt64, ncclMax, c->comm, m->stream));
+    HIP_TRY(hipMemcpyAsync(value, c->scratch, sizeof(int64_t), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return FMHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fmhip_comm_unique_id(void *id) {
+    if (!id) return fail(FMHIP_ERR_INVALID, "id is NULL");
+    TRY(need_rccl());
+    ncclUniqueId u;
+    NCCL_TRY(rccl().GetUniqueId(&u));
+    memcpy(id, &u, sizeof u);
+    return FMHIP_OK;
+}
+
+int fmhip_comm_create(fmhip_model_t m, const void *id, int rank, int world, fmhip_comm_t *out) {
+    if (!out) return fail(FMHIP_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!m || !id) return fail(FMHIP_ERR_INVALID, "model or id is NULL");
+    if (world < 1 || rank < 0 || rank >= world) return fail(FMHIP_ERR_INVALID, "rank %d outside a world of %d", rank, world);
+    TRY(need_rccl());
+    TRY(set_device(m->device));
+    fmhip_comm *c = new (std::nothrow) fmhip_comm();
+    if (!c) return fail(FMHIP_ERR_NOMEM, "out of host memory");
+    c->device = m->device;
+    c->rank = rank;
+    c->world = world;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    ncclResult_t r = rccl().CommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return fail(FMHIP_ERR_COMM, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, rccl().GetErrorString(r));
+    }
+    hipError_t e = hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_cold, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_hot, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->scratch), 2 * sizeof(int64_t));
+    if (e != hipSuccess) {
+        fmhip_comm_destroy(c);
+        return fail(FMHIP_ERR_HIP, "communicator resources: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return FMHIP_OK;
+}
+
+int fmhip_comm_destroy(fmhip_comm_t c) {
+    if (!c) return FMHIP_OK;
+    (void)hipSetDevice(c->device);
+    if (c->cs) (void)hipStreamSynchronize(c->cs);
+    for (auto &p : c->prof) destroy_events(p);
+    if (c->comm) (void)rccl().CommDestroy(c->comm);
+    for (hipEvent_t e : {c->ev_cold, c->ev_hot, c->ev_done})
+        if (e) (void)hipEventDestroy(e);
+    if (c->cs) (void)hipStreamDestroy(c->cs);
+    if (c->scratch) (void)hipFree(c->scratch);
+    delete c;
+    return FMHIP_OK;
+}
+
+int fmhip_comm_info(fmhip_comm_t c, int *rank, int *world) {
+    if (!c) return fail(FMHIP_ERR_INVALID, "communicator is NULL");
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    return FMHIP_OK;
+}
+
+int fmhip_dp_plan(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double upper_fraction, int64_t *cut_out) {
+    TRY(check_comm(m, c));
+    TRY(check_train(m, d));
+    int64_t cut = 0;
+    if (c->rank == 0 && upper_fraction > 0.0 && upper_fraction < 1.0 && d->rb_rows == 0) {
+        // stored nonzeros per feature over this rank's batches (the sparse streams: the dense hot block's
+        // features do not depend on the interval), then the id above which `upper_fraction` of them lie
+        std::vector<int32_t> cnt((size_t)m->n1, 0);
+        int64_t total = 0;
+        for (size_t b = 0; b < d->batches.size(); ++b) {
+            const auto &bm = d->batches[b];
+            const int32_t *hf = d->h_cfeat.data() + bm.col_off, *hp = d->h_cptr.data() + bm.col_off + b;
+            for (int32_t s = 0; s < bm.n_cols; ++s) {
+                cnt[(size_t)hf[s]] += hp[s + 1] - hp[s];
+                total += hp[s + 1] - hp[s];
+            }
+        }
+        const double want = upper_fraction * (double)total;
+        int64_t above = 0;
+        for (int64_t f = m->n1 - 1; f > 0; --f) {
+            above += cnt[(size_t)f];
+            if ((double)above >= want) { cut = f; break; }
+        }
+    }
+    TRY(control_i64(m, c, &cut, true));
+    c->cut = (cut > 0 && cut < m->n1) ? cut : 0;
+    if (cut_out) *cut_out = c->cut;
+    return FMHIP_OK;
+}
+
+int fmhip_dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0, double regw,
+                  double regv) {
+    TRY(check_comm(m, c));
+    TRY(check_train(m, d));
+    if (batch >= 0) TRY(check_batch(d, batch));
+    return dp_step(m, d, batch, c, eta, reg0, regw, regv);
+}
+
+int fmhip_dp_epoch(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double eta, double reg0, double regw, double regv,
+                   fmhip_stats *stats) {
+    TRY(check_comm(m, c));
+    TRY(check_train(m, d));
+    const int64_t nb = (int64_t)d->batches.size();
+    int64_t steps = nb;     // every rank takes the same number of steps: the largest local batch count
+    TRY(control_i64(m, c, &steps, false));
+    for (int64_t j = 0; j < steps; ++j) TRY(dp_step(m, d, j < nb ? j : -1, c, eta, reg0, regw, regv));
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        TRY(read_scal(m, stats));      // all-reduced: the global batch's sums
+        stats->nnz = m->last_nnz;
+        stats->steps = steps;
+    }
+    return FMHIP_OK;
+}
+
+int fmhip_comm_profile_begin(fmhip_comm_t c) {
+    if (!c) return fail(FMHIP_ERR_INVALID, "communicator is NULL");
+    for (auto &p : c->prof) destroy_events(p);
+    c->prof.clear();
+    c->prof_bytes = 0;
+    c->profiling = true;
+    return FMHIP_OK;
+}
+
+int fmhip_comm_profile_end(fmhip_comm_t c, fmhip_comm_profile *p) {
+    if (!c || !p) return fail(FMHIP_ERR_INVALID, "NULL argument");
+    TRY(set_device(c->device));
+    c->profiling = false;
+    memset(p, 0, sizeof *p);
+    HIP_TRY(hipDeviceSynchronize());
+    for (auto &r : c->prof) {
+        float ms = 0.f;
+        if (r.wait_a && r.wait_b && hipEventElapsedTime(&ms, r.wait_a, r.wait_b) == hipSuccess) p->exposed_ms += ms;
+        for (int i = 0; i < r.n_coll; ++i)
+            if (hipEventElapsedTime(&ms, r.c0[i], r.c1[i]) == hipSuccess) p->comm_ms += ms;
+        p->steps += 1;
+        destroy_events(r);
+    }
+    p->bytes = c->prof_bytes;
+    c->prof.clear();
+    return FMHIP_OK;
+}
+
+int fmhip_shard_rows(int64_t n_rows, const int64_t *row_ptr, int world, int rank, int64_t *lo, int64_t *hi) {
+    if (!row_ptr || !lo || !hi) return fail(FMHIP_ERR_INVALID, "NULL argument");
+    if (n_rows < 0 || world < 1 || rank < 0 || rank >= world) return fail(FMHIP_ERR_INVALID, "bad shard request (rows %lld, rank %d of %d)", (long long)n_rows, rank, world);
+    const int64_t nnz = row_ptr[n_rows];
+    // boundary r of rank i: the first row whose offset reaches i/world of the stored nonzeros; datasets
+    // without nonzeros fall back to row counts
+    auto bound = [&](int i) -> int64_t {
+        if (i <= 0) return 0;
+        if (i >= world) return n_rows;
+        if (nnz == 0) return n_rows * i / world;
+        const int64_t target = (int64_t)((__int128)nnz * i / world);
+        return std::lower_bound(row_ptr, row_ptr + n_rows + 1, target) - row_ptr;
+    };
+    *lo = std::min(bound(rank), n_rows);
+    *hi = std::min(std::max(bound(rank + 1), *lo), n_rows);
+    return FMHIP_OK;
+}
+
+}  // extern "C"

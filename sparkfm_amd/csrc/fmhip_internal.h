@@ -1,0 +1,181 @@
+// fmhip_internal.h — host-side state behind the opaque handles of include/fmhip.h, shared by the
+// translation units of libfmhip.so (fmhip_api.hip: datasets, models, the single-GPU step;
+// fmhip_comm.hip: the data-parallel step over RCCL).  Not installed, not part of the ABI.
+#pragma once
+#include "../../include/fmhip.h"
+#include "fm_kernels.h"
+
+#include <cstdarg>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace fmhip {
+namespace host {
+
+// records the calling thread's error message (fmhip_last_error) and returns `code`
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return fail(_e == hipErrorOutOfMemory ? FMHIP_ERR_NOMEM : FMHIP_ERR_HIP,         \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define TRY(expr)               \
+    do {                        \
+        int _r = (expr);        \
+        if (_r != FMHIP_OK) return _r; \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count) {
+        release();
+        if (count == 0) return FMHIP_OK;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(FMHIP_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        }
+        n = count;
+        return FMHIP_OK;
+    }
+    int ensure(size_t count) { return count <= n ? FMHIP_OK : alloc(count); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+constexpr int64_t kAlsMaxNnz = (int64_t)1 << 27;
+
+struct BatchMeta {
+    int64_t row0 = 0, rows = 0;
+    int64_t nnz0 = 0;   // offset of the batch in the global CSR/CSC entry arrays
+    int32_t nnz = 0;
+    int32_t n_cols = 0;     // compressed columns (features present in the batch)
+    int64_t col_off = 0;    // offset into cfeat; cptr offset is col_off + batch index
+    int32_t n_ranges = 0;
+    int64_t range_off = 0;
+    int32_t n_split = 0;          // cut columns spanning > 8 ranges
+    int64_t split_off = 0;
+    int32_t n_split_short = 0;    // cut columns spanning <= 8 ranges
+    int64_t split_short_off = 0;
+    int32_t n_feats = 0;    // distinct features present (== n_cols unless the stream is row-blocked)
+    int32_t n_mp = 0;       // features cut into several pieces (one per row block they occur in)
+    int64_t mp_off = 0;     // offset into mp_feat; mp_ptr offset is mp_off + batch index
+    int32_t n_pieces = 0;   // piece rows those features need
+    int64_t nnz_total = 0;  // stored nonzeros of the batch incl. those held in the dense hot block
+    uint32_t hot_mask = 0;  // hot slots with at least one nonzero in this batch
+};
+
+struct ProfRec {
+    int kind;
+    hipEvent_t a, b;
+    int64_t nnz, rows;
+};
+
+}  // namespace host
+}  // namespace fmhip
+
+struct fmhip_dataset {
+    using BatchMeta = fmhip::host::BatchMeta;
+    template <typename T> using DevBuf = fmhip::host::DevBuf<T>;
+    int device = 0;
+    int64_t n_rows = 0, nnz = 0, dimension = 0, batch_rows = 0;
+    int64_t max_rows = 0;
+    int32_t max_ranges = 0;
+    std::vector<BatchMeta> batches;
+    DevBuf<int64_t> row_ptr;
+    DevBuf<int32_t> col;
+    DevBuf<float> val, y;
+    DevBuf<uint32_t> crow;
+    DevBuf<float> cval;
+    DevBuf<int32_t> row_order;   // per batch: its rows' local ids sorted by stored length, longest first (forward walk order)
+    DevBuf<int32_t> cfeat, cptr, range_seg, split_seg, split_short, cdst, mp_feat, mp_ptr;
+    std::vector<int32_t> h_cfeat, h_cptr, h_split, h_split_short;   // host copies (feature-chunked backward needs them)
+    int64_t rb_rows = 0;       // rows per row block of the transposes (0 = not row-blocked)
+    int32_t max_pieces = 0;
+    // dense hot block: the entries of the (up to kHotT) most frequent features are held as a dense
+    // [n_rows][kHotT] fp32 array instead of in the sparse streams (0 where the feature is absent)
+    int32_t hot_T = 0;                 // 0 = no hot block
+    std::vector<int32_t> hot_ids;      // [kHotT] feature id per slot, -1 = unused slot
+    DevBuf<float> xhot;
+    DevBuf<int32_t> d_hot_ids;
+    int64_t nnz_sparse = 0;
+    bool scoring_only = false;   // rows + labels only (fmhip_rows_create): no transposes, cannot train
+    // fp64 copies of the values (CSR order, CSC order) and labels for the fp64 ALS learner; kept only
+    // for single-batch datasets of at most kAlsMaxNnz stored nonzeros
+    DevBuf<double> val64, cval64, y64;
+};
+
+struct fmhip_model {
+    template <typename T> using DevBuf = fmhip::host::DevBuf<T>;
+    using ProfRec = fmhip::host::ProfRec;
+    static constexpr int kGradHead = fmhip::kGradHead;
+    int device = 0;
+    int64_t n = 0, n1 = 0, n1p = 0;
+    int32_t k = 0, Kp = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DevBuf<float> V, w, w0;
+    DevBuf<float> grad_own;
+    float *grad = nullptr;        // packed gradient in use (own or bound)
+    bool grad_dirty = false;      // holds a gradient that has not been applied/zeroed
+    DevBuf<float> P, e, part, pieces, hot_part;
+    bool hot_pending = false;   // the dense hot block's gradient of the current step is still to be formed
+    DevBuf<double> acc;           // {sum e, sum e^2, rows, nonfinite}
+    DevBuf<double> bsum;          // k_forward's per-block statistic partials
+    int64_t last_nnz = 0, last_rows = 0;
+    int fwd_parts = 0;            // per-block statistic partials the last forward launch wrote
+    // lazy weight decay (fm_apply.hip): the device tables hold U with V = sv*U, w = sw*(stored w); both are
+    // exactly 1 unless rows-only updates with decay are pending.  Tracked in fp64 on the host, so the
+    // scale itself accumulates no fp32 rounding from step to step.
+    double sv = 1.0, sw = 1.0;
+    int64_t bw_next_hi = -1;      // feature-chunked backward: the next interval must end here (-1: none pending)
+    // fp64 master copy of the parameters (reference layout): exact round trip of what the caller set,
+    // and the state the fp64 ALS learner trains; stale once an fp32 SGD step has run
+    std::vector<double> h_w, h_v;
+    double h_w0 = 0.0;
+    bool host64_fresh = false;
+    DevBuf<double> als_w0, als_w, als_v, als_e, als_q;
+    bool profiling = false;
+    bool prof_rotate = false;     // time one kernel kind per step, rotating
+    int64_t prof_step = 0;
+    std::vector<ProfRec> prof;
+
+    // packed gradient: [ scalars (kGradHead floats, 8 used) | G_w (n1p) | G_b (n1p) | pad | G_V (n1p*Kp) ]: the
+    // small head sits next to the G_V rows of the LOWEST feature ids, which the feature-chunked backward
+    // finishes last, so a data-parallel host moves head + last interval in one collective
+    size_t head_floats() const { return ((size_t)kGradHead + 2 * (size_t)n1p + 31) / 32 * 32; }
+    float *scal() const { return grad; }
+    float *Gw() const { return grad + kGradHead; }
+    float *Gb() const { return grad + kGradHead + n1p; }
+    float *GV() const { return grad + head_floats(); }
+    int32_t pack_k() const { return k < Kp ? k : -1; }   // packed rows: slot k of a V row holds w_i
+    size_t grad_floats() const { return head_floats() + (size_t)n1p * Kp; }
+};
+
+
+namespace fmhip {
+namespace host {
+
+int set_device(int device);
+int check_pair(fmhip_model_t m, fmhip_dataset_t d);
+int check_train(fmhip_model_t m, fmhip_dataset_t d);      // + the dataset must have its transposes
+int check_batch(fmhip_dataset_t d, int64_t batch);
+// the pieces of one mini-batch step, all asynchronous on m->stream (fmhip_api.hip)
+int step_forward(fmhip_model_t m, fmhip_dataset_t d, int64_t b);
+int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo, int64_t feat_hi, bool finish, double *acc);
+int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double regv, fmhip_dataset_t d = nullptr, int64_t b = -1);
+int read_scal(fmhip_model_t m, fmhip_stats *st);
+
+}  // namespace host
+}  // namespace fmhip

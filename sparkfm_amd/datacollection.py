@@ -33,7 +33,10 @@ class DataCollection:
         parts = []
         for s, name in enumerate(("TrainingSet", "TestSet", "ValidationSet")):
             rows = np.nonzero(which == s)[0] if s < len(weights) else np.zeros(0, np.int64)
-            parts.append(_take_rows(rawData, rows, name, dataset_kw))
+            # only the training split is trained on: the others are scored (fm.computeRMSE(testSet),
+            # S/driver.scala:111) and keep just their rows and labels on the device
+            kw = dict(dataset_kw) if s == 0 else dict(dict(dataset_kw, batch_rows=0), scoring=True)
+            parts.append(_take_rows(rawData, rows, name, kw))
         return DataCollection(parts[0], parts[1], parts[2], 0)
 
 
@@ -41,8 +44,6 @@ def _take_rows(ds, rows, name, kw):
     lens = ds.row_ptr[rows + 1] - ds.row_ptr[rows]
     ptr = np.zeros(len(rows) + 1, np.int64)
     np.cumsum(lens, out=ptr[1:])
-    if len(rows):
-        idx = np.concatenate([np.arange(ds.row_ptr[r], ds.row_ptr[r + 1]) for r in rows]) if int(ptr[-1]) else np.zeros(0, np.int64)
-    else:
-        idx = np.zeros(0, np.int64)
+    # entry indices of the kept rows, row by row: start of the row + position inside it
+    idx = np.repeat(ds.row_ptr[rows], lens) + (np.arange(int(ptr[-1]), dtype=np.int64) - np.repeat(ptr[:-1], lens))
     return DataSet(ptr, ds.col[idx], ds.val[idx], ds.y[rows], name=name, **kw)

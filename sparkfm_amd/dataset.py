@@ -46,7 +46,7 @@ class Features:
 class DataSet(Features):
     """S/DataSet.scala:42-62.  ``rows`` of the reference = (label, SparseVector) pairs."""
 
-    def __init__(self, row_ptr, col, val, y, name="dataset", batch_rows=0, device=0):
+    def __init__(self, row_ptr, col, val, y, name="dataset", batch_rows=0, device=0, scoring=False):
         super().__init__(row_ptr, col, val)
         self.y = np.ascontiguousarray(y, self.val.dtype)
         if len(self.y) != self.size:
@@ -54,6 +54,9 @@ class DataSet(Features):
         self.name = name
         self.batch_rows = int(batch_rows)
         self.device = int(device)
+        # scoring: rows + labels only on the device (fmhip_rows_create) — held-out data for predict /
+        # computeRMSE (S/driver.scala:100-112); nothing a training step needs is built
+        self.scoring = bool(scoring)
         self._h = None
 
     # -- constructors -------------------------------------------------------------
@@ -102,9 +105,15 @@ class DataSet(Features):
         if self._h is None:
             L = _ffi.load()
             h = C.c_void_p()
-            fn = L.fmhip_dataset_create_f32 if self.val.dtype == np.float32 else L.fmhip_dataset_create
-            _ffi.check(fn(self.device, self.size, _ffi.ptr(self.row_ptr), _ffi.ptr(self.col), _ffi.ptr(self.val),
-                          _ffi.ptr(self.y), self.batch_rows, C.byref(h)))
+            f32 = self.val.dtype == np.float32
+            if self.scoring:
+                fn = L.fmhip_rows_create_f32 if f32 else L.fmhip_rows_create
+                _ffi.check(fn(self.device, self.size, _ffi.ptr(self.row_ptr), _ffi.ptr(self.col), _ffi.ptr(self.val),
+                              _ffi.ptr(self.y), C.byref(h)))
+            else:
+                fn = L.fmhip_dataset_create_f32 if f32 else L.fmhip_dataset_create
+                _ffi.check(fn(self.device, self.size, _ffi.ptr(self.row_ptr), _ffi.ptr(self.col), _ffi.ptr(self.val),
+                              _ffi.ptr(self.y), self.batch_rows, C.byref(h)))
             self._h = h
         return self
 

@@ -1,15 +1,22 @@
 """Data-parallel mini-batch SGD: rows sharded over ranks, one process per GPU.
 
 Every global step each rank runs forward+backward on ITS mini-batch into a packed fp32
-gradient buffer (a plain sum over rows), the buffers are summed across ranks with ONE
-all-reduce (RCCL over xGMI on MI355X: torch.distributed backend "nccl"), and every rank
-applies the identical update, so the parameter replicas stay bit-identical.  This replaces
-the reference's driver-side reduce/collect (`RDD.reduce(_+_)`, `collectAsMap`;
-S/fm/lib/ALS.scala:153,34,139) — SparkFM itself has no data-parallel update step.
+gradient buffer (a plain sum over rows), the buffers are summed across ranks (RCCL over xGMI
+on MI355X), and every rank applies the identical update, so the parameter replicas stay
+bit-identical.  This replaces the reference's driver-side reduce/collect (`RDD.reduce(_+_)`,
+`collectAsMap`; S/fm/lib/ALS.scala:153,34,139) — SparkFM itself has no data-parallel update step.
 
-The compute engine is pluggable so the orchestration can be exercised on CPU ranks (gloo)
-in tests; the product engine is `HipEngine` (the C ABI).  There is no CPU engine in this
-package.
+Two learners:
+
+* ``HipDataParallelSGD`` — the product path: a thin caller of the C ABI's ``fmhip_dp_epoch``
+  (sparkfm_amd/csrc/fmhip_comm.hip).  The library owns the RCCL communicator, the second
+  stream and the overlap of the all-reduce with the feature-chunked backward; Python only ships
+  the 128-byte unique id from rank 0 to the others (here over torch.distributed; a Spark driver
+  would broadcast it).  The same two symbols are what a JVM ``HipSGD`` calls.
+* ``DataParallelSGD`` — the same schedule orchestrated from Python over torch.distributed
+  collectives, with a pluggable compute engine so that the sharding, step counts and
+  zero-contributions can be exercised on CPU ranks (gloo) in tests; its GPU engine is
+  ``HipEngine``.  There is no CPU engine in this package.
 """
 import ctypes as C
 
@@ -25,6 +32,13 @@ class HipEngine:
         self.torch = torch
         self.fm, self.dataset = fm, dataset
         self.L = _ffi.load()
+        # The collectives and grad.zero_() order only against torch's CURRENT stream: the library's
+        # kernels must run on that very stream or the all-reduce can read a half-written gradient.
+        cur = torch.cuda.current_stream(fm.device).cuda_stream
+        mine = getattr(fm._stream, "value", fm._stream)
+        if not mine or mine != cur:
+            raise RuntimeError("HipEngine needs FMModel(..., stream=torch_stream_handle(device)) and that stream to be "
+                               "torch's current stream (model stream %r, current %r)" % (mine, cur))
         n = C.c_int64()
         _ffi.check(self.L.fmhip_grad_floats(fm.handle, C.byref(n)))
         self.grad = torch.zeros(int(n.value), dtype=torch.float32, device="cuda:%d" % fm.device)
@@ -69,7 +83,17 @@ class HipEngine:
         return st.as_dict()
 
     def close(self):
-        _ffi.check(self.L.fmhip_grad_bind(self.fm.handle, None))
+        """Hands the model back its own gradient buffer (the bound torch tensor may then be freed)."""
+        if self.grad is not None and self.fm._h is not None:
+            self.torch.cuda.synchronize(self.fm.device)
+            _ffi.check(self.L.fmhip_grad_bind(self.fm._h, None))
+        self.grad = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _streams = {}
@@ -110,6 +134,8 @@ class DataParallelSGD(FMLearn):
     def engine(self, fm, dataset):
         key = (id(fm), id(dataset))
         if self._engine is None or self._key != key:
+            if self._engine is not None and hasattr(self._engine, "close"):
+                self._engine.close()     # the old model must not keep pointing at a tensor about to be freed
             self._engine = self.engine_factory(fm, dataset)
             self._key = key
         return self._engine
@@ -187,9 +213,96 @@ class DataParallelSGD(FMLearn):
         return fm
 
 
-def shard_rows(n_rows, rank, world):
-    """Contiguous row shard [lo, hi) of `rank` (row-count balanced; the synthetic configs
-    have i.i.d. row lengths so this is nnz-balanced to within ~0.1 %)."""
-    lo = n_rows * rank // world
-    hi = n_rows * (rank + 1) // world
-    return lo, hi
+class RcclComm:
+    """The library's RCCL communicator of one rank (fmhip_comm_create).  `unique_id`: the 128 bytes
+    rank 0 got from `RcclComm.unique_id()`; None = fetch/ship them over torch.distributed."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * _ffi.UNIQUE_ID_BYTES)()
+        _ffi.check(_ffi.load().fmhip_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, fm, rank, world, unique_id=None, group=None):
+        L = _ffi.load()
+        if unique_id is None:
+            import torch.distributed as dist
+            box = [RcclComm.unique_id() if rank == 0 else None]
+            if world > 1:
+                # `src` is a GLOBAL rank: group rank 0 of a sub-group need not be global rank 0
+                src = dist.get_global_rank(group, 0) if group is not None else 0
+                dist.broadcast_object_list(box, src=src, group=group)
+            unique_id = box[0]
+        self.rank, self.world = rank, world
+        self._h = C.c_void_p()
+        _ffi.check(L.fmhip_comm_create(fm.handle, unique_id, rank, world, C.byref(self._h)))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            _ffi.load().fmhip_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipDataParallelSGD(FMLearn):
+    """FMLearn whose `learn` runs one data-parallel epoch over this rank's row shard INSIDE the library:
+    forward -> feature-chunked backward overlapped with the RCCL all-reduce -> identical update
+    (fmhip_dp_epoch).  `upper_fraction`: share of the stored nonzeros in the interval reduced first
+    (0 = no overlap: whole backward, one all-reduce)."""
+
+    def __init__(self, comm, eta=0.05, reg0=0.0, regw=0.0, regv=0.0, upper_fraction=0.45):
+        self.comm = comm
+        self.eta, self.reg0, self.regw, self.regv = float(eta), float(reg0), float(regw), float(regv)
+        self.upper_fraction = float(upper_fraction)
+        self.cut = None
+        self._planned_for = None
+        self.last_stats = None
+
+    def plan(self, fm, dataset):
+        """Collective: rank 0's data pick the cut, every rank receives it."""
+        cut = C.c_int64()
+        _ffi.check(_ffi.load().fmhip_dp_plan(fm.handle, dataset.handle, self.comm.handle, self.upper_fraction, C.byref(cut)))
+        self.cut = int(cut.value)
+        self._planned_for = id(dataset)
+        return self.cut
+
+    def step(self, fm, dataset, batch):
+        """One global step; batch < 0: this rank contributes zeros."""
+        if self._planned_for != id(dataset):
+            self.plan(fm, dataset)
+        _ffi.check(_ffi.load().fmhip_dp_step(fm.handle, dataset.handle, batch, self.comm.handle, self.eta, self.reg0,
+                                             self.regw, self.regv))
+        fm._device_updated()
+
+    def learn(self, fm, dataset):
+        if self._planned_for != id(dataset):
+            self.plan(fm, dataset)
+        st = _ffi.Stats()
+        _ffi.check(_ffi.load().fmhip_dp_epoch(fm.handle, dataset.handle, self.comm.handle, self.eta, self.reg0, self.regw,
+                                              self.regv, C.byref(st)))
+        fm._device_updated()
+        self.last_stats = st.as_dict()
+        return fm
+
+
+def shard_rows(rows, rank, world):
+    """Contiguous row shard [lo, hi) of `rank`.  `rows` = the CSR row_ptr array: balanced by stored
+    nonzeros (fmhip_shard_rows) — the right split for skewed real data; `rows` = a row
+    count: balanced by rows."""
+    import numpy as np
+    if np.ndim(rows) == 0:
+        n_rows = int(rows)
+        return n_rows * rank // world, n_rows * (rank + 1) // world
+    rp = np.ascontiguousarray(rows, np.int64)
+    lo, hi = C.c_int64(), C.c_int64()
+    _ffi.check(_ffi.load().fmhip_shard_rows(len(rp) - 1, _ffi.ptr(rp), world, rank, C.byref(lo), C.byref(hi)))
+    return int(lo.value), int(hi.value)

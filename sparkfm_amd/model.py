@@ -42,32 +42,39 @@ class Model:
 
 
 class FMModel(Model):
-    def __init__(self, num_attribute, num_factor, init_mean=0.0, init_stdev=0.01, seed=0, device=0, stream=None):
+    def __init__(self, num_attribute, num_factor, init_mean=0.0, init_stdev=0.01, seed=0, device=0, stream=None,
+                 init_on_device=False):
         self.num_attribute = int(num_attribute)  # S/fm/FMModel.scala:10
         self.num_factor = int(num_factor)
         self.init_mean, self.init_stdev, self.seed = init_mean, init_stdev, seed
         n1 = self.num_attribute + 1
         # S/fm/FMModel.scala:17-22: w0 = 0, w = 0, v ~ N(mean, stdev).  The reference ignores `seed`
         # (quirk Q2: unseeded breeze Gaussian); here the seed IS honoured so runs are reproducible.
-        rng = np.random.Generator(np.random.PCG64(seed))
+        # init_on_device: the draw happens on the GPU (fmhip_model_init_normal) and no host copy exists until
+        # one is asked for — for models too wide to stage on the host (2^25 x 64 doubles = 17 GB)
+        self._init_on_device = bool(init_on_device)
         self._w0 = 0.0
         self._w = np.zeros(n1)
-        self._v = np.asfortranarray(rng.normal(init_mean, init_stdev, size=(n1, self.num_factor)).T)
+        if self._init_on_device:
+            self._v = None
+        else:
+            rng = np.random.Generator(np.random.PCG64(seed))
+            self._v = np.asfortranarray(rng.normal(init_mean, init_stdev, size=(n1, self.num_factor)).T)
         self.k0 = True  # S/fm/FMModel.scala:25-26
         self.k1 = True
         self.reg0, self.regw, self.regv = 0.0, 0.0, 10.0  # S/fm/FMModel.scala:29-31 (ALS ridge terms)
         self.device = int(device)
         self._stream = stream
         self._h = None
-        self._host_fresh = True   # host arrays hold the current parameters
-        self._dev_fresh = False   # device holds the current parameters
+        self._host_fresh = not self._init_on_device   # host arrays hold the current parameters
+        self._dev_fresh = False                       # device holds the current parameters
 
     # -- parameter access (lazy host<->device sync) --------------------------------------
     def _pull(self):
         if not self._host_fresh:
             w0 = C.c_double()
-            flat = np.empty(self._v.size)
-            _ffi.check(_ffi.load().fmhip_model_get_params(self._h, C.byref(w0), _ffi.ptr(self._w), _ffi.ptr(flat)))
+            flat = np.empty(self.num_factor * (self.num_attribute + 1))
+            _ffi.check(_ffi.load().fmhip_model_get_params(self.handle, C.byref(w0), _ffi.ptr(self._w), _ffi.ptr(flat)))
             self._w0 = w0.value
             self._v = flat.reshape((self.num_factor, self.num_attribute + 1), order="F")
             self._host_fresh = True
@@ -122,6 +129,9 @@ class FMModel(Model):
             h = C.c_void_p()
             _ffi.check(L.fmhip_model_create(self.device, self.num_attribute, self.num_factor, self._stream, C.byref(h)))
             self._h = h
+            if self._init_on_device and not self._host_fresh:
+                _ffi.check(L.fmhip_model_init_normal(h, self.seed, self.init_mean, self.init_stdev))
+                self._dev_fresh = True
         if not self._dev_fresh:
             flat = np.ascontiguousarray(self._v.reshape(-1, order="F"))
             _ffi.check(L.fmhip_model_set_params(self._h, self._w0, _ffi.ptr(self._w), _ffi.ptr(flat)))
@@ -156,11 +166,14 @@ class FMModel(Model):
             _ffi.check(_ffi.load().fmhip_predict(self.handle, features.handle, _ffi.ptr(out)))
             return out
         idx, val = features
-        ds = DataSet.from_rows([(0.0, (idx, val))], device=self.device)
-        try:
-            return float(self.predict(ds)[0])
-        finally:
-            ds.unpersist()
+        idx = np.ascontiguousarray(idx, np.int32)
+        val = np.ascontiguousarray(val, np.float64)
+        if len(idx) != len(val):
+            raise ValueError("index/value length mismatch")
+        out = np.empty(1)
+        _ffi.check(_ffi.load().fmhip_predict_rows(self.handle, 1, _ffi.ptr(np.array([0, len(idx)], np.int64)), _ffi.ptr(idx),
+                                                  _ffi.ptr(val), _ffi.ptr(out)))
+        return float(out[0])
 
     def computeRMSE(self, dataset):
         """Model.computeRMSE (S/Model.scala:13-19)."""

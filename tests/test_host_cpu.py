@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     L = _ffi.load()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.fmhip_version() == 100
+    assert L.fmhip_version() == 200
     m = re.search(r"#define FMHIP_RANGE_LEN (\d+)", hdr)
     assert int(m.group(1)) == _ffi.RANGE_LEN
 
