@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — nnz/sec of FM mini-batch SGD training on MI355X (BASELINE.json's metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3] [--batch-rows B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C4|C5] [--batch-rows B]
 
 A "step" is one mini-batch SGD step (forward + backward + update) over one batch of the
-synthetic workload, all inputs resident in HBM before the timed region.  With N > 1 it is
-launched one process per GPU (torch.distributed.run); every rank owns its own 1M-row shard
-of the same virtual dataset (weak scaling) and the packed gradient is all-reduced over
-RCCL/xGMI every step.  Rank 0 prints ONE JSON line.
+synthetic workload, all inputs resident in HBM before the timed region.
 
-The `roofline` object is measured live with HIP events (recorded by the library on the
-stream its kernels run on) over the timed steps; `cpu_baseline` times the fp64 CPU oracle
-(a port — SparkFM itself needs a JVM, absent here) on a bounded sample of the same workload.
+  N = 1   BASELINE config 3 (1M rows x 100k features, k=32): the configuration the metric is quoted on.
+  N > 1   BASELINE config 4 (10M rows x 1M features, k=32) sharded by rows: every rank owns a shard of
+          the same virtual dataset and steps through mini-batches of 625k rows; the packed gradient
+          (136 MB) is all-reduced over RCCL/xGMI every step INSIDE the library (fmhip_dp_step:
+          overlapped with the feature-chunked backward).  Per-GPU work per step is fixed -> "weak".
+          Started either by the driver (python -m torch.distributed.run ... bench.py --gpus N) or by
+          `python bench.py --gpus N` alone: with WORLD_SIZE unset the parent spawns the N ranks itself —
+          before it has touched the GPU — and forwards rank 0's JSON line.
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events (recorded by the library on
+the stream its kernels run on) over the timed steps; `cpu_baseline` times the fp64 CPU oracle (a port —
+SparkFM itself needs a JVM, absent here) on a bounded sample of the same workload; `sustained` repeats
+the steps back to back for >= 2 s; `extra.hbm_resident` is a Criteo-width model (V = 8.6 GB, k=64: the
+only configuration whose tables do not live in L2 / Infinity Cache) with weight decay.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,6 +35,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md); measured streaming copy ~6.3e12
+# Ceilings for gathers of whole 128-B-multiple rows by where the table lives (MI355X_MICROARCH.md,
+# "Indexed rows"): the XCD's own L2, the Infinity Cache, HBM (measured sweep / spec peak)
+CEIL = {"l2_gather": 16.8e12, "mall_gather": 8.6e12, "hbm_gather": 6.0e12, "hbm_stream": 6.3e12}
+L2_BYTES_PER_XCD = 4 << 20
+MALL_BYTES = 256 << 20
 
 
 def alg_bytes(k):
@@ -34,6 +48,30 @@ def alg_bytes(k):
     backward = V-grad row add 4k + w-grad add 4               = 4k + 4
     whole step B_alg(k) = 8k + 16 (plus 16 B/row and 12(n+1)(k+1) B/step for the dense update)."""
     return {"forward": 4 * k + 12, "backward": 4 * k + 4, "step": 8 * k + 16}
+
+
+def requested_bytes(kp, rows, nnz, nnz_sparse, n_cols, hot, touched_rows, dense_apply, n1p, packed):
+    """Bytes each kernel of one step actually ASKS the memory system for (our own count of its loads and
+    stores, whatever level serves them), and the table its gathers hit."""
+    row = 4 * kp
+    hot_b = 64 * rows if hot else 0
+    fwd = nnz_sparse * (8 + row + (0 if packed else 4)) + rows * (8 + 4 + row + 4) + hot_b
+    bwd = nnz_sparse * (8 + row + (0 if packed else 4)) + n_cols * (row + 8) + (rows * row + hot_b if hot else 0)
+    apply_rows = n1p if dense_apply else touched_rows
+    app = apply_rows * (3 * row + 16)          # V read+write, G read (+ zero store counted with the write)
+    return {"forward": fwd, "backward": bwd, "apply": app}
+
+
+def gather_ceiling(table_bytes, l2_hit=None):
+    """Ceiling for a kernel bound by gathers from a table of `table_bytes` that every XCD reads: the
+    blend of the L2 and Infinity-Cache gather rates at L2 hit rate h (measured by rocprofv3 where a
+    committed profile exists, else the uniform-gather share min(1, 4 MiB / table)); tables beyond the
+    Infinity Cache gather at the HBM rate."""
+    if table_bytes > MALL_BYTES:
+        return "hbm_gather", CEIL["hbm_gather"], None
+    h = l2_hit if l2_hit is not None else min(1.0, L2_BYTES_PER_XCD / max(table_bytes, 1))
+    c = 1.0 / (h / CEIL["l2_gather"] + (1.0 - h) / CEIL["mall_gather"])
+    return "l2_gather x %.2f + mall_gather x %.2f" % (h, 1.0 - h), c, h
 
 
 def host_cores():
@@ -52,7 +90,6 @@ def host_cores():
 def cpu_baseline(d, k, n1, batch_rows, eta, regs, w0, w, v, budget_s=15.0):
     """fp64 CPU oracle (kind "port"), all host cores, on a bounded sample: the first m
     mini-batches of the same rows with the same schedule; m sized for ~budget_s of CPU work."""
-    import oracle
     from oracle import capi
     L = capi.lib()
     threads = host_cores()
@@ -111,23 +148,123 @@ def als_c1(device):
     fm.close()
     nnz = int(d["row_ptr"][-1])
     return {"workload": "C1: 10000 rows x 1000 features, k=8, one ALS epoch (fp64)", "gpu_s_per_epoch": gpu_s,
-            "cpu_oracle_s_per_epoch": cpu_s, "nnz": nnz,
-            "note": "Gauss-Seidel over features: a fidelity path (one persistent workgroup), not a throughput path"}
+            "cpu_oracle_s_per_epoch": cpu_s, "nnz": nnz}
 
 
-def pmc_traffic(config, k, batch_rows, kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes
-    (profiles/pmc_traffic.json), or None when no pass exists for this configuration."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+def committed_pmc(config, k, batch_rows):
+    """Counter-derived figures of the committed rocprofv3 --pmc passes for this configuration
+    (profiles/pmc_traffic.json): {kernel: {traffic_bytes, l2_hit}}; empty when no pass exists."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             entries = json.load(f)["entries"]
     except (OSError, ValueError, KeyError):
-        return None
+        return {}
+    out = {}
     for e in entries:
-        if (e["config"], e["k"], e["batch_rows"], e["kernel"]) == (config, k, batch_rows, kernel):
-            return e["traffic_bytes"]
-    return None
+        if (e.get("config"), e.get("k"), e.get("batch_rows")) == (config, k, batch_rows):
+            out[e["kernel"]] = e
+    return out
+
+
+def kernel_table(prof, k, kp, req, pmc, table_bytes):
+    """Per-kernel: HIP-event time, algorithmic rate, requested-byte rate, the ceiling
+    that binds it and the fraction of THAT ceiling."""
+    ab = alg_bytes(k)
+    pd = prof.as_dict()
+    tot_ms = max(sum(x["ms"] for x in pd.values()), 1e-12)
+    kern = {}
+    for name, p in pd.items():
+        if not p["launches"]:
+            continue
+        avg_ms = p["ms"] / p["launches"]
+        ent = {"avg_ms": avg_ms, "launches": p["launches"], "share": p["ms"] / tot_ms}
+        if name in ab:
+            ent["alg_bytes_per_nnz"] = ab[name]
+            ent["alg_GBps"] = (p["nnz"] / p["launches"]) * ab[name] / (avg_ms * 1e-3) / 1e9
+        if name in req:
+            ent["requested_bytes_per_launch"] = req[name]
+            ent["requested_GBps"] = req[name] / (avg_ms * 1e-3) / 1e9
+            if name in ("forward", "backward"):
+                hit = pmc.get("k_" + name, {}).get("l2_hit")
+                cname, c, h = gather_ceiling(table_bytes[name], hit)
+                ent["ceiling"] = {"name": cname, "GBps": c / 1e9, "table_bytes": table_bytes[name],
+                                  "l2_hit": h, "l2_hit_source": ("profiles/pmc_traffic.json" if hit is not None else
+                                                                 ("uniform-gather model" if h is not None else None))}
+            else:
+                ent["ceiling"] = {"name": "hbm_stream", "GBps": CEIL["hbm_stream"] / 1e9}
+            ent["frac_of_ceiling"] = ent["requested_GBps"] / ent["ceiling"]["GBps"]
+        t = pmc.get("k_" + name, {}).get("traffic_bytes")
+        if t is not None:
+            ent["traffic_from_committed_profile"] = t
+        kern[name] = ent
+    return kern
+
+
+def hbm_resident_leg(device, steps=24, rows=500_000, batch_rows=250_000):
+    """A model that does NOT fit the caches: C5's width (2^25 hashed slots, k=64 -> V = 8.6 GB, packed
+    gradient 8.9 GB) on one GPU, Criteo-shaped rows, weight decay on (lazy rows-only update).  The one
+    place where algorithmic bytes are HBM bytes."""
+    from sparkfm_amd import DataSet, FMModel, _ffi, synth
+    L = _ffi.load()
+    n1, k = 1 << 25, 64
+    d = synth.make_config("C5", rows=rows)
+    ds = DataSet.from_arrays(d, batch_rows=batch_rows, device=device).cache()
+    fm = FMModel(n1 - 1, k, seed=5, device=device, init_on_device=True)
+    hm, hd, nb = fm.handle, ds.handle, ds.n_batches
+    regs = (0.0, 1e-4, 1e-4)
+    bnnz = [ds.batch_info(b)["nnz"] for b in range(nb)]
+    for j in range(4):
+        _ffi.check(L.fmhip_sgd_step(hm, hd, j % nb, 0.02, *regs, None))
+    _ffi.check(L.fmhip_synchronize(hm))
+    _ffi.check(L.fmhip_profile_begin_rotating(hm))
+    t0 = time.perf_counter()
+    for j in range(steps):
+        _ffi.check(L.fmhip_sgd_step(hm, hd, j % nb, 0.02, *regs, None))
+    _ffi.check(L.fmhip_synchronize(hm))
+    dt = time.perf_counter() - t0
+    prof = _ffi.Profile()
+    _ffi.check(L.fmhip_profile_end(hm, C.byref(prof)))
+    st = _ffi.Stats()
+    _ffi.check(L.fmhip_step_stats(hm, C.byref(st)))
+    nnz = sum(bnnz[j % nb] for j in range(steps))
+    value = nnz / dt
+    ab = alg_bytes(k)
+    pd = prof.as_dict()
+    kern = {n: {"avg_ms": p["ms"] / p["launches"], "alg_GBps": (p["nnz"] / p["launches"]) * ab[n] / (p["ms"] / p["launches"] * 1e-3) / 1e9
+                if n in ab else None} for n, p in pd.items() if p["launches"]}
+    out = {"workload": "C5 width on one GPU: %d Criteo-shaped rows x 2^25 hashed slots, k=64 (V = %.1f GB), batch %d rows, "
+                       "eta 0.02, regw = regv = 1e-4 (lazy rows-only update)" % (rows, n1 * k * 4 / 1e9, batch_rows),
+           "value": value, "unit": "nnz/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "alg_bytes_per_nnz": ab["step"], "alg_GBps": value * ab["step"] / 1e9,
+           "frac_of_8TBps": value * ab["step"] / HBM_PEAK, "frac_of_hbm_gather_6TBps": value * ab["step"] / CEIL["hbm_gather"],
+           "kernels": kern, "last_batch_mse": st.sse / max(st.rows, 1), "nonfinite": st.nonfinite}
+    ds.unpersist()
+    fm.close()
+    return out
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (this process
+    has not touched the GPU and never will), forward rank 0's JSON line, exit with the worst exit code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = max(rc, abs(p.wait()))
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    raise SystemExit(rc)
 
 
 def main():
@@ -135,15 +272,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4"])
-    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the config's row count, capped at 1.25M)")
-    ap.add_argument("--batch-rows", type=int, default=250000, help="mini-batch rows per GPU")
+    ap.add_argument("--config", default=None, choices=["C1", "C2", "C3", "C4", "C5"],
+                    help="default: C3 on one GPU (the metric's configuration), C4 on several (BASELINE's 8-GPU config)")
+    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the config's rows / N, capped at 2.5M)")
+    ap.add_argument("--batch-rows", type=int, default=0, help="mini-batch rows per GPU (default 250000; 625000 data-parallel)")
     ap.add_argument("--eta", type=float, default=0.02)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the sustained / HBM-resident / ALS legs")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"],
+                    help="rccl: the library's own communicator (fmhip_dp_step); torch: torch.distributed all-reduce "
+                         "orchestrated from Python (sparkfm_amd.distributed.DataParallelSGD)")
+    ap.add_argument("--upper-fraction", type=float, default=0.45, help="share of the nonzeros in the feature interval reduced first (0 = no overlap)")
     ap.add_argument("--force-dp", action="store_true",
                     help="self-test: take the data-parallel path (RCCL all-reduce included) even with one rank")
     ap.add_argument("--cpu-budget", type=float, default=30.0)
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args, sys.argv[1:])
     # stdout carries exactly one JSON line: libraries that print banners to fd 1 (RCCL prints its
     # version block there at communicator creation) are sent to stderr for the duration of the run
     sys.stdout.flush()
@@ -154,50 +299,84 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                             "--master-addr 127.0.0.1 --master-port 29511 bench.py --gpus %d ..." % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
 
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     use_dp = world > 1 or args.force_dp
+    exchange = args.exchange if use_dp else "none"
     if use_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if exchange == "rccl":
+            # control plane only (unique id, barriers, the max over ranks): the gradients never pass through it
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from sparkfm_amd import DataSet, FMModel, _ffi, synth
-    from sparkfm_amd.distributed import DataParallelSGD, torch_stream_handle
+    from sparkfm_amd.distributed import DataParallelSGD, HipDataParallelSGD, RcclComm, torch_stream_handle
 
-    cfg = synth.CONFIGS[args.config]
-    rows = args.rows or min(cfg["rows"], 1_250_000)
+    config = args.config or ("C4" if world > 1 else "C3")
+    cfg = synth.CONFIGS[config]
+    rows = args.rows or min(cfg["rows"] // world, 2_500_000 if world > 1 else 1_250_000)
     k, n1 = cfg["k"], cfg["features"]
-    batch_rows = min(args.batch_rows, rows)
+    batch_rows = min(args.batch_rows or (625_000 if use_dp else 250_000), rows)
     regs = (0.0, 1e-4, 1e-4)
 
     t0 = time.time()
-    d = synth.make_config(args.config, rows=rows, row_begin=rank * rows)
+    d = synth.make_config(config, rows=rows, row_begin=rank * rows)
     t_gen = time.time() - t0
-    w0, w, v = synth.init_params(cfg["seed"] + 1000, n1, k)
     t0 = time.time()
-    ds = DataSet.from_arrays(d, name=args.config, batch_rows=batch_rows, device=local_rank).cache()
+    ds = DataSet.from_arrays(d, name=config, batch_rows=batch_rows, device=local_rank).cache()
     t_load = time.time() - t0
-    stream = torch_stream_handle(local_rank) if use_dp else None
-    fm = FMModel(n1 - 1, k, device=local_rank, stream=stream)
-    fm.w0, fm.w, fm.v = w0, w, v
+    wide = n1 * k > (1 << 28)                      # too wide to stage fp64 parameters on the host: draw on the device
+    stream = torch_stream_handle(local_rank) if exchange == "torch" else None
+    if wide:
+        fm = FMModel(n1 - 1, k, seed=cfg["seed"] + 1000, device=local_rank, stream=stream, init_on_device=True)
+        w0 = w = v = None
+    else:
+        w0, w, v = synth.init_params(cfg["seed"] + 1000, n1, k)
+        fm = FMModel(n1 - 1, k, device=local_rank, stream=stream)
+        fm.w0, fm.w, fm.v = w0, w, v
     L = _ffi.load()
     hm, hd = fm.handle, ds.handle
     nb = ds.n_batches
-    bnnz = [ds.batch_info(b)["nnz"] for b in range(nb)]
-    dp = DataParallelSGD(eta=args.eta, reg0=regs[0], regw=regs[1], regv=regs[2], always_reduce=True) if use_dp else None
-    eng = dp.engine(fm, ds) if dp else None
+    binfo = [ds.batch_info(b) for b in range(nb)]
+    bnnz = [bi["nnz"] for bi in binfo]
+    comm = dp = eng = None
+    comm_note = None
+    if exchange == "rccl":
+        try:
+            comm = RcclComm(fm, rank, world)
+            dp = HipDataParallelSGD(comm, eta=args.eta, reg0=regs[0], regw=regs[1], regv=regs[2], upper_fraction=args.upper_fraction)
+            dp.plan(fm, ds)
+        except Exception as ex:   # noqa: BLE001 — reported in the JSON line, never silent
+            # every rank fails or succeeds together (communicator creation is collective); fall back to the
+            # Python-orchestrated exchange over torch.distributed
+            comm_note = "library-side RCCL exchange unavailable (%r): fell back to torch.distributed" % (ex,)
+            sys.stderr.write("[bench] rank %d: %s\n" % (rank, comm_note))
+            exchange = "torch"
+            dist.destroy_process_group()
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            fm.close()
+            fm = FMModel(n1 - 1, k, device=local_rank, stream=torch_stream_handle(local_rank), init_on_device=wide,
+                         seed=cfg["seed"] + 1000)
+            if not wide:
+                fm.w0, fm.w, fm.v = w0, w, v
+            hm = fm.handle
+    if exchange == "torch":
+        dp = DataParallelSGD(eta=args.eta, reg0=regs[0], regw=regs[1], regv=regs[2], always_reduce=True,
+                             overlap=args.upper_fraction > 0)
+        eng = dp.engine(fm, ds)
 
     def step(j):
-        if dp:
+        if exchange == "rccl":
+            _ffi.check(L.fmhip_dp_step(hm, hd, j % nb, comm.handle, args.eta, regs[0], regs[1], regs[2]))
+        elif exchange == "torch":
             dp.step(eng, j % nb)
         else:
             _ffi.check(L.fmhip_sgd_step(hm, hd, j % nb, args.eta, regs[0], regs[1], regs[2], None))
@@ -206,43 +385,39 @@ def main():
         _ffi.check(L.fmhip_synchronize(hm))
         torch.cuda.synchronize()
 
-    overlap_used = bool(dp and dp.overlap)
-    try:
-        for j in range(args.warmup):
-            step(j)
-        sync()
-    except Exception as ex:   # noqa: BLE001 — only the overlapped exchange is retried, loudly
-        if not (dp and dp.overlap):
-            raise
-        sys.stderr.write("[bench] rank %d: overlapped all-reduce path failed (%r); retrying with the plain "
-                         "one-collective-per-step path\n" % (rank, ex))
-        dp.overlap = False
-        overlap_used = False
-        eng.grad.zero_()
-        fm.w0, fm.w, fm.v = w0, w, v
-        hm = fm.handle
-        _ffi.check(L.fmhip_grad_bind(hm, C.c_void_p(eng.grad.data_ptr())))
-        for j in range(args.warmup):
-            step(j)
-        sync()
-    if use_dp:
-        dist.barrier()
+    def barrier():
+        if use_dp:
+            dist.barrier()
+
+    for j in range(args.warmup):
+        step(j)
+    sync()
+    barrier()
     if not os.environ.get("FMHIP_BENCH_NO_EVENTS"):
         # one kernel kind per step, rotating: the event records barely perturb the timed region
         _ffi.check(L.fmhip_profile_begin_rotating(hm))
+    if comm is not None:
+        _ffi.check(L.fmhip_comm_profile_begin(comm.handle))
     sync()
+    barrier()
     t0 = time.perf_counter()
     for j in range(args.warmup, args.warmup + args.steps):
         step(j)
     sync()
-    if use_dp:
-        dist.barrier()
+    barrier()
     elapsed = time.perf_counter() - t0
     prof = _ffi.Profile()
     _ffi.check(L.fmhip_profile_end(hm, C.byref(prof)))
+    cprof = None
+    if comm is not None:
+        cp = _ffi.CommProfile()
+        _ffi.check(L.fmhip_comm_profile_end(comm.handle, C.byref(cp)))
+        cprof = cp.as_dict()
     local_nnz = sum(bnnz[j % nb] for j in range(args.warmup, args.warmup + args.steps))
     if use_dp:
-        t = torch.tensor([elapsed, float(local_nnz)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, float(local_nnz)], dtype=torch.float64)
+        if exchange == "torch":
+            t = t.cuda()
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -252,51 +427,150 @@ def main():
     st = _ffi.Stats()
     _ffi.check(L.fmhip_step_stats(hm, C.byref(st)))
 
+    # ---- sustained: the same steps back to back for >= 2 s (clock / power settled)
+    sustained = None
+    if not args.no_extra:
+        barrier()
+        sync()
+        n_done, t0 = 0, time.perf_counter()
+        while True:
+            for j in range(4 * nb):
+                step(n_done + j)
+            n_done += 4 * nb
+            sync()
+            dt = time.perf_counter() - t0
+            flag = torch.tensor([1.0 if dt < 2.0 else 0.0])
+            if use_dp:
+                if exchange == "torch":
+                    flag = flag.cuda()
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)     # every rank takes the same number of steps
+            if float(flag[0]) == 0.0:
+                break
+        barrier()
+        dt = time.perf_counter() - t0
+        s_nnz = float(sum(bnnz[j % nb] for j in range(n_done)))
+        if use_dp:
+            t = torch.tensor([s_nnz], dtype=torch.float64)
+            if exchange == "torch":
+                t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            s_nnz = float(t[0])
+        sustained = {"seconds": dt, "steps": n_done, "value": s_nnz / dt, "unit": "nnz/s", "ms_per_step": dt / n_done * 1e3}
+
+    # ---- the same shard and batch WITHOUT the exchange (what one GPU of the job does alone)
+    no_exchange = None
+    if use_dp and rank == 0 and not args.no_extra:
+        sync()
+        for j in range(4):
+            _ffi.check(L.fmhip_step_compute(hm, hd, j % nb))
+            _ffi.check(L.fmhip_step_apply(hm, args.eta, *regs))
+        sync()
+        t0 = time.perf_counter()
+        for j in range(args.steps):
+            _ffi.check(L.fmhip_step_compute(hm, hd, j % nb))
+            _ffi.check(L.fmhip_step_apply(hm, args.eta, *regs))
+        sync()
+        dt = time.perf_counter() - t0
+        no_exchange = {"value": sum(bnnz[j % nb] for j in range(args.steps)) / dt, "unit": "nnz/s", "ms_per_step": dt / args.steps * 1e3,
+                       "note": "rank 0 alone, same shard and batch, dense update, no all-reduce"}
+    barrier()
+
     if rank == 0:
         ab = alg_bytes(k)
+        kp = 32
+        while kp < k:
+            kp *= 2
+        packed = k < kp
+        pmc = committed_pmc(config, k, batch_rows)
+        bi = binfo[0]
+        lay = ds.layout()
+        hot = len(lay["hot_ids"]) > 0
+        n_cols = bi["n_columns"]
+        nnz0, rows0 = bi["nnz"], bi["rows"]
+        nnz0_sparse = int(round(nnz0 * lay["nnz_sparse"] / max(int(d["row_ptr"][-1]), 1)))   # batch 0's share of the sparse streams
+        dense_apply = use_dp or n_cols * 2 > n1
+        req = requested_bytes(kp, rows0, nnz0, nnz0_sparse, n_cols, hot, n_cols, dense_apply, n1, packed)
+        table_bytes = {"forward": n1 * kp * 4, "backward": rows0 * kp * 4}
+        kern = kernel_table(prof, k, kp, req, pmc, table_bytes)
+        dom = max(("forward", "backward"), key=lambda n: prof.as_dict()[n]["ms"])
         pd = prof.as_dict()
-        kern = {}
-        for name, p in pd.items():
-            if p["launches"]:
-                avg_ms = p["ms"] / p["launches"]
-                ent = {"avg_ms": avg_ms, "launches": p["launches"], "share": p["ms"] / max(sum(x["ms"] for x in pd.values()), 1e-12)}
-                if name in ab:
-                    ent["alg_bytes_per_nnz"] = ab[name]
-                    ent["alg_GBps"] = (p["nnz"] / p["launches"]) * ab[name] / (avg_ms * 1e-3) / 1e9
-                kern[name] = ent
-        dom = max(("forward", "backward"), key=lambda n: pd[n]["ms"])
         achieved = kern[dom]["alg_GBps"] if dom in kern else float("nan")
         value = total_nnz / elapsed
+        step_ms = elapsed / args.steps * 1e3
+        # fraction of the step's time that the kernels' own ceilings account for (<= 1 when no kernel beats its ceiling)
+        explained_ms = sum(e["requested_bytes_per_launch"] / (e["ceiling"]["GBps"] * 1e9) * 1e3 for e in kern.values() if "ceiling" in e)
         out = {
             "metric": "nnz_per_sec_fm_sgd_training", "value": value, "unit": "nnz/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d rows x %d features per GPU, k=%d, nnz/row U{%d..%d}, ids Zipf(%.2f), "
-                                   "fp32 mini-batch SGD" % (args.config, rows, n1, k, cfg["nnz_lo"], cfg["nnz_hi"], cfg["zipf_s"]),
+            "config": {"workload": "%s: %d rows x %d features per GPU, k=%d, %s, fp32 mini-batch SGD" %
+                                   (config, rows, n1, k, "39 hashed Criteo-shaped fields" if cfg.get("criteo") else
+                                    "nnz/row U{%d..%d}, ids Zipf(%.2f)" % (cfg["nnz_lo"], cfg["nnz_hi"], cfg["zipf_s"])),
                        "rows_per_gpu": rows, "features": n1, "k": k, "batch_rows_per_gpu": batch_rows,
-                       "batches_per_gpu": nb, "nnz_per_gpu": int(d["row_ptr"][-1]), "eta": args.eta,
-                       "parallelism": "dp%d" % world,
-                       "allreduce": ("overlapped with the feature-chunked backward" if overlap_used else
-                                     ("one all-reduce per step" if use_dp else "none"))},
+                       "batches_per_gpu": nb, "nnz_per_gpu": int(d["row_ptr"][-1]), "eta": args.eta, "regs": regs,
+                       "parallelism": "dp%d" % world, "exchange": exchange,
+                       "allreduce": ("inside the library (RCCL), overlapped with the feature-chunked backward, cut at feature %d" % dp.cut
+                                     if exchange == "rccl" and dp.cut else
+                                     ("inside the library (RCCL), one all-reduce per step" if exchange == "rccl" else
+                                      ("torch.distributed, orchestrated from Python" if exchange == "torch" else "none")))},
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
-                         "traffic": pmc_traffic(args.config, k, batch_rows, "k_" + dom),
+                         "traffic": kern.get(dom, {}).get("traffic_from_committed_profile"),
+                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this configuration; not measured in this run)",
                          "alg_bytes_per_nnz": ab[dom], "nnz_per_launch": pd[dom]["nnz"] / max(pd[dom]["launches"], 1),
-                         "avg_launch_ms": kern[dom]["avg_ms"] if dom in kern else None},
-            "step_roofline": {"alg_bytes_per_nnz": ab["step"], "achieved_GBps": value / world * ab["step"] / 1e9,
-                              "frac_of_8TBps": value / world * ab["step"] / HBM_PEAK},
+                         "avg_launch_ms": kern[dom]["avg_ms"] if dom in kern else None,
+                         "note": "achieved = ALGORITHMIC bytes (SURVEY §8(d)) / launch time; at this size V, P and the gradient live in "
+                                 "L2 / Infinity Cache, so the binding ceiling is the gather rate of those levels: see kernels[*].ceiling",
+                         "requested_GBps": kern.get(dom, {}).get("requested_GBps"),
+                         "ceiling": kern.get(dom, {}).get("ceiling"),
+                         "frac_of_ceiling": kern.get(dom, {}).get("frac_of_ceiling")},
+            "step_roofline": {"alg_bytes_per_nnz": ab["step"], "alg_GBps": value / world * ab["step"] / 1e9,
+                              "requested_bytes_per_step": sum(e.get("requested_bytes_per_launch", 0) for e in kern.values()),
+                              "time_at_ceilings_ms": explained_ms, "frac": explained_ms / step_ms,
+                              "note": "frac = sum over kernels of (requested bytes / that kernel's ceiling) / measured step time"},
             "kernels": kern,
             "train": {"last_batch_mse": st.sse / max(st.rows, 1), "nonfinite": st.nonfinite},
             "setup_s": {"generate": t_gen, "load_transpose_h2d": t_load},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if sustained:
+            out["sustained"] = sustained
+        if use_dp:
+            gf = C.c_int64()
+            _ffi.check(L.fmhip_grad_floats(hm, C.byref(gf)))
+            payload = int(gf.value) * 4
+            xc = {"nranks": world, "allreduce_bytes_per_step": payload, "backend": exchange}
+            if cprof and cprof["steps"]:
+                xc["exposed_comm_ms"] = cprof["exposed_ms"] / cprof["steps"]
+                xc["comm_busy_ms"] = cprof["comm_ms"] / cprof["steps"]
+                # ring all-reduce moves 2(N-1)/N of the payload per rank
+                busy = max(cprof["comm_ms"] / cprof["steps"], 1e-9)
+                xc["alg_GBps"] = payload / busy / 1e6
+                xc["bus_GBps"] = payload * (2.0 * (world - 1) / max(world, 1)) / busy / 1e6
+            if no_exchange:
+                xc["per_gpu_without_exchange"] = no_exchange
+                xc["efficiency_vs_no_exchange"] = value / (world * no_exchange["value"])
+            if comm_note:
+                xc["note"] = comm_note
+            out["exchange"] = xc
+        if world == 1 and not args.no_cpu_baseline and not wide:
             out["cpu_baseline"] = cpu_baseline(d, k, n1, batch_rows, args.eta, regs, w0, w, v, args.cpu_budget)
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
-            out["als_c1"] = als_c1(local_rank)
+        if world == 1 and not args.no_extra and not use_dp:
+            ds.unpersist()
+            fm.close()
+            extra = {}
+            try:
+                extra["hbm_resident"] = hbm_resident_leg(local_rank)
+            except Exception as ex:   # noqa: BLE001
+                extra["hbm_resident"] = {"error": repr(ex)}
+            extra["als_c1"] = als_c1(local_rank)
+            out["extra"] = extra
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dp:
         dist.barrier()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

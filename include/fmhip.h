@@ -270,6 +270,10 @@ int fmhip_comm_profile_end(fmhip_comm_t c, fmhip_comm_profile *p);
 int fmhip_shard_rows(int64_t n_rows, const int64_t *row_ptr, int world, int rank, int64_t *lo, int64_t *hi);
 
 /* ---- measurement ------------------------------------------------------------------ */
+/* How the library laid a dataset out (for byte accounting; not needed to use it): the number of
+ * features held in the dense hot block (0 = none) with their ids (ids: room for 16, nullable), and
+ * the stored nonzeros that stayed in the sparse streams. */
+int fmhip_dataset_layout(fmhip_dataset_t d, int32_t *n_hot, int32_t *hot_ids, int64_t *nnz_sparse);
 int fmhip_profile_begin(fmhip_model_t m);                  /* start recording HIP events around every kernel */
 /* same, but each SGD step times only ONE kernel kind, rotating forward -> backward -> fixup ->
  * apply from step to step: 2 event records per step instead of 8, so the timed region

@@ -1382,6 +1382,19 @@ int fmhip_step_stats(fmhip_model_t m, fmhip_stats *stats) {
 
 // ---- measurement
 
+int fmhip_dataset_layout(fmhip_dataset_t d, int32_t *n_hot, int32_t *hot_ids, int64_t *nnz_sparse) {
+    if (!d) return fail(FMHIP_ERR_INVALID, "dataset is NULL");
+    int32_t n = 0;
+    for (int h = 0; h < (int)d->hot_ids.size(); ++h)
+        if (d->hot_ids[(size_t)h] >= 0) {
+            if (hot_ids) hot_ids[n] = d->hot_ids[(size_t)h];
+            ++n;
+        }
+    if (n_hot) *n_hot = n;
+    if (nnz_sparse) *nnz_sparse = d->nnz_sparse;
+    return FMHIP_OK;
+}
+
 int fmhip_profile_begin(fmhip_model_t m) {
     if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
     for (auto &r : m->prof) {

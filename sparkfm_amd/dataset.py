@@ -148,6 +148,12 @@ class DataSet(Features):
         _ffi.check(_ffi.load().fmhip_dataset_batch_info(self.handle, b, *[C.byref(x) for x in v]))
         return dict(zip(("row0", "rows", "nnz", "n_columns"), (int(x.value) for x in v)))
 
+    def layout(self):
+        """How the library laid the rows out: ids held in the dense hot block, nonzeros left in the sparse streams."""
+        n, ids, sp = C.c_int32(), np.full(16, -1, np.int32), C.c_int64()
+        _ffi.check(_ffi.load().fmhip_dataset_layout(self.handle, C.byref(n), _ffi.ptr(ids), C.byref(sp)))
+        return dict(hot_ids=ids[:n.value].tolist(), nnz_sparse=int(sp.value))
+
     def transposeInput(self, batch=0):
         """transposeInput (S/DataSet.scala:48, :31-38) of one mini-batch, read back from the GPU:
         (feat, ptr, rows, vals) — ascending present feature ids, offsets, batch-local row ids, values."""

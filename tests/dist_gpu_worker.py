@@ -22,7 +22,8 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % port, rank=rank, world_size=world)
     # the same virtual dataset as the single-process reference: rank r owns rows [r*3000, (r+1)*3000)
-    d = synth.make_zipf(77, 3000 if rank == 0 else 2200, 800, 4, 24, zipf_s=1.05, row_begin=rank * 3000)
+    # uneven shards: rank 1 has 2 batches (1000 + 700 rows) against rank 0's 3, so its last step contributes zeros
+    d = synth.make_zipf(77, 3000 if rank == 0 else 1700, 800, 4, 24, zipf_s=1.05, row_begin=rank * 3000)
     ds = DataSet.from_arrays(d, batch_rows=1000, device=0).cache()
     w0, w, v = synth.init_params(5, 800, k, stdev=0.05)
     w = np.random.default_rng(9).normal(0, 0.05, 800)

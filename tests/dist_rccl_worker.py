@@ -1,0 +1,37 @@
+"""Worker for test_library_side_exchange_two_ranks: one rank = one GPU, the exchange runs INSIDE the
+library (fmhip_comm_create + fmhip_dp_epoch over RCCL); torch.distributed (gloo) only ships the
+128-byte unique id and the final barrier."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    import torch.distributed as dist
+    from sparkfm_amd import DataSet, FMModel, synth
+    from sparkfm_amd.distributed import HipDataParallelSGD, RcclComm
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % port, rank=rank, world_size=world)
+    # uneven shards: rank 1 has 2 batches against rank 0's 3
+    d = synth.make_zipf(77, 3000 if rank == 0 else 1700, 800, 4, 24, zipf_s=1.05, row_begin=rank * 3000)
+    ds = DataSet.from_arrays(d, batch_rows=1000, device=rank).cache()
+    w0, w, v = synth.init_params(5, 800, 32, stdev=0.05)
+    w = np.random.default_rng(9).normal(0, 0.05, 800)
+    fm = FMModel(799, 32, device=rank)
+    fm.w0, fm.w, fm.v = w0, w, v
+    comm = RcclComm(fm, rank, world)
+    dp = HipDataParallelSGD(comm, eta=0.05, regw=1e-3, regv=1e-3)
+    for _ in range(2):
+        dp.learn(fm, ds)
+    np.savez(out + ".%d.npz" % rank, w0=fm.w0, w=fm.w, v=fm.v, cut=dp.cut)
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -30,9 +30,15 @@ def fmhip():
     return sparkfm_amd
 
 
-def make(fmhip, a, batch_rows=0):
+def torch_stream():
+    """The dedicated torch stream HipEngine requires the model to run on (made current on first use)."""
+    from sparkfm_amd.distributed import torch_stream_handle
+    return torch_stream_handle(0)
+
+
+def make(fmhip, a, batch_rows=0, stream=None):
     ds = fmhip.DataSet(a["row_ptr"], a["col"], a["val"], a["y"], batch_rows=batch_rows).cache()
-    fm = fmhip.FMModel(a["n1"] - 1, a["k"])
+    fm = fmhip.FMModel(a["n1"] - 1, a["k"], stream=stream)
     fm.w0, fm.w, fm.v = a["w0"], a["w"], a["v"]
     return ds, fm
 
@@ -221,12 +227,16 @@ def hot_problem(seed, n_rows, n1, k, n_hot, dup_feature=None, zero_feature=None)
 
 @pytest.mark.parametrize("k,n_hot,dup,zero", [(32, 16, None, None), (32, 20, None, None), (16, 5, None, None),
                                                 (64, 9, 2, None), (100, 16, None, 3), (8, 12, 0, 1)])
-def test_dense_hot_block(fmhip, k, n_hot, dup, zero):
+@pytest.mark.parametrize("flat", [0, 1])
+def test_dense_hot_block(fmhip, request, k, n_hot, dup, zero, flat):
     """fmhip_tune(5, 1): the most frequent features (>= 10 % of the rows, at most 16, none that occurs
     twice in a row or with a stored zero) leave the sparse streams for a dense [rows][16] block.
-    Forward, gradient, transposes, epochs and the feature-chunked backward must not notice."""
+    Forward, gradient, transposes, epochs and the feature-chunked backward must not notice.
+    flat=1: the same on the flat-address kernels (fmhip_tune key 8)."""
     from sparkfm_amd import _ffi
     L = _ffi.load()
+    L.fmhip_tune(8, flat)
+    request.addfinalizer(lambda: L.fmhip_tune(8, 0))
     a, hot_ids = hot_problem(100 + k, 3000, 500, k, n_hot, dup, zero)
     a["val"] = a["val"].astype(np.float32).astype(np.float64)       # exactly representable in fp32
     n_rows, br = 3000, 700
@@ -234,7 +244,7 @@ def test_dense_hot_block(fmhip, k, n_hot, dup, zero):
         L.fmhip_tune(5, 1)
         ds, fm = make(fmhip, a, batch_rows=br)
     finally:
-        L.fmhip_tune(5, 0)
+        L.fmhip_tune(5, 1)
     # scoring
     yh = fm.predict(ds)
     oy = oracle.predict(a["w0"], a["w"], a["v"], a["row_ptr"], a["col"], a["val"])
@@ -325,9 +335,9 @@ def test_dense_hot_block_chunked_backward(fmhip):
     a, hot_ids = hot_problem(77, 2500, 600, 32, 14)
     try:
         L.fmhip_tune(5, 1)
-        ds, fm = make(fmhip, a, batch_rows=900)
+        ds, fm = make(fmhip, a, batch_rows=900, stream=torch_stream())
     finally:
-        L.fmhip_tune(5, 0)
+        L.fmhip_tune(5, 1)
     import torch
     from sparkfm_amd.distributed import HipEngine
     eng = HipEngine(fm, ds)
@@ -478,7 +488,7 @@ def test_rows_only_apply_for_wide_models(fmhip, k):
     from sparkfm_amd.distributed import DataParallelSGD
     a, _ = hot_problem(300 + k, 1500, 40000, k, 6)
     ds, fm = make(fmhip, a, batch_rows=400)
-    fm2 = fmhip.FMModel(a["n1"] - 1, k)
+    fm2 = fmhip.FMModel(a["n1"] - 1, k, stream=torch_stream())
     fm2.w0, fm2.w, fm2.v = a["w0"], a["w"], a["v"]
     eta = 0.05
     sgd = fmhip.HipSGD(eta=eta, reg0=0.0, regw=0.0, regv=0.0)            # fused path: rows-only apply
@@ -537,7 +547,7 @@ def test_split_step_equals_fused_step(fmhip):
     ref = fmhip.HipSGD(eta=0.04, regw=1e-3, regv=1e-3)
     ref.learn(fm, ds)
     want = (fm.w0, fm.w.copy(), fm.v.copy())
-    fm2 = fmhip.FMModel(a["n1"] - 1, a["k"])
+    fm2 = fmhip.FMModel(a["n1"] - 1, a["k"], stream=torch_stream())
     fm2.w0, fm2.w, fm2.v = a["w0"], a["w"], a["v"]
     dp = DataParallelSGD(eta=0.04, regw=1e-3, regv=1e-3)
     dp.learn(fm2, ds)
@@ -567,7 +577,7 @@ def test_feature_chunked_backward_equals_whole_backward(fmhip):
     for r in range(3000):                                            # two hot columns -> wave sums + long fixups
         s = slice(a["row_ptr"][r], a["row_ptr"][r + 1])
         a["col"][s.start] = 0 if not (a["col"][s] == 0).any() else a["col"][s.start]
-    ds, fm = make(fmhip, a, batch_rows=1500)
+    ds, fm = make(fmhip, a, batch_rows=1500, stream=torch_stream())
     eng = HipEngine(fm, ds)
     for batch in (0, 1):
         eng.compute(batch)
@@ -703,10 +713,11 @@ def test_config_c1_fit_with_als(fmhip):
 @pytest.mark.parametrize("config", ["C3", "C2"])
 def test_full_size_properties(fmhip, config):
     """BASELINE configs 3 (k=32, the bench workload) and 2 (k=16: packed rows) at their full size (1M
-    rows x 100k features, 40M nonzeros) — far beyond what the oracle walks in seconds, so parity is pinned by (1) the oracle on a
-    random SAMPLE of rows scored against the full model, (2) size-independent identities of the batch
-    gradient, (3) bit-identical repeats and chunked == whole backward, (4) the dense-hot-block and plain
-    layouts agreeing with each other."""
+    rows x 100k features, 40M nonzeros): (1) the oracle on a random sample of rows scored against the full
+    model, (2) the FULL gradient of a 250k-row batch (10M nonzeros) element by element against the
+    multi-threaded oracle, plus size-independent identities computed outside the backward, (3) bit-identical
+    repeats and chunked == whole backward, (4) the dense-hot-block and plain layouts agreeing with each
+    other and with the oracle."""
     import ctypes as C
     import torch
     from sparkfm_amd import _ffi, synth
@@ -725,7 +736,7 @@ def test_full_size_properties(fmhip, config):
             ds = fmhip.DataSet.from_arrays(d, batch_rows=br).cache()
         finally:
             L.fmhip_tune(5, 1)
-        fm = fmhip.FMModel(n1 - 1, k)
+        fm = fmhip.FMModel(n1 - 1, k, stream=torch_stream())
         fm.w0, fm.w, fm.v = w0, w, v
         return ds, fm
 
@@ -755,6 +766,10 @@ def test_full_size_properties(fmhip, config):
     inter = yh[:br] - w0 - lin                                         # 0.5 * sum_f (q_f^2 - s_f)
     # Euler: the interaction is homogeneous of degree 2 in V, so sum_i <v_i, dL/dv_i> = sum_r e_r * 2 * inter_r
     assert float((gv * v).sum()) == pytest.approx(float((e * 2.0 * inter).sum()), rel=2e-3, abs=1e-2)
+    # ... and every element of G_V / G_w against the oracle's gradient of the same batch
+    ogv, ogw, og0, osse, _ = oracle.batch_grad(w0, w, v, 0, br, row_ptr, col, val, y, threads=min(oracle.max_threads(), 16))
+    check_grad(gv, gw, ogv, ogw, np.abs(v).max())
+    assert g0 == pytest.approx(og0, rel=1e-4, abs=1e-2) and st["sse"] == pytest.approx(osse, rel=1e-5)
     # (3) determinism and chunked == whole, bit for bit
     gv2, gw2, _, _ = fm.batchGradient(ds, 0)
     np.testing.assert_array_equal(gv, gv2)
@@ -777,6 +792,7 @@ def test_full_size_properties(fmhip, config):
     ds_p, fm_p = build(0)
     gv_p, gw_p, g0_p, st_p = fm_p.batchGradient(ds_p, 0)
     check_grad(gv, gw, gv_p, gw_p, np.abs(v).max())
+    check_grad(gv_p, gw_p, ogv, ogw, np.abs(v).max())
     assert st_p["sse"] == pytest.approx(st["sse"], rel=1e-6)
     # and training moves the loss the same way on both
     for m_, d_ in ((fm, ds), (fm_p, ds_p)):
@@ -810,11 +826,22 @@ def test_fit_loop_like_the_reference(fmhip):
     assert np.linalg.norm(fm.v - v) <= 1e-4 * np.linalg.norm(v)
 
 
-def test_random_shapes_property(fmhip):
+@pytest.mark.parametrize("flat", [0, 1])
+def test_random_shapes_property(fmhip, flat):
     """Property test over random shapes (hypothesis-style, fixed seeds so the GPU box runs the same
-    cases): rows/features/k/batch size/row-length law vary; GPU gradient and one SGD epoch vs the oracle."""
+    cases): rows/features/k/batch size/row-length law vary; GPU gradient and one SGD epoch vs the oracle.
+    flat=1 repeats it on the flat-address forward and the plain backward walk (fmhip_tune key 8) — the
+    kernels that tables of 4 GiB and more select."""
     from sparkfm_amd import _ffi
     L = _ffi.load()
+    L.fmhip_tune(8, flat)
+    try:
+        _random_shapes(fmhip, L)
+    finally:
+        L.fmhip_tune(8, 0)
+
+
+def _random_shapes(fmhip, L):
     rng = np.random.default_rng(20261003)
     for case in range(40):
         k = int(rng.choice([1, 2, 5, 8, 13, 16, 32, 40, 64]))
@@ -892,9 +919,10 @@ def test_two_ranks_on_one_gpu(fmhip, tmp_path, overlap, k):
     assert float(r0["w0"]) == float(r1["w0"])
     if overlap:
         assert list(r0["cuts"]) == list(r1["cuts"]) and r0["cuts"][0] == 0 and r0["cuts"][-1] == 800 and len(r0["cuts"]) == 3
-    # oracle: global batch j = rank0's batch j  U  rank1's batch j (rank 1 has 3 batches, rank 0 has 3)
+    # oracle: global batch j = rank0's batch j  U  rank1's batch j (rank 0 has 3 batches, rank 1 only 2: in the
+    # last step of every epoch it contributes a zero gradient — HipEngine.compute_empty)
     shards = [synth.make_zipf(77, 3000, 800, 4, 24, zipf_s=1.05, row_begin=0),
-              synth.make_zipf(77, 2200, 800, 4, 24, zipf_s=1.05, row_begin=3000)]
+              synth.make_zipf(77, 1700, 800, 4, 24, zipf_s=1.05, row_begin=3000)]
     w0, w, v = synth.init_params(5, 800, k, stdev=0.05)
     w = np.random.default_rng(9).normal(0, 0.05, 800)
     for _ in range(2):

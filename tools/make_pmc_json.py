@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 runs of tools/profile_round.sh into the two committed records:
+
+    python tools/make_pmc_json.py <tag> <config> <k> <batch_rows>  ->  profiles/<tag>_summary.txt
+                                                                     profiles/pmc_traffic.json (entries of this config replaced)
+
+Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are KiB of
+fabric-side requests (Infinity-Cache hits included); on gfx950 FETCH_SIZE counts a 128-B request of a wide
+(16 B per lane) coalesced read as 64 B.  The row gathers and the hot block's streams are 16-B-per-lane reads, the
+4-B index/value streams are not, and the counter cannot tell them apart: both the raw figure and the doubled one
+are recorded, `traffic_bytes` = doubled reads + writes is the UPPER bound used as `traffic`.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    m = re.search(r"(k_[a-z_0-9]+)(<[^>]*>)?", name)
+    return (m.group(1), (m.group(1) + (m.group(2) or ""))) if m else (None, name[:40])
+
+
+def load_pmc(tag, name, skip):
+    files = glob.glob(os.path.join(ROOT, "gpurun_out", "%s_%s" % (tag, name), "**", "*counter_collection.csv"), recursive=True)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    full = {}
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            base, fn = short(r["Kernel_Name"])
+            if base:
+                agg[base][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                full[base] = fn
+    out = {}
+    for kn, cs in agg.items():
+        out[kn] = {cn: sum(v[skip:]) / max(len(v[skip:]), 1) for cn, v in cs.items()}
+    return out, full
+
+
+def main():
+    tag, config, k, batch_rows = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    skip = 4
+    lines = []
+    stats = glob.glob(os.path.join(ROOT, "gpurun_out", tag + "_stats", "**", "*kernel_stats.csv"), recursive=True)
+    durations = {}
+    if stats:
+        lines.append("# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-extra --steps 12 --warmup 4   (durations in us)")
+        lines.append("%-44s %6s %10s %10s %10s %7s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct"))
+        for r in csv.DictReader(open(stats[0])):
+            base, fn = short(r["Name"])
+            lines.append("%-44s %6s %10.2f %10.2f %10.2f %7s" % (fn, r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3,
+                                                              float(r["MaxNs"]) / 1e3, r["Percentage"]))
+            if base:
+                durations[base] = float(r["AverageNs"]) / 1e3
+    fetch, full = load_pmc(tag, "fetch", skip)
+    write, _ = load_pmc(tag, "write", skip)
+    l2, _ = load_pmc(tag, "l2", skip)
+    sq, _ = load_pmc(tag, "sq", skip)
+    lines.append("")
+    lines.append("# rocprofv3 --pmc, one pass per group (mean per dispatch after the first %d dispatches of each kernel)" % skip)
+    entries = []
+    for kn in sorted(set(fetch) | set(write) | set(l2)):
+        fr = fetch.get(kn, {}).get("FETCH_SIZE")
+        wr = write.get(kn, {}).get("WRITE_SIZE")
+        hit = miss = None
+        if kn in l2:
+            hit, miss = l2[kn].get("TCC_HIT_sum"), l2[kn].get("TCC_MISS_sum")
+        h = hit / max(hit + miss, 1.0) if hit is not None and miss is not None else None
+        parts = []
+        if fr is not None:
+            parts.append("FETCH_SIZE=%.0f KiB (read %.1f MB raw, %.1f MB x2)" % (fr, fr * 1024 / 1e6, 2 * fr * 1024 / 1e6))
+        if wr is not None:
+            parts.append("WRITE_SIZE=%.0f KiB (%.1f MB)" % (wr, wr * 1024 / 1e6))
+        if h is not None:
+            parts.append("TCC_HIT=%.0f TCC_MISS=%.0f L2_hit=%.3f" % (hit, miss, h))
+        if kn in sq:
+            parts.append(" ".join("%s=%.3g" % (c, v) for c, v in sorted(sq[kn].items())))
+        lines.append("%-44s %s" % (full.get(kn, kn), " | ".join(parts)))
+        if fr is not None and wr is not None:
+            ent = {"config": config, "k": k, "batch_rows": batch_rows, "kernel": kn.replace("k_forward_wt", "k_forward").replace("k_backward_p", "k_backward").replace("k_apply_rows", "k_apply"),
+                   "kernel_instance": full.get(kn, kn), "fetch_raw_bytes": int(fr * 1024), "fetch_corrected_bytes": int(2 * fr * 1024),
+                   "write_bytes": int(wr * 1024), "traffic_bytes": int(2 * fr * 1024 + wr * 1024), "l2_hit": h,
+                   "avg_us_kernel_trace": durations.get(kn),
+                   "correction": "x2 applied to ALL fetches (upper bound: the 4-B index/value streams may not need it)",
+                   "source": "profiles/%s_summary.txt" % tag}
+            entries.append(ent)
+    out_txt = os.path.join(ROOT, "profiles", "%s_summary.txt" % tag)
+    open(out_txt, "w").write("\n".join(lines) + "\n")
+    pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        old = json.load(open(pj))
+    except (OSError, ValueError):
+        old = {"entries": []}
+    keep = [e for e in old.get("entries", []) if (e.get("config"), e.get("k"), e.get("batch_rows")) != (config, k, batch_rows)]
+    step = {"config": config, "k": k, "batch_rows": batch_rows, "kernel": "step",
+            "traffic_bytes": sum(e["traffic_bytes"] for e in entries), "source": "profiles/%s_summary.txt" % tag}
+    doc = {"_comment": "Fabric-side traffic per launch from rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE and TCC_HIT/MISS in separate passes; "
+                       "tools/profile_round.sh + tools/make_pmc_json.py). FETCH_SIZE is in KiB and doubled per the gfx950 wide-read "
+                       "correction of MI355X_MICROARCH.md (upper bound); Infinity-Cache hits are counted too, so this is NOT an HBM "
+                       "byte count for cache-resident tables. bench.py copies traffic_bytes into roofline.traffic and l2_hit into the "
+                       "kernels' ceilings; counters cannot be collected from inside bench.py.",
+           "entries": keep + entries + [step]}
+    json.dump(doc, open(pj, "w"), indent=1)
+    print(open(out_txt).read())
+
+
+if __name__ == "__main__":
+    main()
