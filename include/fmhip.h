@@ -236,20 +236,25 @@ int fmhip_step_stats(fmhip_model_t m, fmhip_stats *stats);
  *   each rank: fmhip_comm_create(m, id, rank, world, &c)
  *              fmhip_dp_epoch(m, d, c, ...)  or  fmhip_dp_step(m, d, batch, c, ...) in lock-step
  *
- * A step: forward of this rank's mini-batch; backward of the cold (high-id) feature interval; its slice
- * of the packed gradient is all-reduced on a second stream while the hot interval's backward runs; the
- * rest (head + hot interval) follows; every rank applies the identical update with |B| = the summed row
- * count, so the replicas stay bit-identical.  `batch` < 0: this rank has run out of rows and contributes
- * zeros.  All ranks must call with the same (eta, reg*) and the same cut (fmhip_dp_plan). */
+ * A step: forward of this rank's mini-batch; backward of the coldest (highest-id) feature interval; its
+ * slice of the packed gradient is all-reduced on a second stream while the next interval's backward runs;
+ * the last message carries the head with the hottest interval; every rank applies the identical update
+ * with |B| = the summed row count, so the replicas stay bit-identical.  `batch` < 0: this rank has run
+ * out of rows and contributes zeros.  All ranks must call with the same (eta, reg*) and the same cuts
+ * (fmhip_dp_plan). */
 #define FMHIP_UNIQUE_ID_BYTES 128
 int fmhip_comm_unique_id(void *id /* FMHIP_UNIQUE_ID_BYTES out */);
 int fmhip_comm_create(fmhip_model_t m, const void *id, int rank, int world, fmhip_comm_t *out);
 int fmhip_comm_destroy(fmhip_comm_t c);
 int fmhip_comm_info(fmhip_comm_t c, int *rank, int *world);
-/* Chooses the feature id that cuts the backward in two (about `upper_fraction` of rank 0's stored
- * nonzeros lie at or above it; <= 0: no cut, one all-reduce after the whole backward) and broadcasts
- * it from rank 0.  Collective.  cut (nullable) receives the id (0 = no cut). */
-int fmhip_dp_plan(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double upper_fraction, int64_t *cut);
+/* Chooses the feature ids that cut the backward into intervals and broadcasts them from rank 0 (collective).
+ * upper_fractions[i], ascending: the share of rank 0's stored nonzeros that lies at or above cut i — e.g.
+ * {0.25} = two intervals, the first (ids >= cut) a quarter of the work and nearly all of the gradient's
+ * bytes; {0.15, 0.5} = three.  n_fractions = 0: whole backward, one all-reduce.  cuts (nullable, room for
+ * n_fractions): the ids chosen, first cut first (0 = that cut collapsed). */
+#define FMHIP_DP_MAX_CUTS 7
+int fmhip_dp_plan(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, int n_fractions, const double *upper_fractions,
+                  int64_t *cuts);
 int fmhip_dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0,
                   double regw, double regv);
 /* max over ranks of the local batch count steps, ascending batches; stats (nullable) = the GLOBAL

@@ -131,7 +131,7 @@ def load():
     L.fmhip_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, P(vp)]
     L.fmhip_comm_destroy.argtypes = [vp]
     L.fmhip_comm_info.argtypes = [vp, P(C.c_int), P(C.c_int)]
-    L.fmhip_dp_plan.argtypes = [vp, vp, vp, dbl, P(i64)]
+    L.fmhip_dp_plan.argtypes = [vp, vp, vp, C.c_int, vp, vp]
     L.fmhip_dp_step.argtypes = [vp, vp, i64, vp, dbl, dbl, dbl, dbl]
     L.fmhip_dp_epoch.argtypes = [vp, vp, vp, dbl, dbl, dbl, dbl, P(Stats)]
     L.fmhip_comm_profile_begin.argtypes = [vp]

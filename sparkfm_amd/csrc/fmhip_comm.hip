@@ -15,6 +15,7 @@
 //   comm stream                                  | all-reduce(cold slice)         | all-reduce(head + hot slice)
 // The CSC stream is sorted by feature id, so the backward can deliver the gradient rows of an interval of
 // ids at a time; the cold interval is nearly all of the gradient's volume and under half of the work.
+// More cuts give a deeper pipeline (the collective of interval i runs beside the backward of interval i+1).
 #include "fmhip_internal.h"
 
 #include <dlfcn.h>
@@ -87,9 +88,11 @@ int need_rccl() {
             return fail(FMHIP_ERR_COMM, "%s failed: %s (%s:%d)", #expr, rccl().GetErrorString(_r), __FILE__, __LINE__); \
     } while (0)
 
+constexpr int kMaxCuts = 7;      // == FMHIP_DP_MAX_CUTS
+
 struct CommProf {
     hipEvent_t wait_a = nullptr, wait_b = nullptr;   // compute stream: around its wait for the last collective
-    hipEvent_t c0[2] = {nullptr, nullptr}, c1[2] = {nullptr, nullptr};   // comm stream: around each collective
+    hipEvent_t c0[kMaxCuts + 1] = {}, c1[kMaxCuts + 1] = {};   // comm stream: around each collective
     int n_coll = 0;
 };
 
@@ -99,9 +102,10 @@ struct fmhip_comm {
     int device = 0, rank = 0, world = 1;
     ncclComm_t comm = nullptr;
     hipStream_t cs = nullptr;                 // the collectives' stream
-    hipEvent_t ev_cold = nullptr, ev_hot = nullptr, ev_done = nullptr;
-    int64_t cut = 0;                          // feature id cutting the backward in two (0 = whole backward, one collective)
-    int64_t *scratch = nullptr;               // device int64[2] for the small control collectives
+    hipEvent_t ev_ready[kMaxCuts + 1] = {};   // compute stream: interval i of the gradient is final
+    hipEvent_t ev_done = nullptr;             // comm stream: the last collective has finished
+    std::vector<int64_t> cuts;                // ascending feature ids in (0, n+1) cutting the backward into intervals (empty: one collective)
+    int64_t *scratch = nullptr;               // device int64[kMaxCuts + 1] for the small control collectives
     bool profiling = false;
     std::vector<CommProf> prof;
     int64_t prof_bytes = 0;
@@ -110,8 +114,11 @@ struct fmhip_comm {
 namespace {
 
 void destroy_events(CommProf &p) {
-    for (hipEvent_t e : {p.wait_a, p.wait_b, p.c0[0], p.c0[1], p.c1[0], p.c1[1]})
+    for (hipEvent_t e : {p.wait_a, p.wait_b})
         if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i <= kMaxCuts; ++i)
+        for (hipEvent_t e : {p.c0[i], p.c1[i]})
+            if (e) (void)hipEventDestroy(e);
 }
 
 int check_comm(fmhip_model_t m, fmhip_comm_t c) {
@@ -153,16 +160,20 @@ int dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, d
         c->prof.emplace_back();
         pr = &c->prof.back();
     }
-    const int64_t cut = (c->cut > 0 && c->cut < m->n1 && d->rb_rows == 0) ? c->cut : 0;
-    if (cut > 0) {
-        if (live) TRY(step_backward(m, d, batch, cut, m->n1, false, nullptr));
-        TRY(reduce_slice(m, c, m->GV() + (size_t)cut * m->Kp, (size_t)(m->n1p - cut) * m->Kp, c->ev_cold, pr));
-        if (live) TRY(step_backward(m, d, batch, 0, cut, true, nullptr));
-        // the head (scalars | G_w | G_b) lies right in front of feature 0's row: one message with the hot interval
-        TRY(reduce_slice(m, c, m->grad, m->head_floats() + (size_t)cut * m->Kp, c->ev_hot, pr));
-    } else {
-        if (live) TRY(step_backward(m, d, batch, 0, INT64_MAX, true, nullptr));
-        TRY(reduce_slice(m, c, m->grad, m->grad_floats(), c->ev_hot, pr));
+    // intervals [cuts[i], cuts[i+1]) from the top down; the lowest one carries the head (scalars | G_w | G_b), which
+    // lies right in front of feature 0's row: one message
+    std::vector<int64_t> edge{0};
+    if (d->rb_rows == 0)
+        for (int64_t x : c->cuts)
+            if (x > edge.back() && x < m->n1) edge.push_back(x);
+    edge.push_back(m->n1);
+    for (size_t i = edge.size() - 1; i-- > 0;) {
+        const int64_t lo = edge[i], hi = edge[i + 1];
+        const bool last = i == 0, whole = edge.size() == 2;
+        if (live) TRY(step_backward(m, d, batch, lo, whole ? INT64_MAX : hi, last, nullptr));
+        const int64_t hi_rows = hi == m->n1 ? m->n1p : hi;      // the padding rows ride with the top interval
+        if (last) TRY(reduce_slice(m, c, m->grad, m->head_floats() + (size_t)hi_rows * m->Kp, c->ev_ready[i], pr));
+        else TRY(reduce_slice(m, c, m->GV() + (size_t)lo * m->Kp, (size_t)(hi_rows - lo) * m->Kp, c->ev_ready[i], pr));
     }
     m->bw_next_hi = -1;
     HIP_TRY(hipEventRecord(c->ev_done, c->cs));
@@ -177,11 +188,11 @@ int dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, d
 }
 
 // small control collectives (a count, a cut) through a device scratch word
-int control_i64(fmhip_model_t m, fmhip_comm_t c, int64_t *value, bool broadcast_from_0) {
-    HIP_TRY(hipMemcpyAsync(c->scratch, value, sizeof(int64_t), hipMemcpyHostToDevice, m->stream));
-    if (broadcast_from_0) NCCL_TRY(rccl().Broadcast(c->scratch, c->scratch, 1, ncclInt64, 0, c->comm, m->stream));
-    else NCCL_TRY(rccl().AllReduce(c->scratch, c->scratch, 1, ncclInt64, ncclMax, c->comm, m->stream));
-    HIP_TRY(hipMemcpyAsync(value, c->scratch, sizeof(int64_t), hipMemcpyDeviceToHost, m->stream));
+int control_i64(fmhip_model_t m, fmhip_comm_t c, int64_t *value, int count, bool broadcast_from_0) {
+    HIP_TRY(hipMemcpyAsync(c->scratch, value, count * sizeof(int64_t), hipMemcpyHostToDevice, m->stream));
+    if (broadcast_from_0) NCCL_TRY(rccl().Broadcast(c->scratch, c->scratch, (size_t)count, ncclInt64, 0, c->comm, m->stream));
+    else NCCL_TRY(rccl().AllReduce(c->scratch, c->scratch, (size_t)count, ncclInt64, ncclMax, c->comm, m->stream));
+    HIP_TRY(hipMemcpyAsync(value, c->scratch, count * sizeof(int64_t), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return FMHIP_OK;
 }
@@ -219,10 +230,9 @@ int fmhip_comm_create(fmhip_model_t m, const void *id, int rank, int world, fmhi
         return fail(FMHIP_ERR_COMM, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, rccl().GetErrorString(r));
     }
     hipError_t e = hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_cold, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_hot, hipEventDisableTiming);
+    for (int i = 0; i <= kMaxCuts && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_ready[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->scratch), 2 * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->scratch), (kMaxCuts + 1) * sizeof(int64_t));
     if (e != hipSuccess) {
         fmhip_comm_destroy(c);
         return fail(FMHIP_ERR_HIP, "communicator resources: %s", hipGetErrorString(e));
@@ -237,8 +247,9 @@ int fmhip_comm_destroy(fmhip_comm_t c) {
     if (c->cs) (void)hipStreamSynchronize(c->cs);
     for (auto &p : c->prof) destroy_events(p);
     if (c->comm) (void)rccl().CommDestroy(c->comm);
-    for (hipEvent_t e : {c->ev_cold, c->ev_hot, c->ev_done})
+    for (hipEvent_t e : c->ev_ready)
         if (e) (void)hipEventDestroy(e);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->cs) (void)hipStreamDestroy(c->cs);
     if (c->scratch) (void)hipFree(c->scratch);
     delete c;
@@ -252,13 +263,15 @@ int fmhip_comm_info(fmhip_comm_t c, int *rank, int *world) {
     return FMHIP_OK;
 }
 
-int fmhip_dp_plan(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double upper_fraction, int64_t *cut_out) {
+int fmhip_dp_plan(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, int n_fractions, const double *upper_fractions, int64_t *cuts_out) {
     TRY(check_comm(m, c));
     TRY(check_train(m, d));
-    int64_t cut = 0;
-    if (c->rank == 0 && upper_fraction > 0.0 && upper_fraction < 1.0 && d->rb_rows == 0) {
+    if (n_fractions < 0 || n_fractions > kMaxCuts || (n_fractions > 0 && !upper_fractions))
+        return fail(FMHIP_ERR_INVALID, "n_fractions must be 0..%d with an array of as many fractions", kMaxCuts);
+    int64_t cuts[kMaxCuts + 1] = {};
+    if (c->rank == 0 && n_fractions > 0 && d->rb_rows == 0) {
         // stored nonzeros per feature over this rank's batches (the sparse streams: the dense hot block's
-        // features do not depend on the interval), then the id above which `upper_fraction` of them lie
+        // features do not depend on the interval), then for every fraction the id above which that share lies
         std::vector<int32_t> cnt((size_t)m->n1, 0);
         int64_t total = 0;
         for (size_t b = 0; b < d->batches.size(); ++b) {
@@ -269,16 +282,21 @@ int fmhip_dp_plan(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double upp
                 total += hp[s + 1] - hp[s];
             }
         }
-        const double want = upper_fraction * (double)total;
-        int64_t above = 0;
-        for (int64_t f = m->n1 - 1; f > 0; --f) {
-            above += cnt[(size_t)f];
-            if ((double)above >= want) { cut = f; break; }
+        int64_t above = 0, f = m->n1 - 1;
+        for (int i = 0; i < n_fractions; ++i) {
+            const double want = std::min(std::max(upper_fractions[i], 0.0), 1.0) * (double)total;
+            while (f > 0 && (double)above < want) above += cnt[(size_t)f--];
+            cuts[i] = f + 1 < m->n1 ? f + 1 : 0;
         }
     }
-    TRY(control_i64(m, c, &cut, true));
-    c->cut = (cut > 0 && cut < m->n1) ? cut : 0;
-    if (cut_out) *cut_out = c->cut;
+    TRY(control_i64(m, c, cuts, kMaxCuts + 1, true));
+    c->cuts.clear();
+    for (int i = 0; i < n_fractions; ++i)
+        if (cuts[i] > 0 && cuts[i] < m->n1) c->cuts.push_back(cuts[i]);
+    std::sort(c->cuts.begin(), c->cuts.end());
+    c->cuts.erase(std::unique(c->cuts.begin(), c->cuts.end()), c->cuts.end());
+    if (cuts_out)
+        for (int i = 0; i < n_fractions; ++i) cuts_out[i] = i < (int)c->cuts.size() ? c->cuts[c->cuts.size() - 1 - (size_t)i] : 0;
     return FMHIP_OK;
 }
 
@@ -296,7 +314,7 @@ int fmhip_dp_epoch(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double et
     TRY(check_train(m, d));
     const int64_t nb = (int64_t)d->batches.size();
     int64_t steps = nb;     // every rank takes the same number of steps: the largest local batch count
-    TRY(control_i64(m, c, &steps, false));
+    TRY(control_i64(m, c, &steps, 1, false));
     for (int64_t j = 0; j < steps; ++j) TRY(dp_step(m, d, j < nb ? j : -1, c, eta, reg0, regw, regv));
     if (stats) {
         memset(stats, 0, sizeof *stats);

@@ -256,24 +256,27 @@ class RcclComm:
 class HipDataParallelSGD(FMLearn):
     """FMLearn whose `learn` runs one data-parallel epoch over this rank's row shard INSIDE the library:
     forward -> feature-chunked backward overlapped with the RCCL all-reduce -> identical update
-    (fmhip_dp_epoch).  `upper_fraction`: share of the stored nonzeros in the interval reduced first
-    (0 = no overlap: whole backward, one all-reduce)."""
+    (fmhip_dp_epoch).  `upper_fractions`: ascending shares of the stored nonzeros at or above each cut of
+    the backward — (0.3,) = two intervals, the first a third of the work and nearly all of the bytes;
+    () = no overlap: whole backward, one all-reduce."""
 
-    def __init__(self, comm, eta=0.05, reg0=0.0, regw=0.0, regv=0.0, upper_fraction=0.45):
+    def __init__(self, comm, eta=0.05, reg0=0.0, regw=0.0, regv=0.0, upper_fractions=(0.3,)):
         self.comm = comm
         self.eta, self.reg0, self.regw, self.regv = float(eta), float(reg0), float(regw), float(regv)
-        self.upper_fraction = float(upper_fraction)
-        self.cut = None
+        self.upper_fractions = tuple(float(f) for f in upper_fractions)
+        self.cuts = None
         self._planned_for = None
         self.last_stats = None
 
     def plan(self, fm, dataset):
-        """Collective: rank 0's data pick the cut, every rank receives it."""
-        cut = C.c_int64()
-        _ffi.check(_ffi.load().fmhip_dp_plan(fm.handle, dataset.handle, self.comm.handle, self.upper_fraction, C.byref(cut)))
-        self.cut = int(cut.value)
+        """Collective: rank 0's data pick the cuts, every rank receives them."""
+        import numpy as np
+        fr = np.ascontiguousarray(sorted(self.upper_fractions), np.float64)
+        cuts = np.zeros(max(len(fr), 1), np.int64)
+        _ffi.check(_ffi.load().fmhip_dp_plan(fm.handle, dataset.handle, self.comm.handle, len(fr), _ffi.ptr(fr), _ffi.ptr(cuts)))
+        self.cuts = [int(c) for c in cuts[:len(fr)] if c > 0]
         self._planned_for = id(dataset)
-        return self.cut
+        return self.cuts
 
     def step(self, fm, dataset, batch):
         """One global step; batch < 0: this rank contributes zeros."""

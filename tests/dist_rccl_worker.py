@@ -27,7 +27,7 @@ def main():
     dp = HipDataParallelSGD(comm, eta=0.05, regw=1e-3, regv=1e-3)
     for _ in range(2):
         dp.learn(fm, ds)
-    np.savez(out + ".%d.npz" % rank, w0=fm.w0, w=fm.w, v=fm.v, cut=dp.cut)
+    np.savez(out + ".%d.npz" % rank, w0=fm.w0, w=fm.w, v=fm.v, cuts=np.array(dp.cuts))
     dist.barrier()
     comm.close()
     dist.destroy_process_group()

@@ -273,7 +273,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("upper", [0.45, 0.0])
+@pytest.mark.parametrize("upper", [(0.45,), (), (0.1, 0.3, 0.6)])
 def test_library_side_exchange_one_rank(fmhip, upper):
     """fmhip_comm_create / fmhip_dp_plan / fmhip_dp_epoch with a world of ONE rank: RCCL is loaded, the
     communicator is built, both collectives of the overlapped schedule really run (in place, on the second
@@ -290,10 +290,11 @@ def test_library_side_exchange_one_rank(fmhip, upper):
         fm.w0, fm.w, fm.v = w0, w, v
         if mode == "dp":
             comm = RcclComm(fm, 0, 1)
-            dp = HipDataParallelSGD(comm, eta=0.05, regw=1e-3, regv=1e-3, upper_fraction=upper)
+            dp = HipDataParallelSGD(comm, eta=0.05, regw=1e-3, regv=1e-3, upper_fractions=upper)
             for _ in range(2):
                 dp.learn(fm, ds)
-            assert (dp.cut > 0) == (upper > 0) and dp.last_stats["rows"] == 500 and dp.last_stats["steps"] == 4
+            assert len(dp.cuts) == len(upper) and dp.cuts == sorted(dp.cuts, reverse=True)
+            assert dp.last_stats["rows"] == 500 and dp.last_stats["steps"] == 4
             comm.close()
         else:
             from sparkfm_amd import _ffi

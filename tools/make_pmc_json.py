@@ -64,7 +64,10 @@ def main():
     lines.append("")
     lines.append("# rocprofv3 --pmc, one pass per group (mean per dispatch after the first %d dispatches of each kernel)" % skip)
     entries = []
+    step_kernels = ("k_forward", "k_backward", "k_fixup", "k_apply")      # the SGD step; the dataset build's kernels are setup
     for kn in sorted(set(fetch) | set(write) | set(l2)):
+        if not kn.startswith(step_kernels):
+            continue
         fr = fetch.get(kn, {}).get("FETCH_SIZE")
         wr = write.get(kn, {}).get("WRITE_SIZE")
         hit = miss = None

@@ -19,3 +19,12 @@ run fetch --pmc FETCH_SIZE
 run write --pmc WRITE_SIZE
 run l2 --pmc TCC_HIT_sum TCC_MISS_sum
 run sq --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
+# the HBM-resident leg (C5 width) on its own
+if [ -z "$SKIP_C5" ]; then
+  BENCH="python3 $root/tools/run_c5_shape.py 16"
+  tag=${tag}_c5
+  run stats --kernel-trace --stats
+  run fetch --pmc FETCH_SIZE
+  run write --pmc WRITE_SIZE
+  run l2 --pmc TCC_HIT_sum TCC_MISS_sum
+fi
