@@ -1,0 +1,176 @@
+/*
+ * fmhip_jni.c — JNI shim between jvm/HipSGD.scala and libfmhip.so (include/fmhip.h).
+ *
+ * SOURCE ONLY: the build image has no JDK (no jni.h), so this file has never been compiled here.  It is
+ * deliberately nothing but marshalling: every function pins the Java arrays, calls ONE entry point of the
+ * C ABI with plain pointers and sizes, unpins, and turns a non-zero status into a RuntimeException that
+ * carries fmhip_last_error().  Build on a machine with a JDK:
+ *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude jvm/fmhip_jni.c \
+ *       -Lsparkfm_amd/lib -lfmhip -Wl,-rpath,'$ORIGIN' -o libfmhip_jni.so
+ * Scala `object HipSGD` natives are static methods of class io.edstud.spark.fm.lib.HipSGD$ ("_00024" = '$').
+ */
+#include <jni.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "fmhip.h"
+
+#define JNI_FN(name) JNICALL Java_io_edstud_spark_fm_lib_HipSGD_00024_##name
+#define H_MODEL(h) ((fmhip_model_t)(intptr_t)(h))
+#define H_DATA(h) ((fmhip_dataset_t)(intptr_t)(h))
+#define H_COMM(h) ((fmhip_comm_t)(intptr_t)(h))
+
+static void raise(JNIEnv *env, int rc) {
+    if (rc != FMHIP_OK)
+        (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/RuntimeException"), fmhip_last_error());
+}
+
+/* pinned views of the CSR arrays of one call (jlong == int64_t, jint == int32_t, jdouble == double) */
+typedef struct { jlong *rp; jint *col; jdouble *val; jdouble *y; } csr_pins;
+
+static void pin(JNIEnv *env, csr_pins *p, jlongArray rp, jintArray col, jdoubleArray val, jdoubleArray y) {
+    p->rp = (*env)->GetPrimitiveArrayCritical(env, rp, NULL);
+    p->col = col ? (*env)->GetPrimitiveArrayCritical(env, col, NULL) : NULL;
+    p->val = val ? (*env)->GetPrimitiveArrayCritical(env, val, NULL) : NULL;
+    p->y = y ? (*env)->GetPrimitiveArrayCritical(env, y, NULL) : NULL;
+}
+
+static void unpin(JNIEnv *env, csr_pins *p, jlongArray rp, jintArray col, jdoubleArray val, jdoubleArray y) {
+    if (p->y) (*env)->ReleasePrimitiveArrayCritical(env, y, p->y, JNI_ABORT);
+    if (p->val) (*env)->ReleasePrimitiveArrayCritical(env, val, p->val, JNI_ABORT);
+    if (p->col) (*env)->ReleasePrimitiveArrayCritical(env, col, p->col, JNI_ABORT);
+    (*env)->ReleasePrimitiveArrayCritical(env, rp, p->rp, JNI_ABORT);
+}
+
+JNIEXPORT jlong JNI_FN(modelCreate)(JNIEnv *env, jobject o, jint dev, jlong n, jint k) {
+    fmhip_model_t m = NULL;
+    raise(env, fmhip_model_create(dev, n, k, NULL, &m));
+    return (jlong)(intptr_t)m;
+}
+
+JNIEXPORT void JNI_FN(modelDestroy)(JNIEnv *env, jobject o, jlong h) { raise(env, fmhip_model_destroy(H_MODEL(h))); }
+
+JNIEXPORT void JNI_FN(setParams)(JNIEnv *env, jobject o, jlong h, jdouble w0, jdoubleArray w, jdoubleArray v) {
+    jdouble *pw = (*env)->GetPrimitiveArrayCritical(env, w, NULL);
+    jdouble *pv = (*env)->GetPrimitiveArrayCritical(env, v, NULL);
+    int rc = fmhip_model_set_params(H_MODEL(h), w0, pw, pv);
+    (*env)->ReleasePrimitiveArrayCritical(env, v, pv, JNI_ABORT);
+    (*env)->ReleasePrimitiveArrayCritical(env, w, pw, JNI_ABORT);
+    raise(env, rc);
+}
+
+JNIEXPORT void JNI_FN(getParams)(JNIEnv *env, jobject o, jlong h, jdoubleArray w0, jdoubleArray w, jdoubleArray v) {
+    jdouble *p0 = (*env)->GetPrimitiveArrayCritical(env, w0, NULL);
+    jdouble *pw = (*env)->GetPrimitiveArrayCritical(env, w, NULL);
+    jdouble *pv = (*env)->GetPrimitiveArrayCritical(env, v, NULL);
+    int rc = fmhip_model_get_params(H_MODEL(h), p0, pw, pv);
+    (*env)->ReleasePrimitiveArrayCritical(env, v, pv, 0);        /* 0: copy back */
+    (*env)->ReleasePrimitiveArrayCritical(env, w, pw, 0);
+    (*env)->ReleasePrimitiveArrayCritical(env, w0, p0, 0);
+    raise(env, rc);
+}
+
+JNIEXPORT jlong JNI_FN(datasetCreate)(JNIEnv *env, jobject o, jint dev, jlong n_rows, jlongArray rp, jintArray col,
+                                      jdoubleArray val, jdoubleArray y, jlong batch_rows) {
+    csr_pins p;
+    fmhip_dataset_t d = NULL;
+    pin(env, &p, rp, col, val, y);
+    int rc = fmhip_dataset_create(dev, n_rows, (const int64_t *)p.rp, (const int32_t *)p.col, p.val, p.y, batch_rows, &d);
+    unpin(env, &p, rp, col, val, y);
+    raise(env, rc);
+    return (jlong)(intptr_t)d;
+}
+
+JNIEXPORT jlong JNI_FN(rowsCreate)(JNIEnv *env, jobject o, jint dev, jlong n_rows, jlongArray rp, jintArray col,
+                                   jdoubleArray val, jdoubleArray y) {
+    csr_pins p;
+    fmhip_dataset_t d = NULL;
+    pin(env, &p, rp, col, val, y);
+    int rc = fmhip_rows_create(dev, n_rows, (const int64_t *)p.rp, (const int32_t *)p.col, p.val, p.y, &d);
+    unpin(env, &p, rp, col, val, y);
+    raise(env, rc);
+    return (jlong)(intptr_t)d;
+}
+
+JNIEXPORT void JNI_FN(datasetDestroy)(JNIEnv *env, jobject o, jlong h) { raise(env, fmhip_dataset_destroy(H_DATA(h))); }
+
+JNIEXPORT void JNI_FN(sgdEpoch)(JNIEnv *env, jobject o, jlong m, jlong d, jdouble eta, jdouble r0, jdouble rw, jdouble rv) {
+    raise(env, fmhip_sgd_epoch(H_MODEL(m), H_DATA(d), eta, r0, rw, rv, NULL, NULL));
+}
+
+JNIEXPORT jdouble JNI_FN(rmse)(JNIEnv *env, jobject o, jlong m, jlong d) {
+    double r = 0.0;
+    raise(env, fmhip_rmse(H_MODEL(m), H_DATA(d), &r, NULL));
+    return r;
+}
+
+JNIEXPORT void JNI_FN(predict)(JNIEnv *env, jobject o, jlong m, jlong d, jdoubleArray yhat) {
+    jdouble *py = (*env)->GetPrimitiveArrayCritical(env, yhat, NULL);
+    int rc = fmhip_predict(H_MODEL(m), H_DATA(d), py);
+    (*env)->ReleasePrimitiveArrayCritical(env, yhat, py, 0);
+    raise(env, rc);
+}
+
+JNIEXPORT void JNI_FN(predictRows)(JNIEnv *env, jobject o, jlong m, jlong n_rows, jlongArray rp, jintArray col,
+                                   jdoubleArray val, jdoubleArray yhat) {
+    csr_pins p;
+    pin(env, &p, rp, col, val, yhat);
+    int rc = fmhip_predict_rows(H_MODEL(m), n_rows, (const int64_t *)p.rp, (const int32_t *)p.col, p.val, p.y);
+    /* yhat is an output: copy back (mode 0), the inputs are released without a copy */
+    (*env)->ReleasePrimitiveArrayCritical(env, yhat, p.y, 0);
+    p.y = NULL;
+    unpin(env, &p, rp, col, val, NULL);
+    raise(env, rc);
+}
+
+JNIEXPORT jbyteArray JNI_FN(commUniqueId)(JNIEnv *env, jobject o) {
+    jbyte id[FMHIP_UNIQUE_ID_BYTES];
+    int rc = fmhip_comm_unique_id(id);
+    raise(env, rc);
+    if (rc != FMHIP_OK) return NULL;
+    jbyteArray a = (*env)->NewByteArray(env, FMHIP_UNIQUE_ID_BYTES);
+    if (a) (*env)->SetByteArrayRegion(env, a, 0, FMHIP_UNIQUE_ID_BYTES, id);
+    return a;
+}
+
+JNIEXPORT jlong JNI_FN(commCreate)(JNIEnv *env, jobject o, jlong m, jbyteArray id, jint rank, jint world) {
+    jbyte buf[FMHIP_UNIQUE_ID_BYTES];
+    fmhip_comm_t c = NULL;
+    if ((*env)->GetArrayLength(env, id) != FMHIP_UNIQUE_ID_BYTES) {
+        (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/IllegalArgumentException"), "unique id must be 128 bytes");
+        return 0;
+    }
+    (*env)->GetByteArrayRegion(env, id, 0, FMHIP_UNIQUE_ID_BYTES, buf);
+    raise(env, fmhip_comm_create(H_MODEL(m), buf, rank, world, &c));
+    return (jlong)(intptr_t)c;
+}
+
+JNIEXPORT void JNI_FN(commDestroy)(JNIEnv *env, jobject o, jlong h) { raise(env, fmhip_comm_destroy(H_COMM(h))); }
+
+JNIEXPORT void JNI_FN(dpPlan)(JNIEnv *env, jobject o, jlong m, jlong d, jlong c, jdoubleArray fractions) {
+    jsize n = (*env)->GetArrayLength(env, fractions);
+    jdouble f[FMHIP_DP_MAX_CUTS];
+    if (n > FMHIP_DP_MAX_CUTS) n = FMHIP_DP_MAX_CUTS;
+    (*env)->GetDoubleArrayRegion(env, fractions, 0, n, f);
+    raise(env, fmhip_dp_plan(H_MODEL(m), H_DATA(d), H_COMM(c), (int)n, f, NULL));
+}
+
+JNIEXPORT void JNI_FN(dpEpoch)(JNIEnv *env, jobject o, jlong m, jlong d, jlong c, jdouble eta, jdouble r0, jdouble rw,
+                               jdouble rv) {
+    raise(env, fmhip_dp_epoch(H_MODEL(m), H_DATA(d), H_COMM(c), eta, r0, rw, rv, NULL));
+}
+
+JNIEXPORT jlongArray JNI_FN(shardRows)(JNIEnv *env, jobject o, jlongArray rp, jint world, jint rank) {
+    jsize n = (*env)->GetArrayLength(env, rp);
+    jlong *p = (*env)->GetPrimitiveArrayCritical(env, rp, NULL);
+    int64_t lo = 0, hi = 0;
+    int rc = fmhip_shard_rows((int64_t)n - 1, (const int64_t *)p, world, rank, &lo, &hi);
+    (*env)->ReleasePrimitiveArrayCritical(env, rp, p, JNI_ABORT);
+    raise(env, rc);
+    if (rc != FMHIP_OK) return NULL;
+    jlong out[2];
+    out[0] = lo; out[1] = hi;
+    jlongArray a = (*env)->NewLongArray(env, 2);
+    if (a) (*env)->SetLongArrayRegion(env, a, 0, 2, out);
+    return a;
+}

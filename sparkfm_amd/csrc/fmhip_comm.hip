@@ -357,14 +357,16 @@ int fmhip_shard_rows(int64_t n_rows, const int64_t *row_ptr, int world, int rank
     if (!row_ptr || !lo || !hi) return fail(FMHIP_ERR_INVALID, "NULL argument");
     if (n_rows < 0 || world < 1 || rank < 0 || rank >= world) return fail(FMHIP_ERR_INVALID, "bad shard request (rows %lld, rank %d of %d)", (long long)n_rows, rank, world);
     const int64_t nnz = row_ptr[n_rows];
-    // boundary r of rank i: the first row whose offset reaches i/world of the stored nonzeros; datasets
-    // without nonzeros fall back to row counts
+    // boundary of rank i: the row offset NEAREST to i/world of the stored nonzeros (so one giant row does
+    // not drag every row before it into the same shard); datasets without nonzeros fall back to row counts
     auto bound = [&](int i) -> int64_t {
         if (i <= 0) return 0;
         if (i >= world) return n_rows;
         if (nnz == 0) return n_rows * i / world;
         const int64_t target = (int64_t)((__int128)nnz * i / world);
-        return std::lower_bound(row_ptr, row_ptr + n_rows + 1, target) - row_ptr;
+        int64_t r = std::lower_bound(row_ptr, row_ptr + n_rows + 1, target) - row_ptr;
+        if (r > 0 && (r > n_rows || target - row_ptr[r - 1] < row_ptr[r] - target)) --r;
+        return r;
     };
     *lo = std::min(bound(rank), n_rows);
     *hi = std::min(std::max(bound(rank + 1), *lo), n_rows);

@@ -1,0 +1,56 @@
+/*
+ * c_abi_smoke.c — a plain-C99 consumer of include/fmhip.h, compiled with `gcc -std=c99 -Iinclude` and
+ * linked against libfmhip.so by tests/test_host_cpu.py: proves the header is C (not just C++) and that
+ * the entry points that need no GPU behave (status codes, fmhip_last_error, host-side sharding).
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "fmhip.h"
+
+#define CHECK(cond)                                                       \
+    do {                                                                  \
+        if (!(cond)) { fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } \
+    } while (0)
+
+int main(void) {
+    fmhip_model_t m = NULL;
+    fmhip_dataset_t d = NULL;
+    fmhip_stats st;
+    fmhip_profile pr;
+    fmhip_comm_profile cp;
+    int64_t row_ptr[6] = {0, 100, 101, 102, 103, 400};
+    int64_t bad_ptr[3] = {0, 2, 1};
+    int64_t lo = -1, hi = -1, covered = 0;
+    int r;
+
+    memset(&st, 0, sizeof st);
+    memset(&pr, 0, sizeof pr);
+    memset(&cp, 0, sizeof cp);
+    CHECK(fmhip_version() == FMHIP_VERSION);
+    CHECK(sizeof(st.sse) == 8 && sizeof(pr.ms) == 8 * FMHIP_K_COUNT && sizeof(cp.exposed_ms) == 8);
+    /* argument validation happens before any device call */
+    CHECK(fmhip_model_create(0, 10, 4, NULL, NULL) == FMHIP_ERR_INVALID);
+    CHECK(fmhip_model_create(0, -1, 4, NULL, &m) == FMHIP_ERR_INVALID && m == NULL);
+    CHECK(fmhip_model_create(0, 10, FMHIP_MAX_FACTORS + 1, NULL, &m) == FMHIP_ERR_UNSUPPORTED);
+    CHECK(strstr(fmhip_last_error(), "FMHIP_MAX_FACTORS") != NULL);
+    CHECK(fmhip_dataset_create(0, 2, bad_ptr, NULL, NULL, NULL, 0, &d) == FMHIP_ERR_INVALID && d == NULL);
+    CHECK(strstr(fmhip_last_error(), "row_ptr decreases") != NULL);
+    CHECK(fmhip_rows_create(0, 2, bad_ptr, NULL, NULL, NULL, &d) == FMHIP_ERR_INVALID);
+    CHECK(fmhip_predict(NULL, NULL, NULL) == FMHIP_ERR_INVALID);
+    CHECK(fmhip_dp_step(NULL, NULL, 0, NULL, 0.1, 0, 0, 0) == FMHIP_ERR_INVALID);
+    CHECK(fmhip_comm_create(NULL, NULL, 0, 1, NULL) == FMHIP_ERR_INVALID);
+    CHECK(fmhip_model_destroy(NULL) == FMHIP_OK && fmhip_dataset_destroy(NULL) == FMHIP_OK && fmhip_comm_destroy(NULL) == FMHIP_OK);
+    /* nnz-balanced contiguous shards: rows 0 and 4 hold nearly everything */
+    for (r = 0; r < 3; ++r) {
+        CHECK(fmhip_shard_rows(5, row_ptr, 3, r, &lo, &hi) == FMHIP_OK);
+        CHECK(lo == covered && hi >= lo && hi <= 5);
+        covered = hi;
+    }
+    CHECK(covered == 5);
+    CHECK(fmhip_shard_rows(5, row_ptr, 3, 0, &lo, &hi) == FMHIP_OK && lo == 0 && hi == 4);   /* 103 of 400 nonzeros is nearest to a third */
+    CHECK(fmhip_shard_rows(5, row_ptr, 0, 0, &lo, &hi) == FMHIP_ERR_INVALID);
+    printf("c_abi_smoke ok (fmhip %d)\n", fmhip_version());
+    return 0;
+}

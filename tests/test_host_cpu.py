@@ -190,3 +190,46 @@ def test_split_by_random():
     assert c3.validationSet.size > 0 and c3.trainingSet.size + c3.testSet.size + c3.validationSet.size == 2000
     with pytest.raises(Exception, match="required"):
         DataCollection.splitByRandom(ds, 0.0, 1.0)
+
+
+def test_plain_c_consumer_of_the_header(tmp_path):
+    """include/fmhip.h is C, not just C++: tests/c_abi_smoke.c compiles as strict C99, links against
+    libfmhip.so and exercises the entry points that need no GPU."""
+    import subprocess
+    from sparkfm_amd import _build
+    exe = str(tmp_path / "c_abi_smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_abi_smoke.c"), "-L" + _build.LIBDIR, "-lfmhip",
+                           "-Wl,-rpath," + _build.LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.check_output([exe]).decode()
+    assert "c_abi_smoke ok" in out
+
+
+def test_nnz_balanced_shards():
+    """fmhip_shard_rows: contiguous, covering, balanced by stored nonzeros — on skewed rows a
+    row-count split would be badly off."""
+    from sparkfm_amd.distributed import shard_rows
+    rng = np.random.default_rng(5)
+    lens = np.where(rng.random(20000) < 0.01, rng.integers(500, 3000, 20000), rng.integers(0, 10, 20000))
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    for world in (1, 2, 3, 8):
+        sh = [shard_rows(rp, r, world) for r in range(world)]
+        assert sh[0][0] == 0 and sh[-1][1] == 20000
+        assert all(sh[i][1] == sh[i + 1][0] for i in range(world - 1))
+        nnz = np.array([rp[b] - rp[a] for a, b in sh], np.float64)
+        assert nnz.max() - nnz.min() <= 2 * lens.max()                  # within a row or two of perfect balance
+    assert shard_rows(100, 1, 4) == (25, 50)                            # a bare row count: balanced by rows
+    assert [shard_rows(np.zeros(7, np.int64), r, 3) for r in range(3)] == [(0, 2), (2, 4), (4, 6)]
+
+
+def test_bench_without_a_launcher_fails_cleanly_when_ranks_cannot_start():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset spawns the ranks itself; in this container they die at
+    once (no GPU) and the parent must report that — not hang waiting on a collective."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
+    import torch
+    if not torch.cuda.is_available():
+        assert p.returncode != 0 and p.stdout.strip() == b""
