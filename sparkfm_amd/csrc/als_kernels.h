@@ -15,6 +15,10 @@ struct AlsArgs {
     const int32_t *col;
     const double *val;
     const double *y;
+    // the same rows with every row's entries sorted by feature id (stable): the per-row order in which the
+    // reference's transposed q pass (S/fm/lib/ALS.scala:146-150) adds a row's terms
+    const int32_t *scol;
+    const double *sval;
     // transpose (compressed columns of the single batch) — fp64 values
     int32_t n_cols;
     const int32_t *cfeat;
@@ -24,7 +28,8 @@ struct AlsArgs {
     // fp64 parameters, reference layout v[f + i*k]
     double *w0, *w, *v;
     double reg0, regw, regv;
-    // workspace
+    // workspace: e[n_rows]; q[n_rows * k] (the LDS sweep takes every factor's q from an up-front pass; the
+    // fallback sweep uses the first n_rows)
     double *e, *q;
 };
 

@@ -6,8 +6,13 @@
 // workgroup; the parallelism is inside a column (its entries are spread over the 1024 threads,
 // sums are tree-reduced in a fixed order).  All arithmetic is fp64 without fma contraction — the
 // reference runs on the JVM, which never fuses — so an epoch tracks the fp64 oracle to ~1e-13.
-// This is a fidelity path (the reference's `fit`), not a throughput path: ~3 barriers per
-// (feature, factor).
+// Two sweeps:
+//  * k_als_sweep_lds — residuals e and the factor's q live in LDS (n_rows * 16 B <= 160,000 B: BASELINE config 1's
+//    10,000 rows fill it exactly); ONE wave walks the columns (a column of ~100 entries is two wave-iterations: no
+//    workgroup barrier per feature, wave sums by DPP row reductions), the next column's entries are prefetched
+//    while the current one is reduced; the other waves compute q per factor from the feature-sorted rows.
+//  * k_als_sweep — the general fallback: e, q in global memory, columns spread over the whole workgroup,
+//    ~3 barriers per (feature, factor).
 #include "als_kernels.h"
 
 namespace fmhip {
@@ -158,6 +163,193 @@ __global__ __launch_bounds__(kAlsBlock) void k_als_sweep(AlsArgs a) {
     }
 }
 
+
+// precomputeTermQ (S/fm/lib/ALS.scala:146-150) of EVERY factor before the sweeps, on the whole chip: q_f only
+// reads v[f, :], which nothing modifies before factor f's own sweep.  One thread per (row, factor); a row's terms
+// are added in ascending feature order (the feature-sorted copy of the rows) — the order of the reference's
+// transposed pass.  qall[f * n_rows + r].
+__global__ __launch_bounds__(256) void k_als_q_all(AlsArgs a, double *qall) {
+#pragma clang fp contract(off)
+    const int64_t total = a.n_rows * a.k;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t r = idx / a.k;
+        const int f = (int)(idx % a.k);
+        double qv = 0.0;
+        for (int64_t p = a.row_ptr[r]; p < a.row_ptr[r + 1]; ++p) qv += a.v[f + (int64_t)a.scol[p] * a.k] * a.sval[p];
+        qall[(int64_t)f * a.n_rows + r] = qv;
+    }
+}
+
+// ---- LDS-resident sweep -------------------------------------------------------------------------------
+constexpr int kLdsSweepThreads = 1024;
+constexpr size_t kAlsLdsBytes = 160000;     // e + q of at most 10,000 rows (the static reduction scratch fits beside it)
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// sum over the 64 lanes, identical in every lane; fixed order: quad butterfly, half-row and row mirrors on
+// the vector ALU (DPP), then the four row sums through scalar registers
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma clang fp contract(off)
+    v += dpp_f64<0xB1>(v);     // quad_perm:[1,0,3,2]
+    v += dpp_f64<0x4E>(v);     // quad_perm:[2,3,0,1]
+    v += dpp_f64<0x141>(v);    // row_half_mirror
+    v += dpp_f64<0x140>(v);    // row_mirror
+    double r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        r[i] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * i), __builtin_amdgcn_readlane(__double2loint(v), 16 * i));
+    return (r[0] + r[1]) + (r[2] + r[3]);
+}
+
+// The first 128 entries of a column as one wave holds them: lane l has entries l and 64 + l (raw CSC words: bit 31 of
+// a row word still carries the column-start flag).  Loaded a step ahead, at clamped addresses and without touching the
+// values, so that the requests stay in flight across the step (a mask or a branch on a loaded value makes the
+// compiler wait for it on the spot).
+struct ColHead {
+    uint32_t r0, r1;
+    double x0, x1;
+};
+
+__device__ __forceinline__ ColHead load_head(const AlsArgs &a, int c0, int lane) {
+    const int64_t last = a.nnz - 1;
+    const int64_t p0 = (int64_t)c0 + lane < last ? (int64_t)c0 + lane : last;
+    const int64_t p1 = (int64_t)c0 + 64 + lane < last ? (int64_t)c0 + 64 + lane : last;
+    ColHead h;
+    h.r0 = a.crow[p0];
+    h.r1 = a.crow[p1];
+    h.x0 = a.cval[p0];
+    h.x1 = a.cval[p1];
+    return h;
+}
+
+// One closed-form step on column [c0, c1) by ONE wave (S/fm/lib/ALS.scala:36-43 linear, :52-68 factor):
+// h_r, the sums sum h^2 / sum e*h, theta*, then e += h*(theta* - theta) (and q += x*(theta* - theta)).
+// The first two wave-iterations of the column (<= 128 entries: every column of config 1) stay in registers
+// between the sums and the update — e and q are read from LDS once; `head` arrives prefetched and leaves holding
+// the next column's.
+template <bool FACTOR>
+__device__ __forceinline__ double column_step(const AlsArgs &a, double *e, double *q, int c0, int c1, double theta, double reg,
+                                              ColHead &head, int lane) {
+#pragma clang fp contract(off)
+    const int n = c1 - c0;
+    const ColHead next = load_head(a, c1, lane);                    // in flight while this column is reduced
+    const bool v0 = lane < n, v1 = 64 + lane < n;
+    const uint32_t ra = v0 ? head.r0 & 0x7fffffffu : 0u, rb = v1 ? head.r1 & 0x7fffffffu : 0u;
+    const double xa = head.x0, xb = head.x1;
+    const double ea = e[ra], eb = e[rb];
+    const double qa = FACTOR ? q[ra] : 0.0, qb = FACTOR ? q[rb] : 0.0;
+    double ha = FACTOR ? xa * qa - xa * xa * theta : xa;            // :56-58 / :40
+    double hb = FACTOR ? xb * qb - xb * xb * theta : xb;
+    ha = v0 ? ha : 0.0;
+    hb = v1 ? hb : 0.0;
+    double shs = 0.0, seh = 0.0;
+    shs += ha * ha;
+    seh += (v0 ? ea : 0.0) * ha;
+    shs += hb * hb;
+    seh += (v1 ? eb : 0.0) * hb;
+    for (int p = c0 + 128 + lane; p < c1; p += 64) {               // long columns: re-read in the update pass
+        const uint32_t r = a.crow[p] & 0x7fffffffu;
+        const double x = a.cval[p];
+        const double h = FACTOR ? x * q[r] - x * x * theta : x;
+        shs += h * h;
+        seh += e[r] * h;
+    }
+    shs = wave_sum(shs);
+    seh = wave_sum(seh);
+    const double tn = compute_theta(theta, reg, seh, shs);
+    const double d = tn - theta;
+    const bool upd = is_updatable(tn, theta);
+    if (v0) {
+        if (upd) e[ra] = ea + ha * d;                              // updateError :194-198
+        if (FACTOR) q[ra] = qa + xa * d;                           // :60-62
+    }
+    if (v1) {
+        if (upd) e[rb] = eb + hb * d;
+        if (FACTOR) q[rb] = qb + xb * d;
+    }
+    for (int p = c0 + 128 + lane; p < c1; p += 64) {
+        const uint32_t r = a.crow[p] & 0x7fffffffu;
+        const double x = a.cval[p];
+        if (upd) {
+            const double h = FACTOR ? x * q[r] - x * x * theta : x;
+            e[r] += h * d;
+        }
+        if (FACTOR) q[r] += x * d;
+    }
+    head = next;
+    return tn;
+}
+
+// The column walk of one pass (linear weights, or factor f) by wave 0.  Everything a step needs from global memory
+// is requested a step (the column's entries, theta) or two (its feature id and end offset) ahead, so the chain of a
+// step is LDS + vector ALU only.  Valid because a pass touches every parameter exactly once.
+template <bool FACTOR>
+__device__ __forceinline__ void walk_columns(const AlsArgs &a, double *e, double *q, int f, int lane) {
+    const int k = a.k, nc = a.n_cols;
+    if (nc < 1 || a.nnz < 1) return;
+    double *par = FACTOR ? a.v + f : a.w;                          // parameter of feature i: par[i * stride]
+    const int64_t stride = FACTOR ? k : 1;
+    const double reg = FACTOR ? a.regv : a.regw;
+    int c0 = a.cptr[0], c1 = a.cptr[1];
+    int64_t i_cur = a.cfeat[0], i_nx = a.cfeat[nc > 1 ? 1 : 0];
+    int c_nx1 = a.cptr[nc > 1 ? 2 : 1];
+    double th_cur = par[i_cur * stride];
+    ColHead head = load_head(a, c0, lane);
+    for (int s = 0; s < nc; ++s) {
+        const double th_nx = par[i_nx * stride];                   // step s+1's parameter
+        const int64_t i_nn = a.cfeat[s + 2 < nc ? s + 2 : nc - 1]; // step s+2's feature id and end offset (clamped, unconditional)
+        const int c_nn1 = a.cptr[s + 3 < nc ? s + 3 : nc];
+        if (i_cur < a.num_attribute) {                             // `0 until num_attribute`: slot n is never trained (quirk Q1)
+            const double tn = column_step<FACTOR>(a, e, q, c0, c1, th_cur, reg, head, lane);
+            if (lane == 0) par[i_cur * stride] = tn;               // :40 / :64
+        } else {
+            head = load_head(a, c1, lane);                         // skipped column: still hand the next column's head on
+        }
+        c0 = c1; c1 = c_nx1; c_nx1 = c_nn1;
+        i_cur = i_nx; i_nx = i_nn;
+        th_cur = th_nx;
+    }
+}
+
+__global__ __launch_bounds__(kLdsSweepThreads) void k_als_sweep_lds(AlsArgs a, const double *qall) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) double lds_eq[];
+    __shared__ double sh[2][kLdsSweepThreads / 64];
+    double *e = lds_eq, *q = lds_eq + a.n_rows;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool walker = tid < 64;                                  // wave 0 walks the columns
+    for (int64_t r = tid; r < a.n_rows; r += kLdsSweepThreads) e[r] = a.e[r];
+    __syncthreads();
+    // ---- global bias: drawGlobalBias :152-154 = computeTheta(w0, reg0, sum e, size)
+    {
+        double se = 0.0, dummy = 0.0;
+        for (int64_t r = tid; r < a.n_rows; r += kLdsSweepThreads) se += e[r];
+        block_sum2<kLdsSweepThreads>(se, dummy, sh);
+        const double w0 = *a.w0;
+        const double w0n = compute_theta(w0, a.reg0, se, (double)a.n_rows);
+        if (is_updatable(w0n, w0)) {
+            const double d = w0n - w0;
+            for (int64_t r = tid; r < a.n_rows; r += kLdsSweepThreads) e[r] = e[r] + d;
+        }
+        if (tid == 0) *a.w0 = w0n;
+        __syncthreads();
+    }
+    // ---- linear weights (:36-43)
+    if (walker) walk_columns<false>(a, e, q, 0, lane);
+    // ---- factors (:50-68): q of the factor comes in from the up-front pass, every thread copies its share
+    for (int f = 0; f < a.k; ++f) {
+        __syncthreads();
+        for (int64_t r = tid; r < a.n_rows; r += kLdsSweepThreads) q[r] = qall[(int64_t)f * a.n_rows + r];
+        __syncthreads();
+        if (walker) walk_columns<true>(a, e, q, f, lane);
+    }
+}
+
 }  // namespace
 
 hipError_t launch_als_epoch(const AlsArgs &a, hipStream_t s) {
@@ -167,6 +359,17 @@ hipError_t launch_als_epoch(const AlsArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(k_als_residual, dim3((unsigned)blocks), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (a.scol && (size_t)a.n_rows * 2 * sizeof(double) <= kAlsLdsBytes) {
+        // e and q fit the LDS of one CU: the one-wave column walk
+        e = hipFuncSetAttribute((const void *)k_als_sweep_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAlsLdsBytes);
+        if (e != hipSuccess) return e;
+        int64_t qb = (a.n_rows * a.k + 255) / 256;
+        if (qb > 4096) qb = 4096;
+        hipLaunchKernelGGL(k_als_q_all, dim3((unsigned)(qb < 1 ? 1 : qb)), dim3(256), 0, s, a, a.q);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_als_sweep_lds, dim3(1), dim3(kLdsSweepThreads), (size_t)a.n_rows * 2 * sizeof(double), s, a, a.q);
+        return hipGetLastError();
+    }
     // mean column length decides the workgroup size (a barrier over 4 waves is ~3x cheaper than over 16)
     const int64_t nnz = a.n_cols > 0 ? a.nnz : 0;
     if (a.n_cols > 0 && nnz / a.n_cols < 512) hipLaunchKernelGGL(k_als_sweep<256>, dim3(1), dim3(256), 0, s, a);

@@ -392,8 +392,30 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
         std::vector<double> val64((size_t)nnz), y64((size_t)n_rows);
         for (int64_t p = 0; p < nnz; ++p) val64[(size_t)p] = (double)val[p];
         for (int64_t r = 0; r < n_rows; ++r) y64[(size_t)r] = (double)y[r];
+        // feature-sorted copy of every row (stable: equal ids keep their stored order)
+        std::vector<int32_t> scol((size_t)nnz);
+        std::vector<double> sval((size_t)nnz);
+        std::vector<bool> dupv((size_t)T, false);
+        parallel_chunks(n_rows, T, [&](int t, int64_t lo, int64_t hi) {
+            std::vector<int32_t> idx;
+            bool dup = false;
+            for (int64_t r = lo; r < hi; ++r) {
+                const int64_t p0 = row_ptr[r], len = row_ptr[r + 1] - p0;
+                idx.resize((size_t)len);
+                for (int64_t j = 0; j < len; ++j) idx[(size_t)j] = (int32_t)j;
+                std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y2) { return col[p0 + x] < col[p0 + y2]; });
+                for (int64_t j = 0; j < len; ++j) {
+                    scol[(size_t)(p0 + j)] = col[p0 + idx[(size_t)j]];
+                    sval[(size_t)(p0 + j)] = val64[(size_t)(p0 + idx[(size_t)j])];
+                    if (j && scol[(size_t)(p0 + j)] == scol[(size_t)(p0 + j - 1)]) dup = true;
+                }
+            }
+            dupv[(size_t)t] = dup;
+        });
+        for (bool b : dupv) d->als_dup = d->als_dup || b;
         if ((rc = upload(d->val64, val64.data(), val64.size())) || (rc = upload(d->y64, y64.data(), y64.size())) ||
-            (rc = d->cval64.alloc((size_t)nnz))) {
+            (rc = d->cval64.alloc((size_t)nnz)) || (rc = upload(d->scol, scol.data(), scol.size())) ||
+            (rc = upload(d->sval64, sval.data(), sval.size()))) {
             delete d;
             return rc;
         }
@@ -1253,6 +1275,10 @@ int fmhip_als_epoch(fmhip_model_t m, fmhip_dataset_t d, double reg0, double regw
     if (d->batches.size() > 1 || (d->nnz > 0 && !d->val64.p))
         return fail(FMHIP_ERR_UNSUPPORTED, "ALS walks the whole-dataset transpose: create the dataset with batch_rows <= 0 "
                                            "(single batch, at most 2^27 stored nonzeros)");
+    if (d->rb_rows > 0) return fail(FMHIP_ERR_UNSUPPORTED, "ALS needs a dataset without row blocks (fmhip_tune key 3 = 0)");
+    if (d->als_dup)
+        return fail(FMHIP_ERR_UNSUPPORTED, "ALS: a row stores the same feature index twice; the column walk updates every row of a "
+                                           "column at once and needs the (row, feature) pairs to be distinct");
     if (!m->host64_fresh) {   // parameters last changed by fp32 SGD: start from their fp64 widening
         std::vector<double> w((size_t)m->n1), v((size_t)m->n1 * m->k);
         double w0 = 0.0;
@@ -1267,7 +1293,7 @@ int fmhip_als_epoch(fmhip_model_t m, fmhip_dataset_t d, double reg0, double regw
     TRY(m->als_w.ensure(n1));
     TRY(m->als_v.ensure(nv));
     TRY(m->als_e.ensure(nr));
-    TRY(m->als_q.ensure(nr));
+    TRY(m->als_q.ensure(nr * (size_t)m->k));
     HIP_TRY(hipMemcpyAsync(m->als_w0.p, &m->h_w0, sizeof(double), hipMemcpyHostToDevice, m->stream));
     HIP_TRY(hipMemcpyAsync(m->als_w.p, m->h_w.data(), n1 * sizeof(double), hipMemcpyHostToDevice, m->stream));
     HIP_TRY(hipMemcpyAsync(m->als_v.p, m->h_v.data(), nv * sizeof(double), hipMemcpyHostToDevice, m->stream));
@@ -1281,6 +1307,8 @@ int fmhip_als_epoch(fmhip_model_t m, fmhip_dataset_t d, double reg0, double regw
         a.row_ptr = d->row_ptr.p;
         a.col = d->col.p;
         a.val = d->val64.p;
+        a.scol = d->scol.p;
+        a.sval = d->sval64.p;
         a.y = d->y64.p;
         a.n_cols = bm.n_cols;
         a.cfeat = d->cfeat.p;

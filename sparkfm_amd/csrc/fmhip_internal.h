@@ -114,6 +114,11 @@ struct fmhip_dataset {
     // fp64 copies of the values (CSR order, CSC order) and labels for the fp64 ALS learner; kept only
     // for single-batch datasets of at most kAlsMaxNnz stored nonzeros
     DevBuf<double> val64, cval64, y64;
+    // ... and the rows with their entries sorted by feature id (the per-row order of the reference's transposed
+    // q pass); als_dup: some row stores a feature twice (the column walk updates a row once per step: refused)
+    DevBuf<int32_t> scol;
+    DevBuf<double> sval64;
+    bool als_dup = false;
 };
 
 struct fmhip_model {

@@ -347,3 +347,34 @@ def test_library_side_exchange_two_ranks():
             w0, w, v, _ = oracle.sgd_step(w0, w, v, 0, len(ys), np.array(rp, np.int64), np.concatenate(cols),
                                           np.concatenate(vals), np.array(ys), 0.05, 0.0, 1e-3, 1e-3)
     assert rel(r0["v"], v) <= 1e-5 and rel(r0["w"], w) <= 1e-5 and float(r0["w0"]) == pytest.approx(w0, rel=1e-5, abs=1e-7)
+
+
+@pytest.mark.parametrize("n_rows,n1,k", [(2000, 25, 3), (10000, 300, 4), (10001, 300, 2)])
+def test_als_sweeps_lds_and_fallback(fmhip, n_rows, n1, k):
+    """The two ALS sweeps against the oracle (S/fm/lib/ALS.scala:15-75): columns far longer than the 128 entries
+    the one-wave walk keeps in registers (25 features over 2000 rows), exactly the 10,000 rows whose e and q
+    fill the LDS, and one row more (falls back to the workgroup-wide sweep over global memory)."""
+    from helpers import random_problem
+    a = random_problem(900 + n_rows + k, n_rows, n1, k, 1, min(12, n1 - 1))
+    ds = fmhip.DataSet(a["row_ptr"], a["col"], a["val"], a["y"]).cache()
+    fm = fmhip.FMModel(n1 - 1, k)
+    fm.w0, fm.w, fm.v = a["w0"], a["w"], a["v"]
+    fm.reg0, fm.regw, fm.regv = 0.01, 0.1, 5.0
+    w0, w, v = a["w0"], a["w"], a["v"]
+    for _ in range(2):
+        fmhip.HipALS.run().learn(fm, ds)
+        w0, w, v = oracle.als_epoch(w0, w, v, 0.01, 0.1, 5.0, a["row_ptr"], a["col"], a["val"], a["y"])
+    np.testing.assert_allclose(fm.v, v, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(fm.w, w, rtol=1e-8, atol=1e-11)
+    assert fm.w0 == pytest.approx(w0, rel=1e-9, abs=1e-12)
+    ds.unpersist()
+    fm.close()
+
+
+def test_als_refuses_rows_with_a_repeated_feature(fmhip):
+    from sparkfm_amd import _ffi
+    ds = fmhip.DataSet.from_rows([(1.0, ([0, 2, 2], [1.0, 2.0, 0.5])), (0.0, ([1], [1.0]))]).cache()
+    fm = fmhip.FMModel(2, 2)
+    with pytest.raises(_ffi.FmhipError, match="twice"):
+        fmhip.HipALS.run().learn(fm, ds)
+    assert np.isfinite(fm.computeRMSE(ds))          # everything else accepts such rows
