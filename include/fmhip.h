@@ -110,6 +110,11 @@ int fmhip_device_count(int *count);
  *   key 9  lazy weight decay (1 = on, default): the fused step (fmhip_sgd_step / _epoch) updates only the
  *          rows a batch touched even with regw/regv > 0 — the decay of every row rides in a scale factor
  *          of the tables (fm_apply.hip); 0 = dense update whenever there is decay.  Equal up to fp32 rounding.
+ *   key 10 fused update (0 = off, default): 1 = the fused step applies every finished gradient row to its
+ *          parameter row inside the backward / fixup launches (no packed-gradient round trip, no update
+ *          launch) whenever the rows-only update is legal.  Bit-identical to the separate update launch;
+ *          off by default because the read-modify-write of the parameter row sits in the column walk's
+ *          dependent chain (C3: backward +20 us against 12 us of update launch saved).
  * Keys 3 and 5 are read by fmhip_dataset_create at the time of the call (they decide the layout of the
  * dataset being built and nothing else); every other key is read by the next launch. */
 int fmhip_tune(int key, int value);

@@ -16,15 +16,42 @@ __device__ __forceinline__ void store_row(float *dst, int l, const float4 (&acc)
     if (l == sl) { *dsa = sa; *dsb = sb; }   // sl: the lane whose scalar sums are the real ones
 }
 
-// A finished column piece goes to its destination: the G row of its feature when the feature has a
-// single piece in the batch, else a piece row that k_fixup2 sums per feature (row-blocked streams).
+// Fused update of parameter row i from its finished gradient (acc = G_V row, sa = G_w, sb = G_b; the scalars are
+// valid in lane sl of the slot): U_i <- U_i - eta_v*((G_V - (sv*U_i)*G_b)/|B|), w_i likewise — apply_piece<KP, true>
+// of fm_apply.hip, operation for operation.  pack_k >= 0: slot pack_k of the row is the linear weight.
+template <int LPN, int J>
+__device__ __forceinline__ void apply_row(const FusedUpd &u, int pack_k, int i, int l, const float4 (&acc)[J], float sa, float sb, int sl) {
+    constexpr int KP = 4 * LPN * J;
+    const float b = __shfl(sb, sl, LPN);
+    float4 *V4 = reinterpret_cast<float4 *>(u.V + (size_t)i * KP) + l;
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+        float4 x = V4[jj * LPN];
+        const float4 v = f4mul(x, u.sv), g = acc[jj];
+        const bool has_w = pack_k >= 0 && (l + jj * LPN) == (pack_k >> 2);
+        float wslot = 0.f;
+        if (has_w) wslot = f4pick(x, pack_k & 3) - u.eta_w * (f4pick(g, pack_k & 3) * u.invb);
+        x.x -= u.eta_v * ((g.x - v.x * b) * u.invb);
+        x.y -= u.eta_v * ((g.y - v.y * b) * u.invb);
+        x.z -= u.eta_v * ((g.z - v.z * b) * u.invb);
+        x.w -= u.eta_v * ((g.w - v.w * b) * u.invb);
+        if (has_w) f4set(x, pack_k & 3, wslot);
+        V4[jj * LPN] = x;
+    }
+    if (l == sl && pack_k < 0) u.w[i] = u.w[i] - u.eta_w * (sa * u.invb);
+}
+
+// A finished column piece goes to its destination: the G row of its feature (or, fused, straight into the
+// parameters) when the feature has a single piece in the batch, else a piece row that k_fixup2 sums per
+// feature (row-blocked streams).
 template <int LPN, int J>
 __device__ __forceinline__ void store_seg(const BwdArgs &a, int seg, int l, const float4 (&acc)[J], float sa, float sb,
                                           int sl = 0) {
     constexpr int KP = 4 * LPN * J;
     const int dst = a.cdst[seg];
     if (dst >= 0) {
-        store_row<LPN, J>(a.GV + (size_t)dst * KP, l, acc, sa, sb, a.Gw + dst, a.Gb + dst, sl);
+        if (a.upd.V) apply_row<LPN, J>(a.upd, a.pack_k, dst, l, acc, sa, sb, sl);
+        else store_row<LPN, J>(a.GV + (size_t)dst * KP, l, acc, sa, sb, a.Gw + dst, a.Gb + dst, sl);
     } else {
         float *pr = a.pieces + (size_t)(-1 - dst) * (KP + kPartPad);
         store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
@@ -151,15 +178,38 @@ __device__ __forceinline__ void hot_reduce_body(const HotArgs &a, int h, int kp)
         for (int b = g; b < a.nblk; b += G) f4add(t, reinterpret_cast<const float4 *>(a.part + ((size_t)b * kHotT + h) * PR)[f]);
     sh[threadIdx.x] = t;
     __syncthreads();
-    if (threadIdx.x < R4) {
-        float4 u = f4zero();
+    float4 u = f4zero();
+    if (threadIdx.x < R4)
         for (int gg = 0; gg < G; ++gg) f4add(u, sh[gg * R4 + threadIdx.x]);
+    if (!a.upd.V) {
         if (threadIdx.x < kp / 4) {
             reinterpret_cast<float4 *>(a.GV + (size_t)id * kp)[threadIdx.x] = u;
-        } else {
+        } else if (threadIdx.x < R4) {
             a.Gw[id] = a.pack_k >= 0 ? 0.f : u.x;
             a.Gb[id] = u.y;
         }
+        return;
+    }
+    // fused update of the hot feature's parameter row (apply_piece<KP, true> of fm_apply.hip, operation for operation)
+    __shared__ float hs[2];
+    if (threadIdx.x == kp / 4) { hs[0] = u.x; hs[1] = u.y; }
+    __syncthreads();
+    if (threadIdx.x < kp / 4) {
+        const FusedUpd &f = a.upd;
+        const float b = hs[1];
+        float4 *V4 = reinterpret_cast<float4 *>(f.V + (size_t)id * kp) + threadIdx.x;
+        float4 x = *V4;
+        const float4 v = f4mul(x, f.sv);
+        const bool has_w = a.pack_k >= 0 && (int)threadIdx.x == (a.pack_k >> 2);
+        float wslot = 0.f;
+        if (has_w) wslot = f4pick(x, a.pack_k & 3) - f.eta_w * (f4pick(u, a.pack_k & 3) * f.invb);
+        x.x -= f.eta_v * ((u.x - v.x * b) * f.invb);
+        x.y -= f.eta_v * ((u.y - v.y * b) * f.invb);
+        x.z -= f.eta_v * ((u.z - v.z * b) * f.invb);
+        x.w -= f.eta_v * ((u.w - v.w * b) * f.invb);
+        if (has_w) f4set(x, a.pack_k & 3, wslot);
+        *V4 = x;
+        if (threadIdx.x == 0 && a.pack_k < 0) f.w[id] = f.w[id] - f.eta_w * (hs[0] * f.invb);
     }
 }
 
@@ -531,7 +581,7 @@ __global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
     if (a.red_bsum && blockIdx.x == gridDim.x - 1) {
         // the extra last block finishes the residual statistics of this step (saves a launch)
         __shared__ double sh[3][kBlock / 64];
-        reduce_blocks_body(a.red_bsum, a.red_nblocks, a.red_rows, a.red_scal, a.red_acc, sh);
+        reduce_blocks_body(a.red_bsum, a.red_nblocks, a.red_rows, a.red_scal, a.red_acc, sh, a.red_w0, a.red_eta, a.red_reg0);
         return;
     }
     if (HOT) {

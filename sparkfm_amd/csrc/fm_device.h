@@ -136,8 +136,10 @@ __device__ __forceinline__ uint32_t slot_bcast(uint32_t v, int src) { return (ui
 // ------------------------------------------------------------------ reduce
 // one block, fixed order: sums the forward's per-block partials into
 // scal = {sum e, sum e^2, rows, nonfinite} (fp32, part of the packed gradient) and acc (fp64, +=)
+// w0 (optional): also steps the bias, theta <- theta - eta*(sum e / rows + reg0*theta) — what k_apply does in the unfused path
 __device__ __forceinline__ void reduce_blocks_body(const double *bsum, int32_t nblocks, int32_t n_rows, float *scal,
-                                                   double *acc, double (*sh)[kBlock / 64]) {
+                                                   double *acc, double (*sh)[kBlock / 64], float *w0 = nullptr, float eta = 0.f,
+                                                   float reg0 = 0.f) {
     double s1 = 0.0, s2 = 0.0, bad = 0.0;
     for (int i = threadIdx.x; i < nblocks; i += kBlock) {
         const double4 b = reinterpret_cast<const double4 *>(bsum)[i];
@@ -159,6 +161,10 @@ __device__ __forceinline__ void reduce_blocks_body(const double *bsum, int32_t n
         for (int i = 0; i < kBlock / 64; ++i) { t1 += sh[0][i]; t2 += sh[1][i]; tb += sh[2][i]; }
         if (scal) { scal[0] = (float)t1; scal[1] = (float)t2; scal[2] = (float)n_rows; scal[3] = (float)tb; }
         if (acc) { acc[0] += t1; acc[1] += t2; acc[2] += (double)n_rows; acc[3] += tb; }
+        if (w0) {
+            const float rows = (float)n_rows, invb = rows > 0.f ? 1.0f / rows : 0.f, b0 = *w0;
+            *w0 = b0 - eta * fmaf(reg0, b0, (float)t1 * invb);
+        }
     }
 }
 

@@ -13,7 +13,7 @@ constexpr int kGradHead = 32;      // floats reserved for them at the front of t
 
 // runtime kernel-variant knobs (diagnostics / A-B benchmarking; fmhip_tune)
 enum { kTuneFwd = 0, kTuneBwd = 1, kTuneTile = 2, kTuneRowBlock = 3, kTuneXcd = 4, kTuneHot = 5, kTuneFwdOcc = 6, kTuneRowOrder = 7,
-       kTuneFlat = 8, kTuneLazy = 9, kTuneCount = 10 };
+       kTuneFlat = 8, kTuneLazy = 9, kTuneFused = 10, kTuneCount = 11 };
 constexpr int kHotT = 16;           // slots of the dense hot block (fp32 per row: one 64-B half line)
 extern int g_tune[kTuneCount];
 
@@ -55,6 +55,14 @@ struct FwdArgs {
     float sv, sw;
 };
 
+// Fused update (single-GPU step, nothing to exchange): a finished gradient row is applied to its parameter row on
+// the spot — the rows-only form of fm_apply.hip, same operations on the same values — instead of being stored to
+// the packed gradient, read back, and zeroed by a separate launch.  V == NULL: store the gradient.
+struct FusedUpd {
+    float *V, *w;                 // parameter tables (stored scale sv: V = sv * stored)
+    float sv, eta_v, eta_w, invb; // eta_* = eta / (scale after this step); invb = 1 / rows of the batch
+};
+
 // dense hot block, gradient side: G rows of the hot features = xhot^T . P (plus their two scalar sums)
 struct HotArgs {
     const float *P;          // [n_rows][Kp] = e*q (slot pack_k = e for packed rows)
@@ -66,6 +74,7 @@ struct HotArgs {
     int32_t n_rows;
     int32_t pack_k;
     int32_t nblk;            // hot_blocks(Kp, n_rows)
+    FusedUpd upd;
 };
 struct BwdArgs {
     const uint32_t *crow;      // batch CSC: bit31 = first entry of its column, low bits = batch-local row
@@ -99,6 +108,9 @@ struct BwdArgs {
     int32_t red_nblocks, red_rows;
     float *red_scal;
     double *red_acc;
+    float *red_w0;             // fused update: the statistics block also steps w0 (NULL = leave it to k_apply)
+    float red_eta, red_reg0;
+    FusedUpd upd;
     // dense hot block (hot_blocks > 0): the first hot_blocks workgroups of the backward launch form its
     // partial sums while the others walk the sparse stream; kHotT extra workgroups of k_fixup finish it
     HotArgs hot;

@@ -675,6 +675,7 @@ void hot_attach(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm, BwdArgs
     h.n_rows = (int32_t)bm.rows;
     h.pack_k = m->pack_k();
     h.nblk = hot_blocks(m->Kp, bm.rows);
+    h.upd = ba.upd;
     ba.hot_blocks = h.nblk;
     m->hot_pending = false;
 }
@@ -686,9 +687,13 @@ void hot_attach(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm, BwdArgs
 // holding the first entry of feat_hi is left to the call that covers feat_hi.  `finish` adds the
 // residual-statistics reduction (once per step, with the last interval).
 int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo, int64_t feat_hi, bool finish,
-                  double *acc) {
+                  double *acc, const FusedPlan *fused) {
     const BatchMeta &bm = d->batches[(size_t)b];
     BwdArgs ba = bwd_args(m, d, b);
+    if (fused) {
+        ba.upd = fused->upd;
+        if (finish) { ba.red_w0 = m->w0.p; ba.red_eta = (float)fused->eta; ba.red_reg0 = (float)fused->reg0; }
+    }
     hot_attach(m, d, bm, ba);
     const bool whole = feat_lo <= 0 && feat_hi >= m->n1;
     if (d->rb_rows > 0 && !whole)
@@ -749,10 +754,31 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
     return FMHIP_OK;
 }
 
-// forward + backward + fixup of one batch into the packed gradient
-int step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double *acc) {
+// forward + backward + fixup of one batch into the packed gradient (fused: straight into the parameters)
+int step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double *acc, const FusedPlan *fused = nullptr) {
     TRY(step_forward(m, d, b));
-    return step_backward(m, d, b, 0, INT64_MAX, true, acc);
+    return step_backward(m, d, b, 0, INT64_MAX, true, acc, fused);
+}
+
+// Can this step apply its gradient rows inside the backward (no exchange, no separate update launch)?  It is the
+// rows-only update, so weight decay must be expressible through the tables' scale (lazy decay, fm_apply.hip).
+bool plan_fused(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double eta, double reg0, double regw, double regv, FusedPlan *p) {
+    const double dv = 1.0 - eta * regv, dw = 1.0 - eta * regw;
+    const bool decay = regw != 0.0 || regv != 0.0;
+    if (!g_tune[kTuneFused] || d->rb_rows != 0) return false;
+    if (decay && !(g_tune[kTuneLazy] && dv >= 0.5 && dw >= 0.5 && dv <= 1.0 && dw <= 1.0)) return false;
+    p->eta = eta;
+    p->reg0 = reg0;
+    p->sv_out = m->sv * dv;
+    p->sw_out = m->sw * dw;
+    p->upd.V = m->V.p;
+    p->upd.w = m->w.p;
+    p->upd.sv = (float)m->sv;
+    p->upd.eta_v = (float)(eta / p->sv_out);
+    p->upd.eta_w = (float)(eta / p->sw_out);
+    const float rows = (float)d->batches[(size_t)b].rows;
+    p->upd.invb = rows > 0.f ? 1.0f / rows : 0.f;
+    return true;
 }
 
 // brings lazily decayed tables back to scale 1 (dense pass)
@@ -760,6 +786,17 @@ int fold_scales(fmhip_model_t m) {
     if (m->sv == 1.0 && m->sw == 1.0) return FMHIP_OK;
     HIP_TRY(launch_rescale(m->Kp, m->V.p, m->w.p, m->n1, m->pack_k(), (float)m->sv, (float)m->sw, m->stream));
     m->sv = m->sw = 1.0;
+    return FMHIP_OK;
+}
+
+// what step_apply leaves behind, for a step whose update already happened inside the backward
+int finish_fused(fmhip_model_t m, const FusedPlan &p) {
+    m->sv = p.sv_out;
+    m->sw = p.sw_out;
+    if (m->sv < 0x1p-24 || m->sw < 0x1p-24) TRY(fold_scales(m));
+    m->grad_dirty = false;        // nothing but the statistics head was written
+    m->host64_fresh = false;
+    ++m->prof_step;
     return FMHIP_OK;
 }
 
@@ -1207,14 +1244,16 @@ int fmhip_sgd_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double eta
                    double regv, fmhip_stats *stats) {
     TRY(check_train(m, d));
     TRY(check_batch(d, batch));
-    TRY(step_compute(m, d, batch, nullptr));
+    FusedPlan fp{};
+    const bool fused = plan_fused(m, d, batch, eta, reg0, regw, regv, &fp);
+    TRY(step_compute(m, d, batch, nullptr, fused ? &fp : nullptr));
     if (stats) {
         memset(stats, 0, sizeof *stats);
         TRY(read_scal(m, stats));
         stats->nnz = d->batches[(size_t)batch].nnz_total;
         stats->steps = 1;
     }
-    return step_apply(m, eta, reg0, regw, regv, d, batch);
+    return fused ? finish_fused(m, fp) : step_apply(m, eta, reg0, regw, regv, d, batch);
 }
 
 int fmhip_sgd_epoch(fmhip_model_t m, fmhip_dataset_t d, double eta, double reg0, double regw, double regv,
@@ -1226,8 +1265,10 @@ int fmhip_sgd_epoch(fmhip_model_t m, fmhip_dataset_t d, double eta, double reg0,
     HIP_TRY(hipMemsetAsync(m->acc.p, 0, 4 * sizeof(double), m->stream));
     for (int64_t j = 0; j < nb; ++j) {
         const int64_t b = order ? order[j] : j;
-        TRY(step_compute(m, d, b, m->acc.p));
-        TRY(step_apply(m, eta, reg0, regw, regv, d, b));
+        FusedPlan fp{};
+        const bool fused = plan_fused(m, d, b, eta, reg0, regw, regv, &fp);
+        TRY(step_compute(m, d, b, m->acc.p, fused ? &fp : nullptr));
+        TRY(fused ? finish_fused(m, fp) : step_apply(m, eta, reg0, regw, regv, d, b));
     }
     if (stats) {
         memset(stats, 0, sizeof *stats);
@@ -1380,7 +1421,7 @@ int fmhip_step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, int64
         return fail(FMHIP_ERR_INVALID, "feature intervals must tile [0, n+1) in descending order (expected hi = %lld, got %lld)",
                     (long long)(m->bw_next_hi == INT64_MAX ? m->n1 : m->bw_next_hi), (long long)feat_hi);
     if (finish && feat_lo != 0) return fail(FMHIP_ERR_INVALID, "finish = 1 belongs to the interval that starts at feature 0");
-    TRY(step_backward(m, d, batch, feat_lo, feat_hi, finish != 0, nullptr));
+    TRY(step_backward(m, d, batch, feat_lo, feat_hi, finish != 0, nullptr, nullptr));
     m->bw_next_hi = feat_lo == 0 ? -1 : feat_lo;
     return FMHIP_OK;
 }

@@ -178,7 +178,14 @@ int check_train(fmhip_model_t m, fmhip_dataset_t d);      // + the dataset must 
 int check_batch(fmhip_dataset_t d, int64_t batch);
 // the pieces of one mini-batch step, all asynchronous on m->stream (fmhip_api.hip)
 int step_forward(fmhip_model_t m, fmhip_dataset_t d, int64_t b);
-int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo, int64_t feat_hi, bool finish, double *acc);
+// a step whose gradient rows are applied inside the backward (fmhip_api.hip: plan_fused)
+struct FusedPlan {
+    double eta = 0.0, reg0 = 0.0;
+    double sv_out = 1.0, sw_out = 1.0;    // the tables' scales after the step
+    FusedUpd upd{};
+};
+int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo, int64_t feat_hi, bool finish, double *acc,
+                  const FusedPlan *fused = nullptr);
 int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double regv, fmhip_dataset_t d = nullptr, int64_t b = -1);
 int read_scal(fmhip_model_t m, fmhip_stats *st);
 

@@ -378,3 +378,38 @@ def test_als_refuses_rows_with_a_repeated_feature(fmhip):
     with pytest.raises(_ffi.FmhipError, match="twice"):
         fmhip.HipALS.run().learn(fm, ds)
     assert np.isfinite(fm.computeRMSE(ds))          # everything else accepts such rows
+
+
+@pytest.mark.parametrize("k,regs", [(8, (0.01, 1e-3, 1e-3)), (32, (0.0, 1e-3, 2e-3)), (32, (0.0, 0.0, 0.0)), (64, (0.01, 0.0, 1e-3)),
+                                    (100, (0.0, 1e-3, 1e-3))])
+def test_fused_update_is_bit_identical_to_the_update_launch(fmhip, k, regs):
+    """fmhip_tune key 10: the fused step applies each finished gradient row to its parameter row inside the
+    backward / fixup launches; the unfused one stores the packed gradient and runs k_apply_rows.  Same
+    operations on the same values -> the same bits, for packed rows (k=8), plain rows, wide rows, hot block on,
+    cut columns (hot features spanning many ranges), with and without (lazy) weight decay."""
+    from sparkfm_amd import _ffi
+    from test_gpu_parity import hot_problem
+    L = _ffi.load()
+    a, _ = hot_problem(500 + k, 4000, 30000, k, 9)
+    outs = []
+    for fused in (1, 0):
+        L.fmhip_tune(10, fused)
+        try:
+            ds = fmhip.DataSet(a["row_ptr"], a["col"], a["val"], a["y"], batch_rows=1100).cache()
+            fm = fmhip.FMModel(a["n1"] - 1, k)
+            fm.w0, fm.w, fm.v = a["w0"], a["w"], a["v"]
+            sgd = fmhip.HipSGD(eta=0.05, reg0=regs[0], regw=regs[1], regv=regs[2])
+            for _ in range(3):
+                sgd.learn(fm, ds)
+            outs.append((fm.w0, fm.w.copy(), fm.v.copy(), sgd.last_stats["sse"]))
+        finally:
+            L.fmhip_tune(10, 0)
+        ds.unpersist()
+        fm.close()
+    assert outs[0][0] == outs[1][0] and outs[0][3] == outs[1][3]
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    np.testing.assert_array_equal(outs[0][2], outs[1][2])
+    w0, w, v = a["w0"], a["w"], a["v"]
+    for _ in range(3):
+        w0, w, v, _ = oracle.sgd_epoch(w0, w, v, 1100, a["row_ptr"], a["col"], a["val"], a["y"], 0.05, *regs)
+    assert rel(outs[0][2], v) <= 1e-5 and rel(outs[0][1], w) <= 1e-5 and outs[0][0] == pytest.approx(w0, rel=1e-5, abs=1e-7)
