@@ -227,6 +227,133 @@ __device__ __forceinline__ void hot_reduce_body(const HotArgs &a, int h, int kp)
 //   wave sum   when the whole wave's span (64/LPN ranges) lies inside ONE column the slots are
 //              tree-summed in registers and a single partial is written for the wave.
 // k_fixup and the host-side split list (fmhip_api.hip) apply the same two predicates.
+//
+// RangeWalk = what a slot knows about its range before and while it walks it; shared by the plain walk
+// (k_backward) and the pipelined one (k_backward_p), which differ only in how the entries are fetched.
+template <int LPN, int J, bool PACKED>
+struct RangeWalk {
+    static constexpr int KP = 4 * LPN * J;
+    static constexpr int SLOTS = kBlock / LPN;
+    static constexpr int WS = 64 / LPN;                       // slots (ranges) per wave
+    static constexpr int PR = KP + kPartPad;
+    int l, sl, kj, kc;          // lane in the slot; lane / float4 / component that carry the packed row's scalar slot
+    int rho, beg, seg, ca, wbeg, p0, stop;
+    bool clean, is_head, tail_partial;
+    float4 acc[J];
+    float sa, sb;
+
+    // false: this slot has no range in the launch's interval
+    __device__ __forceinline__ bool setup(const BwdArgs &a, int bx) {
+        l = threadIdx.x & (LPN - 1);
+        // packed rows (k < Kp): slot k of the P row is e, so slot k of acc IS sum e*x (the w gradient) and
+        // there is no e gather; sum e*x^2 is formed from that slot in the lane that owns it (lane sl)
+        sl = PACKED ? (a.pack_k >> 2) & (LPN - 1) : 0;
+        kj = PACKED ? (a.pack_k >> 2) / LPN : 0;
+        kc = a.pack_k & 3;
+        // a launch may cover only the ranges [rho_lo, rho_hi) (feature-chunked backward); block
+        // numbering stays aligned to the global range numbering so the wave-sum predicate is unchanged.
+        // xcd_chunk > 0: XCD-aware placement — workgroups b, b+8, b+16, .. share an XCD (round-robin
+        // dispatch), so XCD x is given the x-th contiguous eighth of the stream: with a row-blocked
+        // stream that is a few whole row blocks, whose slice of P then lives in that XCD's L2 only.
+        const int blk = a.xcd_chunk > 0 ? (bx & 7) * a.xcd_chunk + (bx >> 3) : bx;
+        rho = (a.rho_lo / SLOTS + blk) * SLOTS + threadIdx.x / LPN;
+        if (rho < a.rho_lo || rho >= a.rho_hi) return false;
+        beg = rho * kRangeLen;
+        const int end = (beg + kRangeLen < a.nnz) ? beg + kRangeLen : a.nnz;
+        seg = a.range_seg[rho];
+        ca = a.cptr[seg];
+        const int cb = a.cptr[seg + 1];                       // the column open at `beg`
+        wbeg = (rho - (int)((threadIdx.x & 63) / LPN)) * kRangeLen;
+        clean = (ca <= wbeg) && (cb >= wbeg + WS * kRangeLen);   // wave-uniform by construction
+        is_head = ca < beg;
+        p0 = beg;
+        stop = end;
+        tail_partial = false;
+        if (!clean) {
+            if (is_head && ca >= beg - kRangeLen && cb - beg <= kExtend) {
+                p0 = cb;            // slot rho-1 finishes that column
+                ++seg;
+                is_head = false;
+            }
+            if (end < a.nnz) {
+                const int sn = a.range_seg[rho + 1];
+                const int ca2 = a.cptr[sn], cb2 = a.cptr[sn + 1];   // the column open at `end`
+                if (ca2 < end) {
+                    if (ca2 >= beg && cb2 - end <= kExtend) stop = cb2;   // finish it here
+                    else tail_partial = true;
+                }
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) acc[jj] = f4zero();
+        sa = 0.f;
+        sb = 0.f;
+        return true;
+    }
+
+    __device__ __forceinline__ float *part_row(const BwdArgs &a, int which) const { return a.part + ((size_t)rho * 2 + which) * PR; }
+
+    // the open column ends in front of the entry being walked: its sum goes out, the accumulators restart
+    __device__ __forceinline__ void flush(const BwdArgs &a) {
+        if (is_head) {
+            float *pr = part_row(a, 0);
+            store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
+        } else {
+            store_seg<LPN, J>(a, seg, l, acc, sa, sb, sl);
+        }
+        is_head = false;
+        ++seg;
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) acc[jj] = f4zero();
+        sa = 0.f;
+        sb = 0.f;
+    }
+
+    // acc += x * (the entry's P row); the two scalar sums (sum e*x -> G_w, sum e*x^2 -> G_b)
+    __device__ __forceinline__ void add(const float4 (&pv)[J], float xj, float ej) {
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) f4fma(acc[jj], pv[jj], xj);  // sum x * (e*q)
+        if (PACKED) {
+            float pk = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj)
+                if (jj == kj) pk = f4pick(pv[jj], kc);
+            sb = fmaf(__fmul_rn(pk, xj), xj, sb);
+        } else {
+            accum_scalars(sa, sb, ej, xj);
+        }
+    }
+
+    // one live entry at stream position `pos`: `flag` = bit 31 of its row word (first entry of its column)
+    __device__ __forceinline__ void entry(const BwdArgs &a, int pos, uint32_t rj, const float4 (&pv)[J], float xj, float ej) {
+        if ((rj >> 31) && pos != p0) flush(a);
+        add(pv, xj, ej);
+    }
+
+    __device__ __forceinline__ void finish(const BwdArgs &a) {
+        if (clean) {
+            slots_reduce<LPN, J>(acc, sa, sb);
+            if (beg == wbeg) {
+                float *pr = part_row(a, ca == wbeg ? 1 : 0);
+                store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
+            }
+            return;
+        }
+        if (p0 >= stop) return;   // everything in this range belonged to the previous slot
+        if (is_head) {
+            float *pr = part_row(a, 0);
+            store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
+        } else if (tail_partial) {
+            float *pr = part_row(a, 1);
+            store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
+        } else {
+            store_seg<LPN, J>(a, seg, l, acc, sa, sb, sl);
+        }
+    }
+};
+
+// The plain walk: LPN entries per step (one per lane), their P rows gathered CH at a time with flat loads —
+// the variant for P tables of 4 GiB and more, and for rows wider than the pipelined kernel's registers allow.
 template <int LPN, int J, bool PACKED, bool HOT>
 __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
     constexpr int KP = 4 * LPN * J;
@@ -234,63 +361,20 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
         hot_backward_body<KP / 16>(a.hot, (int)blockIdx.x, a.hot_blocks);
         return;
     }
-    const int bx = HOT ? (int)blockIdx.x - a.hot_blocks : (int)blockIdx.x;
-    constexpr int SLOTS = kBlock / LPN;
-    constexpr int WS = 64 / LPN;                        // slots (ranges) per wave
-    constexpr int PR = KP + kPartPad;
     constexpr int CH = (LPN * J > 16) ? (16 / J) : LPN;  // entries whose P rows are in flight together
-    const int l = threadIdx.x & (LPN - 1);
-    // packed rows (k < Kp): slot k of the P row is e, so slot k of acc IS sum e*x (the w gradient) and
-    // there is no e gather; sum e*x^2 is formed from that slot in the lane that owns it (lane sl)
-    constexpr bool packed = PACKED;
-    const int kl = packed ? (a.pack_k >> 2) & (LPN - 1) : 0, kj = packed ? (a.pack_k >> 2) / LPN : 0, kc = a.pack_k & 3;
-    const int sl = kl;
-    // a launch may cover only the ranges [rho_lo, rho_hi) (feature-chunked backward); block
-    // numbering stays aligned to the global range numbering so the wave-sum predicate is unchanged.
-    // xcd_chunk > 0: XCD-aware placement — workgroups b, b+8, b+16, .. share an XCD (round-robin
-    // dispatch), so XCD x is given the x-th contiguous eighth of the stream: with a row-blocked
-    // stream that is a few whole row blocks, whose slice of P then lives in that XCD's L2 only.
-    const int blk = a.xcd_chunk > 0 ? (bx & 7) * a.xcd_chunk + (bx >> 3) : bx;
-    const int rho = (a.rho_lo / SLOTS + blk) * SLOTS + threadIdx.x / LPN;
-    if (rho < a.rho_lo || rho >= a.rho_hi) return;
-    const int beg = rho * kRangeLen;
-    const int end = (beg + kRangeLen < a.nnz) ? beg + kRangeLen : a.nnz;
-    int seg = a.range_seg[rho];
-    const int ca = a.cptr[seg], cb = a.cptr[seg + 1];   // the column open at `beg`
-    const int wbeg = (rho - (int)((threadIdx.x & 63) / LPN)) * kRangeLen;
-    const bool clean = (ca <= wbeg) && (cb >= wbeg + WS * kRangeLen);   // wave-uniform by construction
-    bool is_head = ca < beg;
-    int p0 = beg, stop = end;
-    bool tail_partial = false;
-    if (!clean) {
-        if (is_head && ca >= beg - kRangeLen && cb - beg <= kExtend) {
-            p0 = cb;            // slot rho-1 finishes that column
-            ++seg;
-            is_head = false;
-        }
-        if (end < a.nnz) {
-            const int sn = a.range_seg[rho + 1];
-            const int ca2 = a.cptr[sn], cb2 = a.cptr[sn + 1];   // the column open at `end`
-            if (ca2 < end) {
-                if (ca2 >= beg && cb2 - end <= kExtend) stop = cb2;   // finish it here
-                else tail_partial = true;
-            }
-        }
-    }
-    float4 acc[J];
-#pragma unroll
-    for (int jj = 0; jj < J; ++jj) acc[jj] = f4zero();
-    float sa = 0.f, sb = 0.f;
-    for (int base = p0; base < stop; base += LPN) {
+    RangeWalk<LPN, J, PACKED> w;
+    if (!w.setup(a, HOT ? (int)blockIdx.x - a.hot_blocks : (int)blockIdx.x)) return;
+    const int l = w.l;
+    for (int base = w.p0; base < w.stop; base += LPN) {
         const int p = base + l;
         uint32_t rf = 0u;
         float x = 0.f, ee = 0.f;
-        if (p < stop) {
+        if (p < w.stop) {
             rf = stream_load(a.crow + p);
             x = stream_load(a.cval + p);
-            if (!packed) ee = a.e[rf & 0x7fffffffu];
+            if (!PACKED) ee = a.e[rf & 0x7fffffffu];
         }
-        const int cnt = (stop - base) < LPN ? (stop - base) : LPN;
+        const int cnt = (w.stop - base) < LPN ? (w.stop - base) : LPN;
 #pragma unroll
         for (int c0 = 0; c0 < LPN; c0 += CH) {
             float4 pv[CH][J];
@@ -305,56 +389,12 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 const float xj = slot_bcast<LPN>(x, c0 + j);
-                const float ej = packed ? 0.f : slot_bcast<LPN>(ee, c0 + j);
-                if (c0 + j < cnt) {
-                    if ((rj[j] >> 31) && (base + c0 + j != p0)) {
-                        // the open column ends here: flush it
-                        if (is_head) {
-                            float *pr = a.part + ((size_t)rho * 2) * PR;
-                            store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
-                        } else {
-                            store_seg<LPN, J>(a, seg, l, acc, sa, sb, sl);
-                        }
-                        is_head = false;
-                        ++seg;
-#pragma unroll
-                        for (int jj = 0; jj < J; ++jj) acc[jj] = f4zero();
-                        sa = 0.f;
-                        sb = 0.f;
-                    }
-#pragma unroll
-                    for (int jj = 0; jj < J; ++jj) f4fma(acc[jj], pv[j][jj], xj);  // sum x * (e*q)
-                    if (packed) {
-                        float pk = 0.f;
-#pragma unroll
-                        for (int jj = 0; jj < J; ++jj)
-                            if (jj == kj) pk = f4pick(pv[j][jj], kc);
-                        sb = fmaf(__fmul_rn(pk, xj), xj, sb);
-                    } else {
-                        accum_scalars(sa, sb, ej, xj);
-                    }
-                }
+                const float ej = PACKED ? 0.f : slot_bcast<LPN>(ee, c0 + j);
+                if (c0 + j < cnt) w.entry(a, base + c0 + j, rj[j], pv[j], xj, ej);
             }
         }
     }
-    if (clean) {
-        slots_reduce<LPN, J>(acc, sa, sb);
-        if (beg == wbeg) {
-            float *pr = a.part + ((size_t)rho * 2 + (ca == wbeg ? 1 : 0)) * PR;
-            store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
-        }
-        return;
-    }
-    if (p0 >= stop) return;   // everything in this range belonged to the previous slot
-    if (is_head) {
-        float *pr = a.part + ((size_t)rho * 2) * PR;
-        store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
-    } else if (tail_partial) {
-        float *pr = a.part + ((size_t)rho * 2 + 1) * PR;
-        store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
-    } else {
-        store_seg<LPN, J>(a, seg, l, acc, sa, sb, sl);
-    }
+    w.finish(a);
 }
 
 // Pipelined variant of k_backward (same walk, same predicates, same outputs): the CSC index /
@@ -370,57 +410,14 @@ __global__ __launch_bounds__(kBlock, (HOT && J == 1 ? 3 : 1)) void k_backward_p(
         hot_backward_body<KP / 16>(a.hot, (int)blockIdx.x, a.hot_blocks);
         return;
     }
-    const int bx = HOT ? (int)blockIdx.x - a.hot_blocks : (int)blockIdx.x;
-    constexpr int SLOTS = kBlock / LPN;
-    constexpr int WS = 64 / LPN;
-    constexpr int PR = KP + kPartPad;
     constexpr int SG = (kRangeLen / LPN) < 8 ? (kRangeLen / LPN) : 8;         // lane-groups per super-group
     constexpr int CHB = (LPN * J > 8) ? ((8 / J) > 0 ? (8 / J) : 1) : LPN;   // entries per gather chunk
     constexpr int NCH = SG * LPN / CHB;                                       // chunks per super-group
-    const int l = threadIdx.x & (LPN - 1);
-    // packed rows (k < Kp): slot k of the P row is e, so slot k of acc IS sum e*x (the w gradient) and
-    // there is no e gather; sum e*x^2 is formed from that slot in the lane that owns it (lane sl)
-    constexpr bool packed = PACKED;
-    const int kl = packed ? (a.pack_k >> 2) & (LPN - 1) : 0, kj = packed ? (a.pack_k >> 2) / LPN : 0, kc = a.pack_k & 3;
-    const int sl = kl;
-    // a launch may cover only the ranges [rho_lo, rho_hi) (feature-chunked backward); block
-    // numbering stays aligned to the global range numbering so the wave-sum predicate is unchanged.
-    // xcd_chunk > 0: XCD-aware placement — workgroups b, b+8, b+16, .. share an XCD (round-robin
-    // dispatch), so XCD x is given the x-th contiguous eighth of the stream: with a row-blocked
-    // stream that is a few whole row blocks, whose slice of P then lives in that XCD's L2 only.
-    const int blk = a.xcd_chunk > 0 ? (bx & 7) * a.xcd_chunk + (bx >> 3) : bx;
-    const int rho = (a.rho_lo / SLOTS + blk) * SLOTS + threadIdx.x / LPN;
-    if (rho < a.rho_lo || rho >= a.rho_hi) return;
+    RangeWalk<LPN, J, PACKED> w;
+    if (!w.setup(a, HOT ? (int)blockIdx.x - a.hot_blocks : (int)blockIdx.x)) return;
+    const int l = w.l;
     const __amdgpu_buffer_rsrc_t prs = make_rsrc(a.P, a.p_bytes);
-    const int beg = rho * kRangeLen;
-    const int end = (beg + kRangeLen < a.nnz) ? beg + kRangeLen : a.nnz;
-    int seg = a.range_seg[rho];
-    const int ca = a.cptr[seg], cb = a.cptr[seg + 1];
-    const int wbeg = (rho - (int)((threadIdx.x & 63) / LPN)) * kRangeLen;
-    const bool clean = (ca <= wbeg) && (cb >= wbeg + WS * kRangeLen);
-    bool is_head = ca < beg;
-    int p0 = beg, stop = end;
-    bool tail_partial = false;
-    if (!clean) {
-        if (is_head && ca >= beg - kRangeLen && cb - beg <= kExtend) {
-            p0 = cb;
-            ++seg;
-            is_head = false;
-        }
-        if (end < a.nnz) {
-            const int sn = a.range_seg[rho + 1];
-            const int ca2 = a.cptr[sn], cb2 = a.cptr[sn + 1];
-            if (ca2 < end) {
-                if (ca2 >= beg && cb2 - end <= kExtend) stop = cb2;
-                else tail_partial = true;
-            }
-        }
-    }
-    float4 acc[J];
-#pragma unroll
-    for (int jj = 0; jj < J; ++jj) acc[jj] = f4zero();
-    float sa = 0.f, sb = 0.f;
-    for (int sbase = p0; sbase < stop; sbase += SG * LPN) {
+    for (int sbase = w.p0; sbase < w.stop; sbase += SG * LPN) {
         uint32_t rf[SG];
         float x[SG], ee[SG];
 #pragma unroll
@@ -428,13 +425,13 @@ __global__ __launch_bounds__(kBlock, (HOT && J == 1 ? 3 : 1)) void k_backward_p(
             const int p = sbase + g * LPN + l;
             rf[g] = 0u;
             x[g] = 0.f;
-            if (p < stop) { rf[g] = stream_load(a.crow + p); x[g] = stream_load(a.cval + p); }
+            if (p < w.stop) { rf[g] = stream_load(a.crow + p); x[g] = stream_load(a.cval + p); }
         }
 #pragma unroll
         for (int g = 0; g < SG; ++g) {
             const int p = sbase + g * LPN + l;
             ee[g] = 0.f;
-            if (!packed && p < stop) ee[g] = a.e[rf[g] & 0x7fffffffu];
+            if (!PACKED && p < w.stop) ee[g] = a.e[rf[g] & 0x7fffffffu];
         }
         float4 pv[2][CHB][J];
         uint32_t rj[2][CHB];
@@ -444,7 +441,7 @@ __global__ __launch_bounds__(kBlock, (HOT && J == 1 ? 3 : 1)) void k_backward_p(
                 const int ent = ch * CHB + j;             // entry index inside the super-group
                 const int g = ent / LPN, jl = ent % LPN;
                 rj[buf][j] = slot_bcast<LPN>(rf[g], jl);
-                const bool live = sbase + ent < stop;
+                const bool live = sbase + ent < w.stop;
                 const uint32_t off = (rj[buf][j] & 0x7fffffffu) * (KP * 4u) + (uint32_t)l * 16u;
 #pragma unroll
                 for (int jj = 0; jj < J; ++jj) pv[buf][j][jj] = buf_load4(prs, live ? off + jj * LPN * 16u : kOob);
@@ -462,26 +459,14 @@ __global__ __launch_bounds__(kBlock, (HOT && J == 1 ? 3 : 1)) void k_backward_p(
             const int cpos = sbase + ch * CHB;
             uint32_t fl = 0u;
 #pragma unroll
-            for (int j = 0; j < CHB; ++j) fl |= (cpos + j == p0) ? 0u : rj[buf][j];
-            const bool plain = (cpos + CHB <= stop) && !(fl >> 31);
+            for (int j = 0; j < CHB; ++j) fl |= (cpos + j == w.p0) ? 0u : rj[buf][j];
+            const bool plain = (cpos + CHB <= w.stop) && !(fl >> 31);
             if (__all(plain)) {
 #pragma unroll
                 for (int j = 0; j < CHB; ++j) {
                     const int ent = ch * CHB + j;
                     const int g = ent / LPN, jl = ent % LPN;
-                    const float xj = slot_bcast<LPN>(x[g], jl);
-                    const float ej = packed ? 0.f : slot_bcast<LPN>(ee[g], jl);
-#pragma unroll
-                    for (int jj = 0; jj < J; ++jj) f4fma(acc[jj], pv[buf][j][jj], xj);
-                    if (packed) {
-                        float pk = 0.f;
-#pragma unroll
-                        for (int jj = 0; jj < J; ++jj)
-                            if (jj == kj) pk = f4pick(pv[buf][j][jj], kc);
-                        sb = fmaf(__fmul_rn(pk, xj), xj, sb);
-                    } else {
-                        accum_scalars(sa, sb, ej, xj);
-                    }
+                    w.add(pv[buf][j], slot_bcast<LPN>(x[g], jl), PACKED ? 0.f : slot_bcast<LPN>(ee[g], jl));
                 }
                 continue;
             }
@@ -490,55 +475,12 @@ __global__ __launch_bounds__(kBlock, (HOT && J == 1 ? 3 : 1)) void k_backward_p(
                 const int ent = ch * CHB + j;
                 const int g = ent / LPN, jl = ent % LPN;
                 const float xj = slot_bcast<LPN>(x[g], jl);
-                const float ej = packed ? 0.f : slot_bcast<LPN>(ee[g], jl);
-                if (sbase + ent < stop) {
-                    if ((rj[buf][j] >> 31) && (sbase + ent != p0)) {
-                        if (is_head) {
-                            float *pr = a.part + ((size_t)rho * 2) * PR;
-                            store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
-                        } else {
-                            store_seg<LPN, J>(a, seg, l, acc, sa, sb, sl);
-                        }
-                        is_head = false;
-                        ++seg;
-#pragma unroll
-                        for (int jj = 0; jj < J; ++jj) acc[jj] = f4zero();
-                        sa = 0.f;
-                        sb = 0.f;
-                    }
-#pragma unroll
-                    for (int jj = 0; jj < J; ++jj) f4fma(acc[jj], pv[buf][j][jj], xj);
-                    if (packed) {
-                        float pk = 0.f;
-#pragma unroll
-                        for (int jj = 0; jj < J; ++jj)
-                            if (jj == kj) pk = f4pick(pv[buf][j][jj], kc);
-                        sb = fmaf(__fmul_rn(pk, xj), xj, sb);
-                    } else {
-                        accum_scalars(sa, sb, ej, xj);
-                    }
-                }
+                const float ej = PACKED ? 0.f : slot_bcast<LPN>(ee[g], jl);
+                if (sbase + ent < w.stop) w.entry(a, sbase + ent, rj[buf][j], pv[buf][j], xj, ej);
             }
         }
     }
-    if (clean) {
-        slots_reduce<LPN, J>(acc, sa, sb);
-        if (beg == wbeg) {
-            float *pr = a.part + ((size_t)rho * 2 + (ca == wbeg ? 1 : 0)) * PR;
-            store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
-        }
-        return;
-    }
-    if (p0 >= stop) return;
-    if (is_head) {
-        float *pr = a.part + ((size_t)rho * 2) * PR;
-        store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
-    } else if (tail_partial) {
-        float *pr = a.part + ((size_t)rho * 2 + 1) * PR;
-        store_row<LPN, J>(pr, l, acc, sa, sb, pr + KP, pr + KP + 1, sl);
-    } else {
-        store_seg<LPN, J>(a, seg, l, acc, sa, sb, sl);
-    }
+    w.finish(a);
 }
 
 // Sums the partials of the columns that were cut across ranges.  The column [ca, cb) spans ranges
