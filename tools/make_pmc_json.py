@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condenses the rocprofv3 runs of tools/profile_round.sh into the two committed records:
 
-    python tools/make_pmc_json.py <tag> <config> <k> <batch_rows>  ->  profiles/<tag>_summary.txt
+    python tools/make_pmc_json.py <tag> <config> <k> <batch_rows> [command]  ->  profiles/<tag>_summary.txt
                                                                      profiles/pmc_traffic.json (entries of this config replaced)
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are KiB of
@@ -44,12 +44,13 @@ def load_pmc(tag, name, skip):
 
 def main():
     tag, config, k, batch_rows = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    command = sys.argv[5] if len(sys.argv) > 5 else "python3 bench.py --no-cpu-baseline --no-extra --steps 12 --warmup 4"
     skip = 4
     lines = []
     stats = glob.glob(os.path.join(ROOT, "gpurun_out", tag + "_stats", "**", "*kernel_stats.csv"), recursive=True)
     durations = {}
     if stats:
-        lines.append("# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-extra --steps 12 --warmup 4   (durations in us)")
+        lines.append("# rocprofv3 --kernel-trace --stats -- %s   (durations in us)" % command)
         lines.append("%-44s %6s %10s %10s %10s %7s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct"))
         for r in csv.DictReader(open(stats[0])):
             base, fn = short(r["Name"])
