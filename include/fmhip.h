@@ -115,8 +115,9 @@ int fmhip_device_count(int *count);
  *          launch) whenever the rows-only update is legal.  Bit-identical to the separate update launch;
  *          off by default because the read-modify-write of the parameter row sits in the column walk's
  *          dependent chain (C3: backward +20 us against 12 us of update launch saved).
- * Keys 3 and 5 are read by fmhip_dataset_create at the time of the call (they decide the layout of the
- * dataset being built and nothing else); every other key is read by the next launch. */
+ * Keys 3 and 5 are only the DEFAULTS of fmhip_dataset_create (read at the time of the call; they decide the
+ * layout of the dataset being built and nothing else) — fmhip_dataset_create_opts states them per dataset;
+ * every other key is read by the next launch. */
 int fmhip_tune(int key, int value);
 
 /* ---- model: `new FMModel(num_attribute, num_factor)`  S/fm/FMModel.scala:9-22 -- */
@@ -146,6 +147,16 @@ int fmhip_dataset_create(int device, int64_t n_rows, const int64_t *row_ptr, con
                          const double *val, const double *y, int64_t batch_rows, fmhip_dataset_t *out);
 int fmhip_dataset_create_f32(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col,
                              const float *val, const float *y, int64_t batch_rows, fmhip_dataset_t *out);
+/* The same with the layout choices spelled out per dataset instead of read from the process-wide tuning
+ * keys 3 and 5 (which remain the defaults, for A/B tools).  struct_size = sizeof(fmhip_dataset_opts). */
+typedef struct fmhip_dataset_opts {
+    int32_t struct_size;
+    int32_t hot_block;       /* dense hot block: -1 = library default (fmhip_tune key 5), 0 = off, 1 = on */
+    int64_t batch_rows;      /* <= 0: one batch */
+    int64_t row_block_rows;  /* rows per row block of the transposes: -1 = library default (key 3), 0 = none */
+} fmhip_dataset_opts;
+int fmhip_dataset_create_opts(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const double *val,
+                              const double *y, const fmhip_dataset_opts *opts, fmhip_dataset_t *out);
 /* Rows + labels only, for scoring held-out data (`fm.computeRMSE(test)`, S/driver.scala:100-112): no
  * transposes, no mini-batches; y may be NULL (labels = 0: predict only).  Training calls refuse it. */
 int fmhip_rows_create(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const double *val,

@@ -164,9 +164,13 @@ void parallel_chunks(int64_t n, int threads, F f) {
 
 // scoring = true: rows + labels only (FMModel.predict / Model.computeRMSE on held-out data,
 // S/driver.scala:100-112) — no transposes, no hot block, nothing a training step needs
+// hot_opt / rb_opt: -1 = the process-wide defaults (fmhip_tune keys 5 / 3)
 template <typename FT>
 int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const FT *val,
-                        const FT *y, int64_t batch_rows, bool scoring, fmhip_dataset_t *out) {
+                        const FT *y, int64_t batch_rows, bool scoring, fmhip_dataset_t *out, int hot_opt = -1,
+                        int64_t rb_opt = -1) {
+    const bool want_hot = hot_opt < 0 ? g_tune[kTuneHot] > 0 : hot_opt > 0;
+    const int64_t want_rb = rb_opt < 0 ? (g_tune[kTuneRowBlock] > 0 ? g_tune[kTuneRowBlock] : 0) : rb_opt;
     if (!out) return fail(FMHIP_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (n_rows < 0) return fail(FMHIP_ERR_INVALID, "n_rows < 0");
@@ -224,7 +228,7 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     std::vector<float> sp_val, xhot;
     std::vector<uint32_t> hot_masks;
     bool split = false;
-    if (g_tune[kTuneHot] > 0 && nb > 1 && nnz > 0 && !scoring) {
+    if (want_hot && nb > 1 && nnz > 0 && !scoring) {
         // Frequencies: exact for datasets of up to 8 M nonzeros; beyond that from every s-th row (the
         // choice of hot features is a layout decision — any set that passes the checks below is valid —
         // and a feature in >= 10 % of the rows cannot hide from a sample of millions of entries).
@@ -431,7 +435,7 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
         while (key_bits < 31 && ((int64_t)1 << key_bits) <= (int64_t)dim) ++key_bits;
         // optional row blocking of the transposes (fmhip_tune key 3): entries sorted by (row block,
         // feature) so that a block's slice of P stays L2-resident while its columns are walked
-        int64_t rb_rows = g_tune[kTuneRowBlock] > 0 ? g_tune[kTuneRowBlock] : 0;
+        int64_t rb_rows = want_rb;
         int rb_bits = 0;
         if (rb_rows > 0) {
             const int64_t blocks = (d->max_rows + rb_rows - 1) / rb_rows;
@@ -1046,6 +1050,14 @@ int fmhip_synchronize(fmhip_model_t m) {
 int fmhip_dataset_create(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const double *val,
                          const double *y, int64_t batch_rows, fmhip_dataset_t *out) {
     return dataset_create_impl<double>(device, n_rows, row_ptr, col, val, y, batch_rows, false, out);
+}
+
+int fmhip_dataset_create_opts(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const double *val,
+                              const double *y, const fmhip_dataset_opts *opts, fmhip_dataset_t *out) {
+    if (!opts || opts->struct_size != (int32_t)sizeof(fmhip_dataset_opts))
+        return fail(FMHIP_ERR_INVALID, "opts is NULL or its struct_size is not sizeof(fmhip_dataset_opts)");
+    return dataset_create_impl<double>(device, n_rows, row_ptr, col, val, y, opts->batch_rows, false, out, opts->hot_block,
+                                       opts->row_block_rows);
 }
 
 int fmhip_rows_create(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const double *val,

@@ -46,7 +46,8 @@ class Features:
 class DataSet(Features):
     """S/DataSet.scala:42-62.  ``rows`` of the reference = (label, SparseVector) pairs."""
 
-    def __init__(self, row_ptr, col, val, y, name="dataset", batch_rows=0, device=0, scoring=False):
+    def __init__(self, row_ptr, col, val, y, name="dataset", batch_rows=0, device=0, scoring=False, hot_block=None,
+                 row_block_rows=None):
         super().__init__(row_ptr, col, val)
         self.y = np.ascontiguousarray(y, self.val.dtype)
         if len(self.y) != self.size:
@@ -57,6 +58,8 @@ class DataSet(Features):
         # scoring: rows + labels only on the device (fmhip_rows_create) — held-out data for predict /
         # computeRMSE (S/driver.scala:100-112); nothing a training step needs is built
         self.scoring = bool(scoring)
+        # layout choices of THIS dataset (None = the library's defaults): dense hot block on/off, rows per row block
+        self.hot_block, self.row_block_rows = hot_block, row_block_rows
         self._h = None
 
     # -- constructors -------------------------------------------------------------
@@ -110,6 +113,12 @@ class DataSet(Features):
                 fn = L.fmhip_rows_create_f32 if f32 else L.fmhip_rows_create
                 _ffi.check(fn(self.device, self.size, _ffi.ptr(self.row_ptr), _ffi.ptr(self.col), _ffi.ptr(self.val),
                               _ffi.ptr(self.y), C.byref(h)))
+            elif self.hot_block is not None or self.row_block_rows is not None:
+                opts = _ffi.DatasetOpts(C.sizeof(_ffi.DatasetOpts), -1 if self.hot_block is None else int(bool(self.hot_block)),
+                                        self.batch_rows, -1 if self.row_block_rows is None else int(self.row_block_rows))
+                val64, y64 = self.val.astype(np.float64, copy=False), self.y.astype(np.float64, copy=False)
+                _ffi.check(L.fmhip_dataset_create_opts(self.device, self.size, _ffi.ptr(self.row_ptr), _ffi.ptr(self.col),
+                                                       _ffi.ptr(val64), _ffi.ptr(y64), C.byref(opts), C.byref(h)))
             else:
                 fn = L.fmhip_dataset_create_f32 if f32 else L.fmhip_dataset_create
                 _ffi.check(fn(self.device, self.size, _ffi.ptr(self.row_ptr), _ffi.ptr(self.col), _ffi.ptr(self.val),

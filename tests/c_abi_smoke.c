@@ -38,6 +38,17 @@ int main(void) {
     CHECK(fmhip_dataset_create(0, 2, bad_ptr, NULL, NULL, NULL, 0, &d) == FMHIP_ERR_INVALID && d == NULL);
     CHECK(strstr(fmhip_last_error(), "row_ptr decreases") != NULL);
     CHECK(fmhip_rows_create(0, 2, bad_ptr, NULL, NULL, NULL, &d) == FMHIP_ERR_INVALID);
+    {
+        fmhip_dataset_opts o;
+        memset(&o, 0, sizeof o);
+        CHECK(fmhip_dataset_create_opts(0, 2, bad_ptr, NULL, NULL, NULL, &o, &d) == FMHIP_ERR_INVALID);   /* struct_size unset */
+        CHECK(strstr(fmhip_last_error(), "struct_size") != NULL);
+        o.struct_size = (int32_t)sizeof o;
+        o.hot_block = -1;
+        o.row_block_rows = -1;
+        CHECK(fmhip_dataset_create_opts(0, 2, bad_ptr, NULL, NULL, NULL, &o, &d) == FMHIP_ERR_INVALID);
+        CHECK(strstr(fmhip_last_error(), "row_ptr decreases") != NULL);
+    }
     CHECK(fmhip_predict(NULL, NULL, NULL) == FMHIP_ERR_INVALID);
     CHECK(fmhip_dp_step(NULL, NULL, 0, NULL, 0.1, 0, 0, 0) == FMHIP_ERR_INVALID);
     CHECK(fmhip_comm_create(NULL, NULL, 0, 1, NULL) == FMHIP_ERR_INVALID);

@@ -413,3 +413,25 @@ def test_fused_update_is_bit_identical_to_the_update_launch(fmhip, k, regs):
     for _ in range(3):
         w0, w, v, _ = oracle.sgd_epoch(w0, w, v, 1100, a["row_ptr"], a["col"], a["val"], a["y"], 0.05, *regs)
     assert rel(outs[0][2], v) <= 1e-5 and rel(outs[0][1], w) <= 1e-5 and outs[0][0] == pytest.approx(w0, rel=1e-5, abs=1e-7)
+
+
+def test_per_dataset_layout_options(fmhip):
+    """fmhip_dataset_create_opts: the dense hot block is chosen per dataset, not through process-wide state; both
+    layouts report every stored nonzero and give the same gradient."""
+    from test_gpu_parity import hot_problem
+    a, hot_ids = hot_problem(808, 3000, 500, 32, 12)
+    grads = []
+    for hb in (True, False):
+        ds = fmhip.DataSet(a["row_ptr"], a["col"], a["val"], a["y"], batch_rows=700, hot_block=hb).cache()
+        lay = ds.layout()
+        assert (len(lay["hot_ids"]) > 0) == hb and (lay["nnz_sparse"] < ds.nnz) == hb
+        if hb:
+            assert set(lay["hot_ids"]) <= set(int(h) for h in hot_ids)
+        fm = fmhip.FMModel(a["n1"] - 1, a["k"])
+        fm.w0, fm.w, fm.v = a["w0"], a["w"], a["v"]
+        gv, gw, g0, st = fm.batchGradient(ds, 1)
+        assert st["nnz"] == a["row_ptr"][1400] - a["row_ptr"][700]
+        grads.append((gv, gw))
+        ds.unpersist()
+        fm.close()
+    check_grad(grads[0][0], grads[0][1], grads[1][0], grads[1][1], np.abs(a["v"]).max())
