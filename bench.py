@@ -358,6 +358,7 @@ def main():
     batch_rows = min(args.batch_rows or (625_000 if use_dp else 250_000), rows)
     regs = (0.0, 1e-4, 1e-4)
 
+    synth.set_threads(max(1, host_cores() // max(1, min(world, 8))) if world > 1 else host_cores())
     t0 = time.time()
     d = synth.make_config(config, rows=rows, row_begin=rank * rows)
     t_gen = time.time() - t0

@@ -9,11 +9,15 @@
  * does not depend on the thread count.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
 typedef __uint128_t u128;
+
+/* launchers export OMP_NUM_THREADS=1 to their ranks (torch.distributed.run does): the caller states the thread count */
+void fms_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 
 typedef struct { u128 state, inc; } pcg64;
 

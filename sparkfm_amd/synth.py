@@ -37,6 +37,8 @@ def _load():
         L.fms_zipf_fill.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_double,
                                     C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.fms_zipf_fill.restype = C.c_int
+        L.fms_set_threads.argtypes = [C.c_int]
+        L.fms_set_threads.restype = None
         L.fms_criteo_count.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]
         L.fms_criteo_count.restype = None
         L.fms_criteo_fill.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_double,
@@ -44,6 +46,11 @@ def _load():
         L.fms_criteo_fill.restype = C.c_int
         _lib = L
     return _lib
+
+
+def set_threads(n):
+    """OpenMP threads of the generator (launchers such as torch.distributed.run export OMP_NUM_THREADS=1)."""
+    _load().fms_set_threads(int(n))
 
 
 def make_zipf(seed, n_rows, n_features, nnz_lo, nnz_hi, zipf_s=1.05, k_true=4, noise=0.1, row_begin=0):
