@@ -12,16 +12,18 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    # FMHIP_TEST_ONE_GPU=1: every rank on device 0 (only works where RCCL accepts two ranks on one device)
+    dev = 0 if os.environ.get("FMHIP_TEST_ONE_GPU") else rank
     import torch.distributed as dist
     from sparkfm_amd import DataSet, FMModel, synth
     from sparkfm_amd.distributed import HipDataParallelSGD, RcclComm
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % port, rank=rank, world_size=world)
     # uneven shards: rank 1 has 2 batches against rank 0's 3
     d = synth.make_zipf(77, 3000 if rank == 0 else 1700, 800, 4, 24, zipf_s=1.05, row_begin=rank * 3000)
-    ds = DataSet.from_arrays(d, batch_rows=1000, device=rank).cache()
+    ds = DataSet.from_arrays(d, batch_rows=1000, device=dev).cache()
     w0, w, v = synth.init_params(5, 800, 32, stdev=0.05)
     w = np.random.default_rng(9).normal(0, 0.05, 800)
-    fm = FMModel(799, 32, device=rank)
+    fm = FMModel(799, 32, device=dev)
     fm.w0, fm.w, fm.v = w0, w, v
     comm = RcclComm(fm, rank, world)
     dp = HipDataParallelSGD(comm, eta=0.05, regw=1e-3, regv=1e-3)
