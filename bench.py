@@ -298,8 +298,8 @@ def spawn_ranks(args, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default=None, choices=["C1", "C2", "C3", "C4", "C5"],
                     help="default: C3 on one GPU (the metric's configuration), C4 on several (BASELINE's 8-GPU config)")
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the config's rows / N, capped at 2.5M)")
@@ -316,6 +316,10 @@ def main():
                          "time a few candidates during warm-up and keep the fastest (all ranks agree through a max-reduce)")
     ap.add_argument("--force-dp", action="store_true",
                     help="self-test: take the data-parallel path (RCCL all-reduce included) even with one rank")
+    ap.add_argument("--emulate-allreduce", default="",
+                    help="RANKS:BUSBW_GBps, one-rank runs only (with --force-dp): hold the comm stream after every collective for "
+                         "the time a ring all-reduce over RANKS GPUs at that bus bandwidth would take (fmhip_comm_emulate), so the "
+                         "overlap schedule and the cut tuning can be timed on a one-GPU box")
     ap.add_argument("--cpu-budget", type=float, default=30.0)
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -389,6 +393,13 @@ def main():
             dp = HipDataParallelSGD(comm, eta=args.eta, reg0=regs[0], regw=regs[1], regv=regs[2],
                                     upper_fractions=fixed if fixed is not None else (0.3,))
             dp.plan(fm, ds)
+            if args.emulate_allreduce:
+                if world != 1:
+                    raise SystemExit("--emulate-allreduce is for one-rank runs")
+                emu_ranks, emu_busbw = args.emulate_allreduce.split(":")
+                emu_ranks, emu_busbw = int(emu_ranks), float(emu_busbw)
+                # ring all-reduce: 2(N-1)/N of the payload crosses each rank's links -> payload rate = busbw * N / (2(N-1))
+                _ffi.check(L.fmhip_comm_emulate(comm.handle, emu_busbw * emu_ranks / (2.0 * (emu_ranks - 1))))
         except Exception as ex:   # noqa: BLE001 — reported in the JSON line, never silent
             # every rank fails or succeeds together (communicator creation is collective); fall back to the
             # Python-orchestrated exchange over torch.distributed
@@ -429,7 +440,7 @@ def main():
     sync()
     barrier()
     tuning = None
-    if exchange == "rccl" and args.upper_fractions == "auto" and world > 1:
+    if exchange == "rccl" and args.upper_fractions == "auto" and (world > 1 or args.emulate_allreduce):
         # measure, don't guess: the best cut depends on the all-reduce's real bandwidth on this node
         tuning = []
         for cand in ((0.45,), (0.3,), (0.2,), (0.12, 0.4), (0.08, 0.25, 0.5), ()):
@@ -443,7 +454,8 @@ def main():
                 step(j)
             sync()
             tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            if use_dp:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             tuning.append({"upper_fractions": list(cand), "cuts": list(dp.cuts), "ms_per_step": float(tt[0]) / 4 * 1e3})
         best = min(tuning, key=lambda x: x["ms_per_step"])
         dp.upper_fractions = tuple(best["upper_fractions"])
@@ -612,6 +624,8 @@ def main():
                 xc["note"] = comm_note
             if tuning:
                 xc["cut_tuning"] = tuning
+            if args.emulate_allreduce:
+                xc["emulated"] = "ring all-reduce over %s GPUs at bus bandwidth %s GB/s, as a delay on the comm stream (one real rank)" % tuple(args.emulate_allreduce.split(":"))
             out["exchange"] = xc
         if world == 1 and not args.no_cpu_baseline and not wide:
             out["cpu_baseline"] = cpu_baseline(d, k, n1, batch_rows, args.eta, regs, w0, w, v, args.cpu_budget)

@@ -284,6 +284,11 @@ typedef struct fmhip_comm_profile {
     double exposed_ms, comm_ms;
     int64_t steps, bytes;
 } fmhip_comm_profile;
+/* Measurement aid for boxes with fewer GPUs than the job: after every collective the comm stream is held
+ * for payload_bytes / (payload_gb_per_s GB/s) by a one-wave delay kernel — the time a real all-reduce of
+ * that payload would take at that rate — so the overlap schedule can be timed with one rank.  0 = off.
+ * (Optimistic: a real collective also takes CUs and memory bandwidth from the backward beside it.) */
+int fmhip_comm_emulate(fmhip_comm_t c, double payload_gb_per_s);
 int fmhip_comm_profile_begin(fmhip_comm_t c);
 int fmhip_comm_profile_end(fmhip_comm_t c, fmhip_comm_profile *p);
 /* Contiguous row shard [lo, hi) of `rank`, balanced by stored nonzeros (not by row count): the

@@ -28,7 +28,7 @@ SYMBOLS = (
     "fmhip_step_stats", "fmhip_profile_begin", "fmhip_profile_begin_rotating", "fmhip_profile_end",
     "fmhip_rows_create", "fmhip_rows_create_f32", "fmhip_predict_rows", "fmhip_model_init_normal", "fmhip_dataset_layout", "fmhip_dataset_create_opts",
     "fmhip_comm_unique_id", "fmhip_comm_create", "fmhip_comm_destroy", "fmhip_comm_info", "fmhip_dp_plan",
-    "fmhip_dp_step", "fmhip_dp_epoch", "fmhip_comm_profile_begin", "fmhip_comm_profile_end", "fmhip_shard_rows",
+    "fmhip_dp_step", "fmhip_dp_epoch", "fmhip_comm_profile_begin", "fmhip_comm_profile_end", "fmhip_shard_rows", "fmhip_comm_emulate",
 )
 UNIQUE_ID_BYTES = 128
 
@@ -139,6 +139,7 @@ def load():
     L.fmhip_dp_plan.argtypes = [vp, vp, vp, C.c_int, vp, vp]
     L.fmhip_dp_step.argtypes = [vp, vp, i64, vp, dbl, dbl, dbl, dbl]
     L.fmhip_dp_epoch.argtypes = [vp, vp, vp, dbl, dbl, dbl, dbl, P(Stats)]
+    L.fmhip_comm_emulate.argtypes = [vp, dbl]
     L.fmhip_comm_profile_begin.argtypes = [vp]
     L.fmhip_comm_profile_end.argtypes = [vp, P(CommProfile)]
     L.fmhip_shard_rows.argtypes = [i64, vp, C.c_int, C.c_int, P(i64), P(i64)]

@@ -90,6 +90,13 @@ int need_rccl() {
 
 constexpr int kMaxCuts = 7;      // == FMHIP_DP_MAX_CUTS
 
+// Stand-in for a collective's duration on the comm stream (fmhip_comm_emulate): one wave spins on the
+// constant-rate clock (100 MHz) until `ticks` have passed.  Bounded by construction; occupies one wave of one CU.
+__global__ void k_comm_delay(uint64_t ticks) {
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 struct CommProf {
     hipEvent_t wait_a = nullptr, wait_b = nullptr;   // compute stream: around its wait for the last collective
     hipEvent_t c0[kMaxCuts + 1] = {}, c1[kMaxCuts + 1] = {};   // comm stream: around each collective
@@ -106,6 +113,7 @@ struct fmhip_comm {
     hipEvent_t ev_done = nullptr;             // comm stream: the last collective has finished
     std::vector<int64_t> cuts;                // ascending feature ids in (0, n+1) cutting the backward into intervals (empty: one collective)
     int64_t *scratch = nullptr;               // device int64[kMaxCuts + 1] for the small control collectives
+    double emu_bytes_per_us = 0.0;            // > 0: every collective is followed by a delay of bytes / this (fmhip_comm_emulate)
     bool profiling = false;
     std::vector<CommProf> prof;
     int64_t prof_bytes = 0;
@@ -131,16 +139,20 @@ int check_comm(fmhip_model_t m, fmhip_comm_t c) {
 int reduce_slice(fmhip_model_t m, fmhip_comm_t c, float *buf, size_t count, hipEvent_t after, CommProf *pr) {
     HIP_TRY(hipEventRecord(after, m->stream));
     HIP_TRY(hipStreamWaitEvent(c->cs, after, 0));
+    int pi = -1;
     if (pr) {
-        const int i = pr->n_coll++;
-        HIP_TRY(hipEventCreate(&pr->c0[i]));
-        HIP_TRY(hipEventCreate(&pr->c1[i]));
-        HIP_TRY(hipEventRecord(pr->c0[i], c->cs));
-        NCCL_TRY(rccl().AllReduce(buf, buf, count, ncclFloat, ncclSum, c->comm, c->cs));
-        HIP_TRY(hipEventRecord(pr->c1[i], c->cs));
-    } else {
-        NCCL_TRY(rccl().AllReduce(buf, buf, count, ncclFloat, ncclSum, c->comm, c->cs));
+        pi = pr->n_coll++;
+        HIP_TRY(hipEventCreate(&pr->c0[pi]));
+        HIP_TRY(hipEventCreate(&pr->c1[pi]));
+        HIP_TRY(hipEventRecord(pr->c0[pi], c->cs));
     }
+    NCCL_TRY(rccl().AllReduce(buf, buf, count, ncclFloat, ncclSum, c->comm, c->cs));
+    if (c->emu_bytes_per_us > 0.0) {
+        const double us = (double)(count * sizeof(float)) / c->emu_bytes_per_us;
+        hipLaunchKernelGGL(k_comm_delay, dim3(1), dim3(64), 0, c->cs, (uint64_t)(us * 100.0));
+        HIP_TRY(hipGetLastError());
+    }
+    if (pr) HIP_TRY(hipEventRecord(pr->c1[pi], c->cs));
     c->prof_bytes += c->profiling ? (int64_t)(count * sizeof(float)) : 0;
     return FMHIP_OK;
 }
@@ -253,6 +265,13 @@ int fmhip_comm_destroy(fmhip_comm_t c) {
     if (c->cs) (void)hipStreamDestroy(c->cs);
     if (c->scratch) (void)hipFree(c->scratch);
     delete c;
+    return FMHIP_OK;
+}
+
+int fmhip_comm_emulate(fmhip_comm_t c, double payload_gb_per_s) {
+    if (!c) return fail(FMHIP_ERR_INVALID, "communicator is NULL");
+    if (payload_gb_per_s < 0.0) return fail(FMHIP_ERR_INVALID, "negative rate");
+    c->emu_bytes_per_us = payload_gb_per_s * 1e3;      // GB/s = 1e3 bytes per microsecond
     return FMHIP_OK;
 }
 
