@@ -66,11 +66,11 @@ __device__ __forceinline__ void apply_w0(const ApplyArgs &a, float invb) {
 template <int KP>
 __global__ __launch_bounds__(kBlock) void k_apply(ApplyArgs a) {
     constexpr int LPR = KP / 4;  // lanes per feature row (<= 64, divides the wave)
-    const float invb = a.scal[2] > 0.f ? 1.0f / a.scal[2] : 0.f;
-    const int64_t total = a.n1 * LPR;
+    const float rows = *a.rows, invb = rows > 0.f ? 1.0f / rows : 0.f;
+    const int64_t total = (a.row_hi - a.row_lo) * LPR;
     for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kBlock)
-        apply_piece<KP, false>(a, idx / LPR, (int)(idx % LPR), invb);
-    apply_w0(a, invb);
+        apply_piece<KP, false>(a, a.row_lo + idx / LPR, (int)(idx % LPR), invb);
+    if (a.do_w0) apply_w0(a, invb);
 }
 
 // The same update restricted to the rows a batch touched (its distinct features + the dense hot
@@ -80,14 +80,14 @@ __global__ __launch_bounds__(kBlock) void k_apply(ApplyArgs a) {
 template <int KP>
 __global__ __launch_bounds__(kBlock) void k_apply_rows(ApplyArgs a) {
     constexpr int LPR = KP / 4;
-    const float invb = a.scal[2] > 0.f ? 1.0f / a.scal[2] : 0.f;
+    const float rows = *a.rows, invb = rows > 0.f ? 1.0f / rows : 0.f;
     const int64_t total = ((int64_t)a.n_feat + a.n_hot) * LPR;
     for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kBlock) {
         const int64_t j = idx / LPR;
         const int32_t i = j < a.n_feat ? a.feat[j] : a.hot_ids[j - a.n_feat];
         if (i >= 0) apply_piece<KP, true>(a, i, (int)(idx % LPR), invb);
     }
-    apply_w0(a, invb);
+    if (a.do_w0) apply_w0(a, invb);
 }
 
 
@@ -130,7 +130,7 @@ hipError_t launch_init_normal(int Kp, float *V, float *w, float *w0, int64_t n1,
 
 hipError_t launch_apply(int Kp, const ApplyArgs &a, hipStream_t s) {
     const bool rows_only = a.feat != nullptr;
-    int64_t total = (rows_only ? (int64_t)a.n_feat + a.n_hot : a.n1) * (Kp / 4);
+    int64_t total = (rows_only ? (int64_t)a.n_feat + a.n_hot : a.row_hi - a.row_lo) * (Kp / 4);
     int64_t blocks = (total + kBlock - 1) / kBlock;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;

@@ -121,7 +121,10 @@ struct ApplyArgs {
     float *V, *w, *w0;
     float *GV, *Gw, *Gb;
     const float *scal;  // {sum e, sum e^2, rows, ...}
+    const float *rows;  // the batch's (global) row count |B|: scal + 2 unless it was exchanged on its own
     int64_t n1;         // n+1 (rows of V actually used)
+    int64_t row_lo, row_hi;   // dense pass: the feature rows [row_lo, row_hi) (whole model: 0, n1)
+    int32_t do_w0;      // this launch also steps w0 (once per step)
     int32_t pack_k;     // >= 0: packed rows — slot pack_k of a V row is the linear weight
     float eta, reg0, regw, regv;
     // scale of the stored tables on entry (V = sv_in * stored, w = sw_in * stored; fm_apply.hip).  The dense

@@ -836,7 +836,11 @@ int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double reg
     a.Gw = m->Gw();
     a.Gb = m->Gb();
     a.scal = m->scal();
+    a.rows = m->scal() + 2;
     a.n1 = m->n1;
+    a.row_lo = 0;
+    a.row_hi = m->n1;
+    a.do_w0 = 1;
     a.pack_k = m->pack_k();
     a.eta = (float)eta;
     a.reg0 = (float)reg0;
@@ -853,6 +857,45 @@ int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double reg
     m->grad_dirty = false;
     m->host64_fresh = false;
     ++m->prof_step;
+    return FMHIP_OK;
+}
+
+// The dense update of the feature rows [lo, hi) only — the data-parallel step applies an interval as soon as its
+// slice of the gradient has been exchanged (fmhip_comm.hip).  `rows`: device float holding the global row count;
+// `last`: the final interval of the step (also steps w0 from the head's scalars and closes the step's bookkeeping).
+int step_apply_interval(fmhip_model_t m, double eta, double reg0, double regw, double regv, int64_t lo, int64_t hi,
+                        const float *rows, bool last) {
+    ApplyArgs a{};
+    a.sv_in = (float)m->sv;
+    a.sw_in = (float)m->sw;
+    a.eta_v = a.eta_w = (float)eta;
+    a.V = m->V.p;
+    a.w = m->w.p;
+    a.w0 = m->w0.p;
+    a.GV = m->GV();
+    a.Gw = m->Gw();
+    a.Gb = m->Gb();
+    a.scal = m->scal();
+    a.rows = rows;
+    a.n1 = m->n1;
+    a.row_lo = lo;
+    a.row_hi = hi;
+    a.do_w0 = last ? 1 : 0;
+    a.pack_k = m->pack_k();
+    a.eta = (float)eta;
+    a.reg0 = (float)reg0;
+    a.regw = (float)regw;
+    a.regv = (float)regv;
+    if (hi > lo || last) {
+        ProfScope ps(m, FMHIP_K_APPLY, m->last_nnz, m->last_rows);
+        HIP_TRY(launch_apply(m->Kp, a, m->stream));
+    }
+    if (last) {
+        m->sv = m->sw = 1.0;      // every interval folded the pending scale
+        m->grad_dirty = false;
+        m->host64_fresh = false;
+        ++m->prof_step;
+    }
     return FMHIP_OK;
 }
 

@@ -11,8 +11,10 @@
 // loader hands back that copy instead of a second runtime.
 //
 // Schedule of one step (two streams, no host synchronisation):
-//   compute stream  forward | backward(cold ids) | backward(hot ids) + statistics |      wait | apply
-//   comm stream                                  | all-reduce(cold slice)         | all-reduce(head + hot slice)
+//   compute stream  forward | backward(cold ids) | backward(hot ids) + statistics | wait 1 | apply(cold rows) | wait 2 | apply(hot rows, w0)
+//   comm stream     rows    |                    | all-reduce(cold slice)         | all-reduce(hot slice + scalars)
+// (a slice = the G_V, G_w and G_b rows of a feature interval, one grouped call; the row count |B| is exchanged at the
+// start of the step so that an interval can be applied as soon as ITS slice has arrived, beside the later slices)
 // The CSC stream is sorted by feature id, so the backward can deliver the gradient rows of an interval of
 // ids at a time; the cold interval is nearly all of the gradient's volume and under half of the work.
 // More cuts give a deeper pipeline (the collective of interval i runs beside the backward of interval i+1).
@@ -41,6 +43,8 @@ struct Rccl {
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
 };
 
 Rccl &rccl() {
@@ -67,6 +71,8 @@ Rccl &rccl() {
         r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
         r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
         if (!ok) {
             dlclose(r.handle);
             r.handle = nullptr;
@@ -97,10 +103,15 @@ __global__ void k_comm_delay(uint64_t ticks) {
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
+// the row count of this rank's mini-batch travels as a kernel argument (a host buffer would have to outlive the
+// asynchronous copy, and the host runs steps ahead of the stream)
+__global__ void k_set_float(float *p, float v) { *p = v; }
+
 struct CommProf {
     hipEvent_t wait_a = nullptr, wait_b = nullptr;   // compute stream: around its wait for the last collective
     hipEvent_t c0[kMaxCuts + 1] = {}, c1[kMaxCuts + 1] = {};   // comm stream: around each collective
-    int n_coll = 0;
+    hipEvent_t a0[kMaxCuts + 1] = {}, a1[kMaxCuts + 1] = {};   // compute stream: around each interval's update
+    int n_coll = 0, n_apply = 0;
 };
 
 }  // namespace
@@ -110,7 +121,9 @@ struct fmhip_comm {
     ncclComm_t comm = nullptr;
     hipStream_t cs = nullptr;                 // the collectives' stream
     hipEvent_t ev_ready[kMaxCuts + 1] = {};   // compute stream: interval i of the gradient is final
-    hipEvent_t ev_done = nullptr;             // comm stream: the last collective has finished
+    hipEvent_t ev_done[kMaxCuts + 1] = {};    // comm stream: interval i's slice has been exchanged
+    hipEvent_t ev_rows = nullptr;             // compute stream: this rank's row count is in place
+    float *rows_dev = nullptr;                // device float: the step's global row count |B| (exchanged first)
     std::vector<int64_t> cuts;                // ascending feature ids in (0, n+1) cutting the backward into intervals (empty: one collective)
     int64_t *scratch = nullptr;               // device int64[kMaxCuts + 1] for the small control collectives
     double emu_bytes_per_us = 0.0;            // > 0: every collective is followed by a delay of bytes / this (fmhip_comm_emulate)
@@ -125,7 +138,7 @@ void destroy_events(CommProf &p) {
     for (hipEvent_t e : {p.wait_a, p.wait_b})
         if (e) (void)hipEventDestroy(e);
     for (int i = 0; i <= kMaxCuts; ++i)
-        for (hipEvent_t e : {p.c0[i], p.c1[i]})
+        for (hipEvent_t e : {p.c0[i], p.c1[i], p.a0[i], p.a1[i]})
             if (e) (void)hipEventDestroy(e);
 }
 
@@ -135,8 +148,14 @@ int check_comm(fmhip_model_t m, fmhip_comm_t c) {
     return set_device(m->device);
 }
 
-// one collective on the comm stream behind `after` (an event of the compute stream)
-int reduce_slice(fmhip_model_t m, fmhip_comm_t c, float *buf, size_t count, hipEvent_t after, CommProf *pr) {
+struct Region {
+    float *p;
+    size_t n;
+};
+
+// The all-reduce of up to three regions of the packed gradient (one grouped call) on the comm stream, behind `after`
+// (an event of the compute stream); `done` is recorded behind it.
+int reduce_regions(fmhip_model_t m, fmhip_comm_t c, const Region *reg, int n_reg, hipEvent_t after, hipEvent_t done, CommProf *pr) {
     HIP_TRY(hipEventRecord(after, m->stream));
     HIP_TRY(hipStreamWaitEvent(c->cs, after, 0));
     int pi = -1;
@@ -146,19 +165,35 @@ int reduce_slice(fmhip_model_t m, fmhip_comm_t c, float *buf, size_t count, hipE
         HIP_TRY(hipEventCreate(&pr->c1[pi]));
         HIP_TRY(hipEventRecord(pr->c0[pi], c->cs));
     }
-    NCCL_TRY(rccl().AllReduce(buf, buf, count, ncclFloat, ncclSum, c->comm, c->cs));
+    size_t bytes = 0;
+    if (n_reg > 1) NCCL_TRY(rccl().GroupStart());
+    for (int i = 0; i < n_reg; ++i) {
+        if (!reg[i].n) continue;
+        NCCL_TRY(rccl().AllReduce(reg[i].p, reg[i].p, reg[i].n, ncclFloat, ncclSum, c->comm, c->cs));
+        bytes += reg[i].n * sizeof(float);
+    }
+    if (n_reg > 1) NCCL_TRY(rccl().GroupEnd());
     if (c->emu_bytes_per_us > 0.0) {
-        const double us = (double)(count * sizeof(float)) / c->emu_bytes_per_us;
+        const double us = (double)bytes / c->emu_bytes_per_us;
         hipLaunchKernelGGL(k_comm_delay, dim3(1), dim3(64), 0, c->cs, (uint64_t)(us * 100.0));
         HIP_TRY(hipGetLastError());
     }
     if (pr) HIP_TRY(hipEventRecord(pr->c1[pi], c->cs));
-    c->prof_bytes += c->profiling ? (int64_t)(count * sizeof(float)) : 0;
+    HIP_TRY(hipEventRecord(done, c->cs));
+    c->prof_bytes += c->profiling ? (int64_t)bytes : 0;
     return FMHIP_OK;
 }
 
 int dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0, double regw, double regv) {
     const bool live = batch >= 0;
+    // |B| first: every interval's update divides by the GLOBAL row count, so it is exchanged on its own (4 bytes,
+    // hidden under the forward) instead of waiting for the head in the last message
+    const float my_rows = live ? (float)d->batches[(size_t)batch].rows : 0.f;
+    hipLaunchKernelGGL(k_set_float, dim3(1), dim3(1), 0, m->stream, c->rows_dev, my_rows);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_rows, m->stream));
+    HIP_TRY(hipStreamWaitEvent(c->cs, c->ev_rows, 0));
+    NCCL_TRY(rccl().AllReduce(c->rows_dev, c->rows_dev, 1, ncclFloat, ncclSum, c->comm, c->cs));
     if (live) {
         TRY(step_forward(m, d, batch));
     } else {
@@ -172,31 +207,48 @@ int dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, d
         c->prof.emplace_back();
         pr = &c->prof.back();
     }
-    // intervals [cuts[i], cuts[i+1]) from the top down; the lowest one carries the head (scalars | G_w | G_b), which
-    // lies right in front of feature 0's row: one message
+    // intervals [edge[i], edge[i+1]) from the top down; the lowest one carries the statistics scalars
     std::vector<int64_t> edge{0};
     if (d->rb_rows == 0)
         for (int64_t x : c->cuts)
             if (x > edge.back() && x < m->n1) edge.push_back(x);
     edge.push_back(m->n1);
-    for (size_t i = edge.size() - 1; i-- > 0;) {
-        const int64_t lo = edge[i], hi = edge[i + 1];
-        const bool last = i == 0, whole = edge.size() == 2;
-        if (live) TRY(step_backward(m, d, batch, lo, whole ? INT64_MAX : hi, last, nullptr));
-        const int64_t hi_rows = hi == m->n1 ? m->n1p : hi;      // the padding rows ride with the top interval
-        if (last) TRY(reduce_slice(m, c, m->grad, m->head_floats() + (size_t)hi_rows * m->Kp, c->ev_ready[i], pr));
-        else TRY(reduce_slice(m, c, m->GV() + (size_t)lo * m->Kp, (size_t)(hi_rows - lo) * m->Kp, c->ev_ready[i], pr));
+    const int n_int = (int)edge.size() - 1;
+    for (int i = n_int - 1; i >= 0; --i) {
+        const int64_t lo = edge[(size_t)i], hi = edge[(size_t)i + 1];
+        const bool last = i == 0;
+        if (live) TRY(step_backward(m, d, batch, lo, n_int == 1 ? INT64_MAX : hi, last, nullptr));
+        if (n_int == 1) {
+            const Region whole[1] = {{m->grad, m->grad_floats()}};
+            TRY(reduce_regions(m, c, whole, 1, c->ev_ready[i], c->ev_done[i], pr));
+        } else {
+            // G_V rows, G_w and G_b of the interval; the lowest interval's G_w region starts at the scalars in front of it
+            const Region reg[3] = {{m->GV() + (size_t)lo * m->Kp, (size_t)(hi - lo) * m->Kp},
+                                   {last ? m->grad : m->Gw() + lo, (size_t)(hi - lo) + (last ? (size_t)kGradHead : 0)},
+                                   {m->Gb() + lo, (size_t)(hi - lo)}};
+            TRY(reduce_regions(m, c, reg, 3, c->ev_ready[i], c->ev_done[i], pr));
+        }
     }
     m->bw_next_hi = -1;
-    HIP_TRY(hipEventRecord(c->ev_done, c->cs));
     if (pr) {
         HIP_TRY(hipEventCreate(&pr->wait_a));
         HIP_TRY(hipEventCreate(&pr->wait_b));
         HIP_TRY(hipEventRecord(pr->wait_a, m->stream));
     }
-    HIP_TRY(hipStreamWaitEvent(m->stream, c->ev_done, 0));
+    // update every interval as its slice arrives (identical on all ranks: replicas stay bit-identical)
+    for (int i = n_int - 1; i >= 0; --i) {
+        HIP_TRY(hipStreamWaitEvent(m->stream, c->ev_done[i], 0));
+        if (pr) {
+            const int ai = pr->n_apply++;
+            HIP_TRY(hipEventCreate(&pr->a0[ai]));
+            HIP_TRY(hipEventCreate(&pr->a1[ai]));
+            HIP_TRY(hipEventRecord(pr->a0[ai], m->stream));
+        }
+        TRY(step_apply_interval(m, eta, reg0, regw, regv, edge[(size_t)i], edge[(size_t)i + 1], c->rows_dev, i == 0));
+        if (pr) HIP_TRY(hipEventRecord(pr->a1[pr->n_apply - 1], m->stream));
+    }
     if (pr) HIP_TRY(hipEventRecord(pr->wait_b, m->stream));
-    return step_apply(m, eta, reg0, regw, regv);   // dense: after the exchange every row may carry a gradient
+    return FMHIP_OK;
 }
 
 // small control collectives (a count, a cut) through a device scratch word
@@ -243,8 +295,10 @@ int fmhip_comm_create(fmhip_model_t m, const void *id, int rank, int world, fmhi
     }
     hipError_t e = hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking);
     for (int i = 0; i <= kMaxCuts && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_ready[i], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
+    for (int i = 0; i <= kMaxCuts && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->scratch), (kMaxCuts + 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->rows_dev), 32 * sizeof(float));
     if (e != hipSuccess) {
         fmhip_comm_destroy(c);
         return fail(FMHIP_ERR_HIP, "communicator resources: %s", hipGetErrorString(e));
@@ -261,7 +315,10 @@ int fmhip_comm_destroy(fmhip_comm_t c) {
     if (c->comm) (void)rccl().CommDestroy(c->comm);
     for (hipEvent_t e : c->ev_ready)
         if (e) (void)hipEventDestroy(e);
-    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    for (hipEvent_t e : c->ev_done)
+        if (e) (void)hipEventDestroy(e);
+    if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
+    if (c->rows_dev) (void)hipFree(c->rows_dev);
     if (c->cs) (void)hipStreamDestroy(c->cs);
     if (c->scratch) (void)hipFree(c->scratch);
     delete c;
@@ -361,7 +418,10 @@ int fmhip_comm_profile_end(fmhip_comm_t c, fmhip_comm_profile *p) {
     HIP_TRY(hipDeviceSynchronize());
     for (auto &r : c->prof) {
         float ms = 0.f;
+        // what the compute stream spent between its last backward and the end of the step, minus the updates themselves
         if (r.wait_a && r.wait_b && hipEventElapsedTime(&ms, r.wait_a, r.wait_b) == hipSuccess) p->exposed_ms += ms;
+        for (int i = 0; i < r.n_apply; ++i)
+            if (hipEventElapsedTime(&ms, r.a0[i], r.a1[i]) == hipSuccess) p->exposed_ms -= ms;
         for (int i = 0; i < r.n_coll; ++i)
             if (hipEventElapsedTime(&ms, r.c0[i], r.c1[i]) == hipSuccess) p->comm_ms += ms;
         p->steps += 1;

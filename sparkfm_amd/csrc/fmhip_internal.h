@@ -187,6 +187,8 @@ struct FusedPlan {
 int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo, int64_t feat_hi, bool finish, double *acc,
                   const FusedPlan *fused = nullptr);
 int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double regv, fmhip_dataset_t d = nullptr, int64_t b = -1);
+int step_apply_interval(fmhip_model_t m, double eta, double reg0, double regw, double regv, int64_t lo, int64_t hi,
+                        const float *rows, bool last);
 int read_scal(fmhip_model_t m, fmhip_stats *st);
 
 }  // namespace host
