@@ -391,7 +391,7 @@ def main():
             fixed = None if args.upper_fractions == "auto" else (() if args.upper_fractions == "none" else
                                                                  tuple(float(x) for x in args.upper_fractions.split(",")))
             dp = HipDataParallelSGD(comm, eta=args.eta, reg0=regs[0], regw=regs[1], regv=regs[2],
-                                    upper_fractions=fixed if fixed is not None else (0.3,))
+                                    upper_fractions=fixed if fixed is not None else (0.08, 0.25, 0.5))
             dp.plan(fm, ds)
             if args.emulate_allreduce:
                 if world != 1:
