@@ -90,11 +90,11 @@ int fmhip_device_count(int *count);
  *                           frequency-ranked (hot = low id), results are the same either way
  *   key 1  backward kernel: 1 = pipelined buffer-load walk (default), 0 = plain walk
  *   key 2  LDS tile rows : 0 = auto (V-tile: as many rows as fit 128 KiB; w-tile: 6144)
- *   key 3  rows per row block of the transposes built by the NEXT fmhip_dataset_create (0 = off):
+ *   key 3  default rows per row block of the transposes fmhip_dataset_create builds (0 = off):
  *          entries sorted by (row block, feature) so a block's slice of P stays L2-resident in the
  *          backward; features occurring in several blocks are summed by an extra fixup pass
  *   key 4  XCD-aware workgroup placement in the backward (0 = off, default)
- *   key 5  dense hot block, applied by the NEXT fmhip_dataset_create (1 = on, default; 0 = off): in a
+ *   key 5  default for the dense hot block of the datasets fmhip_dataset_create builds (1 = on; 0 = off): in a
  *          dataset of more than one mini-batch the (at most 16) features present in >= 10 % of the rows —
  *          none that occurs twice in a row or with a stored zero — leave the sparse streams for a dense
  *          [rows][16] fp32 array; their V rows are served from LDS in the forward and their gradient rows
@@ -115,6 +115,10 @@ int fmhip_device_count(int *count);
  *          launch) whenever the rows-only update is legal.  Bit-identical to the separate update launch;
  *          off by default because the read-modify-write of the parameter row sits in the column walk's
  *          dependent chain (C3: backward +20 us against 12 us of update launch saved).
+ *   key 11 merged finish (1 = on, default): when the fused step's update is the dense pass it runs inside the
+ *          fixup launch — the rows the fixups assemble update themselves from registers, every other row is
+ *          updated by extra workgroups beside them (bandwidth-bound work next to latency-bound work) — instead
+ *          of as a launch of its own.  Bit-identical; 0 = separate update launch.
  * Keys 3 and 5 are only the DEFAULTS of fmhip_dataset_create (read at the time of the call; they decide the
  * layout of the dataset being built and nothing else) — fmhip_dataset_create_opts states them per dataset;
  * every other key is read by the next launch. */
@@ -122,17 +126,17 @@ int fmhip_tune(int key, int value);
 
 /* ---- model: `new FMModel(num_attribute, num_factor)`  S/fm/FMModel.scala:9-22 -- */
 /* Parameters start at zero; the reference's unseeded N(0, 0.01) init (quirk Q2) is the
- * caller's job: draw on the host, then fmhip_model_set_params.  `stream` is a
+ * caller's job: draw on the host, then fmhip_model_set_params — or fmhip_model_init_normal.  `stream` is a
  * hipStream_t (NULL = the library creates its own non-blocking stream). */
 int fmhip_model_create(int device, int64_t num_attribute, int32_t num_factor, void *stream, fmhip_model_t *out);
 int fmhip_model_destroy(fmhip_model_t m);
 /* padded_factors: floats per device row (whole 128-B lines: 32, 64, 128 or 256) */
 int fmhip_model_info(fmhip_model_t m, int64_t *num_attribute, int32_t *num_factor, int32_t *padded_factors);
-/* w: n+1 doubles, v: k*(n+1) doubles at v[f + i*k]  (FMModel.w0 / .w / .v, S/fm/FMModel.scala:17-19) */
 /* The reference's own initialisation, drawn on the device: w0 = 0, w = 0, v ~ N(mean, stdev)
  * (S/fm/FMModel.scala:17-22; its draw is unseeded — quirk Q2 — here `seed` makes it reproducible: element
  * (f, i) depends only on (seed, f, i)).  For models too wide to stage on the host (2^25 x 64: 17 GB fp64). */
 int fmhip_model_init_normal(fmhip_model_t m, uint64_t seed, double mean, double stdev);
+/* w: n+1 doubles, v: k*(n+1) doubles at v[f + i*k]  (FMModel.w0 / .w / .v, S/fm/FMModel.scala:17-19) */
 int fmhip_model_set_params(fmhip_model_t m, double w0, const double *w, const double *v);
 int fmhip_model_get_params(fmhip_model_t m, double *w0, double *w, double *v);
 int fmhip_model_set_params_f32(fmhip_model_t m, float w0, const float *w, const float *v);

@@ -41,16 +41,51 @@ __device__ __forceinline__ void apply_row(const FusedUpd &u, int pack_k, int i, 
     if (l == sl && pack_k < 0) u.w[i] = u.w[i] - u.eta_w * (sa * u.invb);
 }
 
+// Merged finish: the dense update of parameter row i straight from the registers that hold its finished gradient
+// (acc = G_V row, sa = G_w, sb = G_b; the scalars are valid in lane sl of the slot) — apply_piece<KP, false> of
+// fm_device.h, operation for operation; the packed gradient's row is never written (it stays zero).
+template <int LPN, int J>
+__device__ __forceinline__ void finish_row(const ApplyArgs &f, int i, int l, const float4 (&acc)[J], float sa, float sb, int sl) {
+    constexpr int KP = 4 * LPN * J;
+    const float invb = f.invb_val;
+    const float b = __shfl(sb, sl, LPN), gw = __shfl(sa, sl, LPN);
+    float4 *V4 = reinterpret_cast<float4 *>(f.V + (size_t)i * KP) + l;
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+        float4 u = V4[jj * LPN];
+        const float4 g = acc[jj];
+        float4 v = f4mul(u, f.sv_in);
+        const bool has_w = f.pack_k >= 0 && (l + jj * LPN) == (f.pack_k >> 2);
+        float wslot = 0.f;
+        if (has_w) {
+            const float wi = f4pick(u, f.pack_k & 3) * f.sw_in;
+            wslot = wi - f.eta * fmaf(f.regw, wi, f4pick(g, f.pack_k & 3) * invb);
+        }
+        u.x = v.x - f.eta * fmaf(f.regv, v.x, (g.x - v.x * b) * invb);
+        u.y = v.y - f.eta * fmaf(f.regv, v.y, (g.y - v.y * b) * invb);
+        u.z = v.z - f.eta * fmaf(f.regv, v.z, (g.z - v.z * b) * invb);
+        u.w = v.w - f.eta * fmaf(f.regv, v.w, (g.w - v.w * b) * invb);
+        if (has_w) f4set(u, f.pack_k & 3, wslot);
+        V4[jj * LPN] = u;
+    }
+    if (l == sl) {
+        const float wi = f.w[i] * f.sw_in;
+        f.w[i] = wi - f.eta * fmaf(f.regw, wi, (f.pack_k >= 0 ? 0.f : gw) * invb);
+    }
+}
+
 // A finished column piece goes to its destination: the G row of its feature (or, fused, straight into the
 // parameters) when the feature has a single piece in the batch, else a piece row that k_fixup2 sums per
 // feature (row-blocked streams).
-template <int LPN, int J>
+// FIN: the caller is the fixup launch, which may be running the merged finish (the column walk never does)
+template <int LPN, int J, bool FIN = false>
 __device__ __forceinline__ void store_seg(const BwdArgs &a, int seg, int l, const float4 (&acc)[J], float sa, float sb,
                                           int sl = 0) {
     constexpr int KP = 4 * LPN * J;
     const int dst = a.cdst[seg];
     if (dst >= 0) {
-        if (a.upd.V) apply_row<LPN, J>(a.upd, a.pack_k, dst, l, acc, sa, sb, sl);
+        if (FIN && a.fin_blocks > 0) finish_row<LPN, J>(a.fin, dst, l, acc, sa, sb, sl);
+        else if (a.upd.V) apply_row<LPN, J>(a.upd, a.pack_k, dst, l, acc, sa, sb, sl);
         else store_row<LPN, J>(a.GV + (size_t)dst * KP, l, acc, sa, sb, a.Gw + dst, a.Gb + dst, sl);
     } else {
         float *pr = a.pieces + (size_t)(-1 - dst) * (KP + kPartPad);
@@ -166,7 +201,7 @@ __device__ __forceinline__ void hot_backward_body(const HotArgs &a, int bx, int 
 
 // one workgroup per hot slot: sums that slot's partial rows over the hot workgroups (groups of threads
 // take interleaved partials, then the groups are summed in order) and stores the G row
-__device__ __forceinline__ void hot_reduce_body(const HotArgs &a, int h, int kp) {
+__device__ __forceinline__ void hot_reduce_body(const HotArgs &a, int h, int kp, const ApplyArgs &fin, bool merged) {
     const int id = a.hot_ids[h];
     if (id < 0) return;
     const int PR = kp + kPartPad, R4 = PR / 4;
@@ -181,6 +216,35 @@ __device__ __forceinline__ void hot_reduce_body(const HotArgs &a, int h, int kp)
     float4 u = f4zero();
     if (threadIdx.x < R4)
         for (int gg = 0; gg < G; ++gg) f4add(u, sh[gg * R4 + threadIdx.x]);
+    if (merged) {
+        // merged finish: the dense update of the hot feature's parameter row (apply_piece<KP, false>, operation for operation)
+        __shared__ float hf[2];
+        if (threadIdx.x == kp / 4) { hf[0] = u.x; hf[1] = u.y; }
+        __syncthreads();
+        if (threadIdx.x < kp / 4) {
+            const float invb = fin.invb_val, b = hf[1];
+            float4 *V4 = reinterpret_cast<float4 *>(fin.V + (size_t)id * kp) + threadIdx.x;
+            float4 x = *V4;
+            const float4 v = f4mul(x, fin.sv_in);
+            const bool has_w = fin.pack_k >= 0 && (int)threadIdx.x == (fin.pack_k >> 2);
+            float wslot = 0.f;
+            if (has_w) {
+                const float wi = f4pick(x, fin.pack_k & 3) * fin.sw_in;
+                wslot = wi - fin.eta * fmaf(fin.regw, wi, f4pick(u, fin.pack_k & 3) * invb);
+            }
+            x.x = v.x - fin.eta * fmaf(fin.regv, v.x, (u.x - v.x * b) * invb);
+            x.y = v.y - fin.eta * fmaf(fin.regv, v.y, (u.y - v.y * b) * invb);
+            x.z = v.z - fin.eta * fmaf(fin.regv, v.z, (u.z - v.z * b) * invb);
+            x.w = v.w - fin.eta * fmaf(fin.regv, v.w, (u.w - v.w * b) * invb);
+            if (has_w) f4set(x, fin.pack_k & 3, wslot);
+            *V4 = x;
+            if (threadIdx.x == 0) {
+                const float wi = fin.w[id] * fin.sw_in;
+                fin.w[id] = wi - fin.eta * fmaf(fin.regw, wi, (fin.pack_k >= 0 ? 0.f : hf[0]) * invb);
+            }
+        }
+        return;
+    }
     if (!a.upd.V) {
         if (threadIdx.x < kp / 4) {
             reinterpret_cast<float4 *>(a.GV + (size_t)id * kp)[threadIdx.x] = u;
@@ -526,11 +590,25 @@ __global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
         reduce_blocks_body(a.red_bsum, a.red_nblocks, a.red_rows, a.red_scal, a.red_acc, sh, a.red_w0, a.red_eta, a.red_reg0);
         return;
     }
+    // merged finish: fin_blocks workgroups in front of the statistics block update every parameter row the fixup part
+    // does not own (those update themselves, straight from registers) — bandwidth-bound work beside latency-bound work
+    const int fin0 = (int)gridDim.x - (a.red_bsum ? 1 : 0) - a.fin_blocks;
+    if (a.fin_blocks > 0 && (int)blockIdx.x >= fin0) {
+        constexpr int LPR = KP / 4;
+        const ApplyArgs &f = a.fin;
+        const int64_t total = (f.row_hi - f.row_lo) * LPR;
+        for (int64_t idx = (int64_t)((int)blockIdx.x - fin0) * kBlock + threadIdx.x; idx < total; idx += (int64_t)a.fin_blocks * kBlock) {
+            const int64_t i = f.row_lo + idx / LPR;
+            if (i < a.fin_own_bits && (a.fin_own[i >> 5] >> (i & 31) & 1u)) continue;
+            apply_piece<KP, false>(f, i, (int)(idx % LPR), f.invb_val);
+        }
+        return;
+    }
     if (HOT) {
         // kHotT more workgroups finish the dense hot block's gradient rows
-        const int hot0 = (int)gridDim.x - (a.red_bsum ? 1 : 0) - kHotT;
+        const int hot0 = fin0 - kHotT;
         if ((int)blockIdx.x >= hot0) {
-            hot_reduce_body(a.hot, (int)blockIdx.x - hot0, KP);
+            hot_reduce_body(a.hot, (int)blockIdx.x - hot0, KP, a.fin, a.fin_blocks > 0);
             return;
         }
     }
@@ -555,7 +633,7 @@ __global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
             sa += pr[KP];
             sb += pr[KP + 1];
         }
-        store_seg<LPN, J>(a, seg, l, acc, sa, sb);
+        store_seg<LPN, J, true>(a, seg, l, acc, sa, sb);
         return;
     }
     // ---- one WORKGROUP per long column: units strided over the 4 waves x WS slots, four in flight per
@@ -618,7 +696,7 @@ __global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
             sa += wsc[w2][0];
             sb += wsc[w2][1];
         }
-        store_seg<LPN, J>(a, seg, l, acc, sa, sb);
+        store_seg<LPN, J, true>(a, seg, l, acc, sa, sb);
     }
 }
 
@@ -678,8 +756,8 @@ hipError_t fix_dispatch(const BwdArgs &a, hipStream_t s) {
     constexpr int SLOTS = kBlock / LPN;
     const int extra = a.red_bsum ? 1 : 0;
     const int hot = a.hot_blocks > 0 ? kHotT : 0;
-    if (a.n_split < 1 && a.n_split_short < 1 && !extra && !hot) return hipSuccess;
-    dim3 g((unsigned)((a.n_split_short + SLOTS - 1) / SLOTS + a.n_split + hot + extra)), b(kBlock);
+    if (a.n_split < 1 && a.n_split_short < 1 && !extra && !hot && a.fin_blocks < 1) return hipSuccess;
+    dim3 g((unsigned)((a.n_split_short + SLOTS - 1) / SLOTS + a.n_split + hot + a.fin_blocks + extra)), b(kBlock);
     if (hot) hipLaunchKernelGGL((k_fixup<LPN, J, true>), g, b, 0, s, a);
     else hipLaunchKernelGGL((k_fixup<LPN, J, false>), g, b, 0, s, a);
     return hipGetLastError();

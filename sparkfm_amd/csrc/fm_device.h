@@ -133,6 +133,71 @@ __device__ __forceinline__ float slot_bcast(float v, int src) { return __int_as_
 template <int LPN>
 __device__ __forceinline__ uint32_t slot_bcast(uint32_t v, int src) { return (uint32_t)slot_bcast<LPN>((int)v, src); }
 
+// ------------------------------------------------------------------ apply
+// theta <- theta - eta*(g/|B| + reg*theta) with g_V = G_V - v*G_b (S/fm/lib/ALS.scala:56-58:
+// sum e*(x*q - x^2*v)); the packed gradient is zeroed on the way out.
+//
+// Lazy weight decay.  The tables hold U with V = sv*U (and w = sw*stored w); normally sv = sw = 1.  The
+// update (1 - eta*reg)*theta - eta*g/|B| touches EVERY row through its decay factor; the rows-only pass
+// instead multiplies the scale, sv' = sv*(1 - eta*regv), and updates just the rows with a gradient:
+//     U_i <- U_i - (eta/sv') * (G_V - (sv*U_i)*G_b)/|B|        (so that sv'*U_i' is the eager result)
+// — no per-row timestamps and no catch-up pass: the forward multiplies its row sums by the scale
+// (row_finish) and the next dense pass (below) folds it back in.  With no decay and sv = 1 both passes
+// perform the same operations on the same values (bit-identical; tested).
+//
+// one float4 of one feature row; ROWS = the rows-only (lazy) form
+template <int KP, bool ROWS>
+__device__ __forceinline__ void apply_piece(const ApplyArgs &a, int64_t i, int c, float invb) {
+    constexpr int LPR = KP / 4;
+    float4 *V4 = reinterpret_cast<float4 *>(a.V) + i * LPR + c;
+    float4 *G4 = reinterpret_cast<float4 *>(a.GV) + i * LPR + c;
+    const float b = a.Gb[i];
+    float4 g = *G4, u = *V4;
+    float4 v = f4mul(u, a.sv_in);                      // the parameter values (x 1 is exact)
+    float wslot = 0.f;
+    const bool has_w = a.pack_k >= 0 && c == (a.pack_k >> 2);
+    if (has_w) {   // packed rows: this float4 holds the linear weight in component pack_k & 3
+        const float us = f4pick(u, a.pack_k & 3), gi = f4pick(g, a.pack_k & 3) * invb;
+        const float wi = us * a.sw_in;
+        wslot = ROWS ? us - a.eta_w * gi : wi - a.eta * fmaf(a.regw, wi, gi);
+    }
+    if (ROWS) {
+        u.x -= a.eta_v * ((g.x - v.x * b) * invb);
+        u.y -= a.eta_v * ((g.y - v.y * b) * invb);
+        u.z -= a.eta_v * ((g.z - v.z * b) * invb);
+        u.w -= a.eta_v * ((g.w - v.w * b) * invb);
+    } else {
+        u.x = v.x - a.eta * fmaf(a.regv, v.x, (g.x - v.x * b) * invb);
+        u.y = v.y - a.eta * fmaf(a.regv, v.y, (g.y - v.y * b) * invb);
+        u.z = v.z - a.eta * fmaf(a.regv, v.z, (g.z - v.z * b) * invb);
+        u.w = v.w - a.eta * fmaf(a.regv, v.w, (g.w - v.w * b) * invb);
+    }
+    if (has_w) f4set(u, a.pack_k & 3, wslot);
+    *V4 = u;
+    *G4 = f4zero();
+    if (c == 0) {
+        const float us = a.w[i], gi = a.Gw[i] * invb;
+        const float wi = us * a.sw_in;
+        a.w[i] = ROWS ? us - a.eta_w * gi : wi - a.eta * fmaf(a.regw, wi, gi);
+        a.Gw[i] = 0.f;
+        a.Gb[i] = 0.f;  // same wave already holds its copy of b (all lanes of a row share a wave)
+    }
+}
+
+// 1/|B|: from the step's row count on the device, or given by the host
+__device__ __forceinline__ float apply_invb(const ApplyArgs &a) {
+    if (a.use_invb_val) return a.invb_val;
+    const float rows = *a.rows;
+    return rows > 0.f ? 1.0f / rows : 0.f;
+}
+
+__device__ __forceinline__ void apply_w0(const ApplyArgs &a, float invb) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float w0 = *a.w0;
+        *a.w0 = w0 - a.eta * fmaf(a.reg0, w0, a.scal[0] * invb);
+    }
+}
+
 // ------------------------------------------------------------------ reduce
 // one block, fixed order: sums the forward's per-block partials into
 // scal = {sum e, sum e^2, rows, nonfinite} (fp32, part of the packed gradient) and acc (fp64, +=)

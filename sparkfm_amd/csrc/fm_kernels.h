@@ -13,7 +13,7 @@ constexpr int kGradHead = 32;      // floats reserved for them at the front of t
 
 // runtime kernel-variant knobs (diagnostics / A-B benchmarking; fmhip_tune)
 enum { kTuneFwd = 0, kTuneBwd = 1, kTuneTile = 2, kTuneRowBlock = 3, kTuneXcd = 4, kTuneHot = 5, kTuneFwdOcc = 6, kTuneRowOrder = 7,
-       kTuneFlat = 8, kTuneLazy = 9, kTuneFused = 10, kTuneCount = 11 };
+       kTuneFlat = 8, kTuneLazy = 9, kTuneFused = 10, kTuneMerged = 11, kTuneCount = 12 };
 constexpr int kHotT = 16;           // slots of the dense hot block (fp32 per row: one 64-B half line)
 extern int g_tune[kTuneCount];
 
@@ -76,6 +76,29 @@ struct HotArgs {
     int32_t nblk;            // hot_blocks(Kp, n_rows)
     FusedUpd upd;
 };
+struct ApplyArgs {
+    float *V, *w, *w0;
+    float *GV, *Gw, *Gb;
+    const float *scal;  // {sum e, sum e^2, rows, ...}
+    const float *rows;  // the batch's (global) row count |B|: scal + 2 unless it was exchanged on its own
+    int64_t n1;         // n+1 (rows of V actually used)
+    int64_t row_lo, row_hi;   // dense pass: the feature rows [row_lo, row_hi) (whole model: 0, n1)
+    int32_t do_w0;      // this launch also steps w0 (once per step)
+    float invb_val;     // use_invb_val: 1/|B| given by the host (the statistics of the step are still being summed)
+    int32_t use_invb_val;
+    int32_t pack_k;     // >= 0: packed rows — slot pack_k of a V row is the linear weight
+    float eta, reg0, regw, regv;
+    // scale of the stored tables on entry (V = sv_in * stored, w = sw_in * stored; fm_apply.hip).  The dense
+    // pass leaves them at scale 1; the rows-only pass leaves them at sv_in * (1 - eta*regv) (resp. w) and
+    // uses eta_v = eta / that (eta_w likewise) as its step on the stored values
+    float sv_in, sw_in, eta_v, eta_w;
+    // rows-only variant (feat != NULL): just the listed distinct features and the hot block's ids
+    const int32_t *feat;     // [n_feat] distinct feature ids of the batch
+    int32_t n_feat;
+    const int32_t *hot_ids;  // [n_hot], -1 = unused
+    int32_t n_hot;
+};
+
 struct BwdArgs {
     const uint32_t *crow;      // batch CSC: bit31 = first entry of its column, low bits = batch-local row
     const float *cval;
@@ -108,6 +131,13 @@ struct BwdArgs {
     int32_t red_nblocks, red_rows;
     float *red_scal;
     double *red_acc;
+    // merged finish (single-GPU dense step): the fixup launch also performs the parameter update — its own rows
+    // (cut columns, hot block) straight from registers, every other row in fin_blocks extra workgroups that run
+    // beside the latency-bound fixups; fin_own = bitmap of the features the fixup part owns
+    ApplyArgs fin;
+    int32_t fin_blocks;
+    const uint32_t *fin_own;
+    int32_t fin_own_bits;
     float *red_w0;             // fused update: the statistics block also steps w0 (NULL = leave it to k_apply)
     float red_eta, red_reg0;
     FusedUpd upd;
@@ -117,26 +147,6 @@ struct BwdArgs {
     int32_t hot_blocks;
 };
 
-struct ApplyArgs {
-    float *V, *w, *w0;
-    float *GV, *Gw, *Gb;
-    const float *scal;  // {sum e, sum e^2, rows, ...}
-    const float *rows;  // the batch's (global) row count |B|: scal + 2 unless it was exchanged on its own
-    int64_t n1;         // n+1 (rows of V actually used)
-    int64_t row_lo, row_hi;   // dense pass: the feature rows [row_lo, row_hi) (whole model: 0, n1)
-    int32_t do_w0;      // this launch also steps w0 (once per step)
-    int32_t pack_k;     // >= 0: packed rows — slot pack_k of a V row is the linear weight
-    float eta, reg0, regw, regv;
-    // scale of the stored tables on entry (V = sv_in * stored, w = sw_in * stored; fm_apply.hip).  The dense
-    // pass leaves them at scale 1; the rows-only pass leaves them at sv_in * (1 - eta*regv) (resp. w) and
-    // uses eta_v = eta / that (eta_w likewise) as its step on the stored values
-    float sv_in, sw_in, eta_v, eta_w;
-    // rows-only variant (feat != NULL): just the listed distinct features and the hot block's ids
-    const int32_t *feat;     // [n_feat] distinct feature ids of the batch
-    int32_t n_feat;
-    const int32_t *hot_ids;  // [n_hot], -1 = unused
-    int32_t n_hot;
-};
 
 int hot_blocks(int Kp, int64_t n_rows);
 

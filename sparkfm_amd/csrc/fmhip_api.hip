@@ -487,6 +487,22 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
             finish_batch_meta(hb, bm.nnz, cnt, base);
         }
     }
+    // bitmap of the features whose gradient rows the fixup launch assembles (cut columns + hot block), per batch:
+    // the merged finish skips them in its dense pass.  Kept for models of up to 2^24 features (2 MiB per batch).
+    std::vector<uint32_t> own;
+    if (d->rb_rows == 0 && dim < (1 << 24) && nb * ((int64_t)dim / 32 + 1) <= ((int64_t)1 << 26)) {
+        d->own_words = (int64_t)dim / 32 + 1;
+        own.assign((size_t)(nb * d->own_words), 0u);
+        for (int64_t b = 0; b < nb; ++b) {
+            uint32_t *bits = own.data() + (size_t)(b * d->own_words);
+            const HostBatch &hb = hbs[(size_t)b];
+            for (const std::vector<int32_t> *lst : {&hb.split_seg, &hb.split_short})
+                for (int32_t c : *lst) { const int32_t f = hb.cfeat[(size_t)c]; bits[f >> 5] |= 1u << (f & 31); }
+            for (int32_t f : d->hot_ids)
+                if (f >= 0) bits[f >> 5] |= 1u << (f & 31);
+            d->batches[(size_t)b].own_off = b * d->own_words;
+        }
+    }
     std::vector<int32_t> cfeat, cptr, range_seg, split_seg, split_short, cdst, mp_feat, mp_ptr;
     for (int64_t b = 0; b < nb; ++b) {
         BatchMeta &bm = d->batches[(size_t)b];
@@ -523,7 +539,8 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
         (rc = upload(d->range_seg, range_seg.data(), range_seg.size())) ||
         (rc = upload(d->split_seg, split_seg.data(), split_seg.size())) ||
         (rc = upload(d->split_short, split_short.data(), split_short.size())) || (rc = upload(d->cdst, cdst.data(), cdst.size())) ||
-        (rc = upload(d->mp_feat, mp_feat.data(), mp_feat.size())) || (rc = upload(d->mp_ptr, mp_ptr.data(), mp_ptr.size()))) {
+        (rc = upload(d->mp_feat, mp_feat.data(), mp_feat.size())) || (rc = upload(d->mp_ptr, mp_ptr.data(), mp_ptr.size())) ||
+        (rc = upload(d->own_bits, own.data(), own.size()))) {
         delete d;
         return rc;
     }
@@ -684,6 +701,9 @@ void hot_attach(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm, BwdArgs
     m->hot_pending = false;
 }
 
+// (the hot block's arguments are a copy inside BwdArgs: nothing to patch for the merged finish, kept as a hook)
+inline void hot_attach_fin(BwdArgs &) {}
+
 // backward + fixup of the columns whose feature id lies in [feat_lo, feat_hi) into the packed
 // gradient.  The CSC stream is sorted by feature, so the interval is a contiguous run of entries;
 // the range holding its first entry is walked by THIS call in full (the entries of lower features
@@ -695,7 +715,7 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
     const BatchMeta &bm = d->batches[(size_t)b];
     BwdArgs ba = bwd_args(m, d, b);
     if (fused) {
-        ba.upd = fused->upd;
+        if (fused->mode == 1) ba.upd = fused->upd;
         if (finish) { ba.red_w0 = m->w0.p; ba.red_eta = (float)fused->eta; ba.red_reg0 = (float)fused->reg0; }
     }
     hot_attach(m, d, bm, ba);
@@ -713,6 +733,38 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
         {
             ProfScope ps(m, FMHIP_K_BACKWARD, bm.nnz_total, bm.rows);
             HIP_TRY(launch_backward(m->Kp, ba, m->stream));
+        }
+        if (fused && fused->mode == 2) {
+            // merged finish: the fixup launch also updates the parameters (its own rows from registers, the rest in
+            // extra workgroups beside it); the column walk above stored its gradient rows as usual
+            ApplyArgs &f = ba.fin;
+            f.V = m->V.p;
+            f.w = m->w.p;
+            f.w0 = m->w0.p;
+            f.GV = m->GV();
+            f.Gw = m->Gw();
+            f.Gb = m->Gb();
+            f.scal = m->scal();
+            f.rows = m->scal() + 2;
+            f.n1 = m->n1;
+            f.row_lo = 0;
+            f.row_hi = m->n1;
+            f.do_w0 = 0;                                   // the statistics block steps w0 (red_w0)
+            f.pack_k = m->pack_k();
+            f.eta = (float)fused->eta;
+            f.reg0 = (float)fused->reg0;
+            f.regw = (float)fused->regw;
+            f.regv = (float)fused->regv;
+            f.sv_in = (float)m->sv;
+            f.sw_in = (float)m->sw;
+            f.eta_v = f.eta_w = f.eta;
+            f.invb_val = fused->upd.invb;
+            f.use_invb_val = 1;
+            int64_t blocks = (m->n1 * (m->Kp / 4) + 255) / 256;
+            ba.fin_blocks = (int32_t)std::min<int64_t>(std::max<int64_t>(blocks, 1), 2048);
+            ba.fin_own = d->own_bits.p + bm.own_off;
+            ba.fin_own_bits = (int32_t)std::min<int64_t>(d->own_words * 32, INT32_MAX);
+            hot_attach_fin(ba);
         }
         {
             ProfScope ps(m, FMHIP_K_FIXUP, bm.nnz_total, bm.rows);
@@ -769,10 +821,28 @@ int step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double *acc, con
 bool plan_fused(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double eta, double reg0, double regw, double regv, FusedPlan *p) {
     const double dv = 1.0 - eta * regv, dw = 1.0 - eta * regw;
     const bool decay = regw != 0.0 || regv != 0.0;
-    if (!g_tune[kTuneFused] || d->rb_rows != 0) return false;
-    if (decay && !(g_tune[kTuneLazy] && dv >= 0.5 && dw >= 0.5 && dv <= 1.0 && dw <= 1.0)) return false;
+    const bool lazy_ok = !decay || (g_tune[kTuneLazy] && dv >= 0.5 && dw >= 0.5 && dv <= 1.0 && dw <= 1.0);
+    const BatchMeta &bm0 = d->batches[(size_t)b];
     p->eta = eta;
     p->reg0 = reg0;
+    p->regw = regw;
+    p->regv = regv;
+    {
+        const float rows = (float)bm0.rows;
+        p->upd.invb = rows > 0.f ? 1.0f / rows : 0.f;
+    }
+    // merged finish (key 11): when the step's update is the DENSE pass (the batch touches most of the model, or decay
+    // cannot ride in the scale) it runs inside the fixup launch, beside the fixups, instead of as a launch of its own
+    const int64_t touched = (int64_t)bm0.n_cols + (d->hot_T ? kHotT : 0);
+    const bool rows_only = lazy_ok && touched * 2 <= m->n1;
+    if (g_tune[kTuneMerged] && !g_tune[kTuneFused] && d->rb_rows == 0 && !rows_only && bm0.own_off >= 0 && d->dimension <= m->n) {
+        p->mode = 2;
+        p->sv_out = p->sw_out = 1.0;      // the dense pass folds the scale
+        return true;
+    }
+    if (!g_tune[kTuneFused] || d->rb_rows != 0) return false;
+    if (!lazy_ok) return false;
+    p->mode = 1;
     p->sv_out = m->sv * dv;
     p->sw_out = m->sw * dw;
     p->upd.V = m->V.p;
@@ -780,8 +850,6 @@ bool plan_fused(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double eta, doubl
     p->upd.sv = (float)m->sv;
     p->upd.eta_v = (float)(eta / p->sv_out);
     p->upd.eta_w = (float)(eta / p->sw_out);
-    const float rows = (float)d->batches[(size_t)b].rows;
-    p->upd.invb = rows > 0.f ? 1.0f / rows : 0.f;
     return true;
 }
 

@@ -74,6 +74,7 @@ struct BatchMeta {
     int32_t n_pieces = 0;   // piece rows those features need
     int64_t nnz_total = 0;  // stored nonzeros of the batch incl. those held in the dense hot block
     uint32_t hot_mask = 0;  // hot slots with at least one nonzero in this batch
+    int64_t own_off = -1;   // offset (in words) of the batch's bitmap of fixup-owned features, -1 = none
 };
 
 struct ProfRec {
@@ -100,6 +101,10 @@ struct fmhip_dataset {
     DevBuf<float> cval;
     DevBuf<int32_t> row_order;   // per batch: its rows' local ids sorted by stored length, longest first (forward walk order)
     DevBuf<int32_t> cfeat, cptr, range_seg, split_seg, split_short, cdst, mp_feat, mp_ptr;
+    // per batch: bitmap over the feature ids [0, dimension] of the rows whose gradient the FIXUP launch assembles (cut
+    // columns, hot block) — the merged finish lets those update themselves and skips them in its dense pass
+    DevBuf<uint32_t> own_bits;
+    int64_t own_words = 0;       // words per batch
     std::vector<int32_t> h_cfeat, h_cptr, h_split, h_split_short;   // host copies (feature-chunked backward needs them)
     int64_t rb_rows = 0;       // rows per row block of the transposes (0 = not row-blocked)
     int32_t max_pieces = 0;
@@ -178,9 +183,11 @@ int check_train(fmhip_model_t m, fmhip_dataset_t d);      // + the dataset must 
 int check_batch(fmhip_dataset_t d, int64_t batch);
 // the pieces of one mini-batch step, all asynchronous on m->stream (fmhip_api.hip)
 int step_forward(fmhip_model_t m, fmhip_dataset_t d, int64_t b);
-// a step whose gradient rows are applied inside the backward (fmhip_api.hip: plan_fused)
+// a step whose update happens inside the backward (mode 1: every finished gradient row, fmhip_tune key 10) or
+// inside the fixup launch (mode 2, the merged finish: dense update beside the fixups, key 11) — fmhip_api.hip
 struct FusedPlan {
-    double eta = 0.0, reg0 = 0.0;
+    int mode = 0;
+    double eta = 0.0, reg0 = 0.0, regw = 0.0, regv = 0.0;
     double sv_out = 1.0, sw_out = 1.0;    // the tables' scales after the step
     FusedUpd upd{};
 };

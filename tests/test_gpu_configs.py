@@ -380,20 +380,23 @@ def test_als_refuses_rows_with_a_repeated_feature(fmhip):
     assert np.isfinite(fm.computeRMSE(ds))          # everything else accepts such rows
 
 
+@pytest.mark.parametrize("n1", [30000, 700])
 @pytest.mark.parametrize("k,regs", [(8, (0.01, 1e-3, 1e-3)), (32, (0.0, 1e-3, 2e-3)), (32, (0.0, 0.0, 0.0)), (64, (0.01, 0.0, 1e-3)),
                                     (100, (0.0, 1e-3, 1e-3))])
-def test_fused_update_is_bit_identical_to_the_update_launch(fmhip, k, regs):
-    """fmhip_tune key 10: the fused step applies each finished gradient row to its parameter row inside the
-    backward / fixup launches; the unfused one stores the packed gradient and runs k_apply_rows.  Same
-    operations on the same values -> the same bits, for packed rows (k=8), plain rows, wide rows, hot block on,
-    cut columns (hot features spanning many ranges), with and without (lazy) weight decay."""
+def test_where_the_update_runs_does_not_change_a_bit(fmhip, k, regs, n1):
+    """Three places for the same update: a launch of its own (keys 10 = 11 = 0), inside the fixup launch beside the
+    fixups (key 11, the default; taken when the update is the dense pass: n1 = 700) and inside the column walk's
+    flush (key 10; rows-only update: n1 = 30000 is far wider than a batch).  Same operations on the same values ->
+    the same bits, for packed rows (k=8), plain rows, wide rows, hot block on, cut columns (hot features spanning
+    many ranges), with and without (lazy) weight decay; and all of them track the oracle."""
     from sparkfm_amd import _ffi
     from test_gpu_parity import hot_problem
     L = _ffi.load()
-    a, _ = hot_problem(500 + k, 4000, 30000, k, 9)
+    a, _ = hot_problem(500 + k, 4000, n1, k, 9)
     outs = []
-    for fused in (1, 0):
+    for fused, merged in ((0, 1), (0, 0), (1, 0)):
         L.fmhip_tune(10, fused)
+        L.fmhip_tune(11, merged)
         try:
             ds = fmhip.DataSet(a["row_ptr"], a["col"], a["val"], a["y"], batch_rows=1100).cache()
             fm = fmhip.FMModel(a["n1"] - 1, k)
@@ -404,15 +407,22 @@ def test_fused_update_is_bit_identical_to_the_update_launch(fmhip, k, regs):
             outs.append((fm.w0, fm.w.copy(), fm.v.copy(), sgd.last_stats["sse"]))
         finally:
             L.fmhip_tune(10, 0)
+            L.fmhip_tune(11, 1)
         ds.unpersist()
         fm.close()
+    # merged == plain always; fused (rows-only form) == plain when the plain update is rows-only too, or there is no decay
     assert outs[0][0] == outs[1][0] and outs[0][3] == outs[1][3]
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     np.testing.assert_array_equal(outs[0][2], outs[1][2])
+    if n1 == 30000 or regs[1:] == (0.0, 0.0):
+        assert outs[2][0] == outs[1][0]
+        np.testing.assert_array_equal(outs[2][1], outs[1][1])
+        np.testing.assert_array_equal(outs[2][2], outs[1][2])
     w0, w, v = a["w0"], a["w"], a["v"]
     for _ in range(3):
         w0, w, v, _ = oracle.sgd_epoch(w0, w, v, 1100, a["row_ptr"], a["col"], a["val"], a["y"], 0.05, *regs)
-    assert rel(outs[0][2], v) <= 1e-5 and rel(outs[0][1], w) <= 1e-5 and outs[0][0] == pytest.approx(w0, rel=1e-5, abs=1e-7)
+    for o in outs:
+        assert rel(o[2], v) <= 1e-5 and rel(o[1], w) <= 1e-5 and o[0] == pytest.approx(w0, rel=1e-5, abs=1e-7)
 
 
 def test_per_dataset_layout_options(fmhip):
