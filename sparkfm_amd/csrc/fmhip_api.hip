@@ -20,6 +20,10 @@
 
 using namespace fmhip;
 
+#ifndef FMHIP_FIN_BLOCKS
+#define FMHIP_FIN_BLOCKS 2048     // cap on the merged finish's update workgroups (beside ~2k fixup workgroups at C3)
+#endif
+
 static_assert(FMHIP_RANGE_LEN == kRangeLen, "header and kernels disagree on the CSC range length");
 
 namespace fmhip {
@@ -761,7 +765,7 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
             f.invb_val = fused->upd.invb;
             f.use_invb_val = 1;
             int64_t blocks = (m->n1 * (m->Kp / 4) + 255) / 256;
-            ba.fin_blocks = (int32_t)std::min<int64_t>(std::max<int64_t>(blocks, 1), 2048);
+            ba.fin_blocks = (int32_t)std::min<int64_t>(std::max<int64_t>(blocks, 1), FMHIP_FIN_BLOCKS);
             ba.fin_own = d->own_bits.p + bm.own_off;
             ba.fin_own_bits = (int32_t)std::min<int64_t>(d->own_words * 32, INT32_MAX);
             hot_attach_fin(ba);
