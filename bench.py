@@ -198,6 +198,14 @@ def kernel_table(prof, k, kp, req, pmc, table_bytes):
         if t is not None:
             ent["traffic_from_committed_profile"] = t
         kern[name] = ent
+    if "apply" in req and "apply" not in kern and "fixup" in kern:
+        # merged finish: the dense update ran inside the fixup launch (fmhip_tune key 11)
+        ent = kern["fixup"]
+        ent["includes"] = "the parameter update (merged finish)"
+        ent["requested_bytes_per_launch"] = req["apply"]
+        ent["requested_GBps"] = req["apply"] / (ent["avg_ms"] * 1e-3) / 1e9
+        ent["ceiling"] = {"name": "hbm_stream", "GBps": CEIL["hbm_stream"] / 1e9}
+        ent["frac_of_ceiling"] = ent["requested_GBps"] / ent["ceiling"]["GBps"]
     return kern
 
 
