@@ -472,8 +472,9 @@ def main():
         sync()
         barrier()
     if not os.environ.get("FMHIP_BENCH_NO_EVENTS"):
-        # one kernel kind per step, rotating: the event records barely perturb the timed region
-        _ffi.check(L.fmhip_profile_begin_rotating(hm))
+        # one kernel kind on every 4th step, rotating (a pair of event records costs ~8 us of stream time): with the
+        # default 200 steps every kind is timed 12-13 times and the timed region is perturbed by < 1 %
+        _ffi.check(L.fmhip_profile_begin_sampled(hm, 4 if args.steps >= 64 else 1))
     sync()
     barrier()
     t0 = time.perf_counter()

@@ -309,6 +309,9 @@ int fmhip_profile_begin(fmhip_model_t m);                  /* start recording HI
  * apply from step to step: 2 event records per step instead of 8, so the timed region
  * is barely perturbed (event records cost ~4 us each on the stream) */
 int fmhip_profile_begin_rotating(fmhip_model_t m);
+/* the same on every `period`-th step only (step 0 forward, step `period` backward, ...): one pair of event
+ * records per `period` steps — period 4 keeps the perturbation of a 0.3 ms step under 1 % */
+int fmhip_profile_begin_sampled(fmhip_model_t m, int period);
 int fmhip_profile_end(fmhip_model_t m, fmhip_profile *p);  /* synchronise, sum, stop recording */
 
 #ifdef __cplusplus

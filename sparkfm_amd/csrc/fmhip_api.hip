@@ -56,7 +56,8 @@ struct ProfScope {
     ProfScope(fmhip_model *m_, int kind, int64_t nnz, int64_t rows) : m(m_), on(m_->profiling) {
         if (on && m->prof_rotate) {
             static const int live[4] = {FMHIP_K_FORWARD, FMHIP_K_BACKWARD, FMHIP_K_FIXUP, FMHIP_K_APPLY};
-            if (live[m->prof_step % 4] != kind) on = false;
+            const int64_t period = m->prof_period > 0 ? m->prof_period : 1;
+            if (m->prof_step % period != 0 || live[(m->prof_step / period) % 4] != kind) on = false;
         }
         if (!on) return;
         r.kind = kind;
@@ -1600,13 +1601,20 @@ int fmhip_profile_begin(fmhip_model_t m) {
     m->prof.clear();
     m->profiling = true;
     m->prof_rotate = false;
+    m->prof_period = 1;
     m->prof_step = 0;
     return FMHIP_OK;
 }
 
-int fmhip_profile_begin_rotating(fmhip_model_t m) {
+int fmhip_profile_begin_rotating(fmhip_model_t m) { return fmhip_profile_begin_sampled(m, 1); }
+
+int fmhip_profile_begin_sampled(fmhip_model_t m, int period) {
+    if (period < 1) return fail(FMHIP_ERR_INVALID, "period must be >= 1");
     int rc = fmhip_profile_begin(m);
-    if (rc == FMHIP_OK) m->prof_rotate = true;
+    if (rc == FMHIP_OK) {
+        m->prof_rotate = true;
+        m->prof_period = period;
+    }
     return rc;
 }
 

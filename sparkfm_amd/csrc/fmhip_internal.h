@@ -158,6 +158,7 @@ struct fmhip_model {
     DevBuf<double> als_w0, als_w, als_v, als_e, als_q;
     bool profiling = false;
     bool prof_rotate = false;     // time one kernel kind per step, rotating
+    int prof_period = 1;          // ... and only on every prof_period-th step
     int64_t prof_step = 0;
     std::vector<ProfRec> prof;
 
