@@ -445,3 +445,33 @@ def test_per_dataset_layout_options(fmhip):
         ds.unpersist()
         fm.close()
     check_grad(grads[0][0], grads[0][1], grads[1][0], grads[1][1], np.abs(a["v"]).max())
+
+
+def test_permutation_of_a_rows_nonzeros(fmhip):
+    """SURVEY §4's property: a row is a set of (index, value) pairs — storing them in another order (the reference's
+    loader neither sorts nor reorders, S/fm/FMUtils.scala:28-36) changes the prediction and the gradient only by fp32
+    summation order, and the transposes not at all (rows ascend inside a column whatever the stored order)."""
+    from helpers import random_problem
+    a = random_problem(4242, 2500, 300, 32, 0, 40, empty_rows=(3,), sort_idx=True)
+    b = {k_: (v.copy() if isinstance(v, np.ndarray) else v) for k_, v in a.items()}
+    rng = np.random.default_rng(1)
+    for r in range(2500):
+        s = slice(a["row_ptr"][r], a["row_ptr"][r + 1])
+        p = rng.permutation(s.stop - s.start)
+        b["col"][s] = a["col"][s][p]
+        b["val"][s] = a["val"][s][p]
+    res = []
+    for x in (a, b):
+        ds = fmhip.DataSet(x["row_ptr"], x["col"], x["val"], x["y"], batch_rows=900).cache()
+        fm = fmhip.FMModel(x["n1"] - 1, x["k"])
+        fm.w0, fm.w, fm.v = x["w0"], x["w"], x["v"]
+        res.append((fm.predict(ds), fm.batchGradient(ds, 1), ds.transposeInput(1)))
+        ds.unpersist()
+        fm.close()
+    sc = term_scale(a)
+    assert (np.abs(res[0][0] - res[1][0]) <= 2 * TOL_Y * sc).all()
+    check_grad(res[0][1][0], res[0][1][1], res[1][1][0], res[1][1][1], np.abs(a["v"]).max())
+    for u, v in zip(res[0][2], res[1][2]):
+        np.testing.assert_array_equal(u, v)
+    oy = oracle.predict(a["w0"], a["w"], a["v"], a["row_ptr"], a["col"], a["val"])
+    assert (np.abs(res[1][0] - oy) <= TOL_Y * sc).all()
