@@ -467,14 +467,20 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
 // chunks of CHB entries so chunk c+1 is in flight while chunk c is accumulated.
 // (HOT: the waves-per-SIMD bound keeps the MFMA accumulators of the hot body from costing the walkers
 // their third wave)
+#ifndef FMHIP_BWD_WAVES
+#define FMHIP_BWD_WAVES 3
+#endif
 template <int LPN, int J, bool PACKED, bool HOT>
-__global__ __launch_bounds__(kBlock, (HOT && J == 1 ? 3 : 1)) void k_backward_p(BwdArgs a) {
+__global__ __launch_bounds__(kBlock, (HOT && J == 1 ? FMHIP_BWD_WAVES : 1)) void k_backward_p(BwdArgs a) {
     constexpr int KP = 4 * LPN * J;
     if (HOT && (int)blockIdx.x < a.hot_blocks) {
         hot_backward_body<KP / 16>(a.hot, (int)blockIdx.x, a.hot_blocks);
         return;
     }
-    constexpr int SG = (kRangeLen / LPN) < 8 ? (kRangeLen / LPN) : 8;         // lane-groups per super-group
+#ifndef FMHIP_BWD_SG
+#define FMHIP_BWD_SG 8
+#endif
+    constexpr int SG = (kRangeLen / LPN) < FMHIP_BWD_SG ? (kRangeLen / LPN) : FMHIP_BWD_SG;   // lane-groups per super-group
     constexpr int CHB = (LPN * J > 8) ? ((8 / J) > 0 ? (8 / J) : 1) : LPN;   // entries per gather chunk
     constexpr int NCH = SG * LPN / CHB;                                       // chunks per super-group
     RangeWalk<LPN, J, PACKED> w;

@@ -233,3 +233,27 @@ def test_bench_without_a_launcher_fails_cleanly_when_ranks_cannot_start():
     import torch
     if not torch.cuda.is_available():
         assert p.returncode != 0 and p.stdout.strip() == b""
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The bench line committed under profiles/ (a real MI355X run of `python bench.py`) carries every key of the
+    driver's contract plus the roofline / cpu_baseline objects, with a roofline that cannot exceed 1 against its ceiling."""
+    import json
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_c3_n1.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "nnz/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] == pytest.approx(d["config"]["nnz_per_gpu"] / d["config"]["batches_per_gpu"] / (d["ms_per_step"] * 1e-3), rel=0.02)
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0 < r["frac_of_ceiling"] <= 1.0
+    assert 0 < d["step_roofline"]["frac"] <= 1.0
+    for k_ in d["kernels"].values():
+        if "frac_of_ceiling" in k_:
+            assert 0 < k_["frac_of_ceiling"] <= 1.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "nnz/s" and c["sample"]
+    assert d["sustained"]["seconds"] >= 2.0 and d["extra"]["hbm_resident"]["frac_of_8TBps"] <= 1.0
