@@ -399,7 +399,7 @@ def main():
             fixed = None if args.upper_fractions == "auto" else (() if args.upper_fractions == "none" else
                                                                  tuple(float(x) for x in args.upper_fractions.split(",")))
             dp = HipDataParallelSGD(comm, eta=args.eta, reg0=regs[0], regw=regs[1], regv=regs[2],
-                                    upper_fractions=fixed if fixed is not None else (0.08, 0.25, 0.5))
+                                    upper_fractions=fixed if fixed is not None else (0.05, 0.15, 0.3, 0.55))
             dp.plan(fm, ds)
             if args.emulate_allreduce:
                 if world != 1:
@@ -451,7 +451,7 @@ def main():
     if exchange == "rccl" and args.upper_fractions == "auto" and (world > 1 or args.emulate_allreduce):
         # measure, don't guess: the best cut depends on the all-reduce's real bandwidth on this node
         tuning = []
-        for cand in ((0.45,), (0.3,), (0.2,), (0.12, 0.4), (0.08, 0.25, 0.5), ()):
+        for cand in ((0.3,), (0.2,), (0.12, 0.4), (0.08, 0.25, 0.5), (0.05, 0.15, 0.3, 0.55), (0.04, 0.1, 0.2, 0.35, 0.6), ()):
             dp.upper_fractions = cand
             dp.plan(fm, ds)
             step(0)

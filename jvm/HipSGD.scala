@@ -44,7 +44,7 @@ class HipSGD protected (eta: Double, reg0: Double, regw: Double, regv: Double, b
       if (model == 0L) model = HipSGD.modelCreate(device, fm.num_attribute, fm.num_factor)
       if (world > 1 && comm == 0L) {
         comm = HipSGD.commCreate(model, uniqueId, rank, world)
-        HipSGD.dpPlan(model, data, comm, Array(0.08, 0.25, 0.5))   // cuts of the backward for the overlapped all-reduce
+        HipSGD.dpPlan(model, data, comm, Array(0.05, 0.15, 0.3, 0.55))   // cuts of the backward for the overlapped all-reduce
       }
       cached = dataset
     }

@@ -257,11 +257,11 @@ class HipDataParallelSGD(FMLearn):
     """FMLearn whose `learn` runs one data-parallel epoch over this rank's row shard INSIDE the library:
     forward -> feature-chunked backward overlapped with the RCCL all-reduce -> identical update
     (fmhip_dp_epoch).  `upper_fractions`: ascending shares of the stored nonzeros at or above each cut of
-    the backward — (0.08, 0.25, 0.5) = four intervals, the first 8 % of the work and two thirds of the bytes
+    the backward — (0.05, 0.15, 0.3, 0.55) = five intervals, the first 5 % of the work and over half of the bytes
     (the fastest of the candidates timed against an emulated 8-GPU all-reduce at C4's width);
     () = no overlap: whole backward, one all-reduce."""
 
-    def __init__(self, comm, eta=0.05, reg0=0.0, regw=0.0, regv=0.0, upper_fractions=(0.08, 0.25, 0.5)):
+    def __init__(self, comm, eta=0.05, reg0=0.0, regw=0.0, regv=0.0, upper_fractions=(0.05, 0.15, 0.3, 0.55)):
         self.comm = comm
         self.eta, self.reg0, self.regw, self.regv = float(eta), float(reg0), float(regw), float(regv)
         self.upper_fractions = tuple(float(f) for f in upper_fractions)
