@@ -139,6 +139,10 @@ int fmhip_model_init_normal(fmhip_model_t m, uint64_t seed, double mean, double 
 /* w: n+1 doubles, v: k*(n+1) doubles at v[f + i*k]  (FMModel.w0 / .w / .v, S/fm/FMModel.scala:17-19) */
 int fmhip_model_set_params(fmhip_model_t m, double w0, const double *w, const double *v);
 int fmhip_model_get_params(fmhip_model_t m, double *w0, double *w, double *v);
+/* The parameters of `n` selected features only (ids need not be sorted or distinct): w[j] and the k factors
+ * v[f + j*k] of feature ids[j] — what `fm.w(i)` / `fm.v(::, i)` read in the reference (S/fm/FMModel.scala:18-19).
+ * For models too wide to copy whole. */
+int fmhip_model_get_rows(fmhip_model_t m, int64_t n, const int32_t *ids, double *w, double *v);
 int fmhip_model_set_params_f32(fmhip_model_t m, float w0, const float *w, const float *v);
 int fmhip_model_get_params_f32(fmhip_model_t m, float *w0, float *w, float *v);
 int fmhip_synchronize(fmhip_model_t m);

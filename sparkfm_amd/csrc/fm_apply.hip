@@ -61,7 +61,29 @@ __global__ __launch_bounds__(kBlock) void k_init_normal(float *V, float *w, floa
     if (blockIdx.x == 0 && threadIdx.x == 0) *w0 = 0.f;
 }
 
+__global__ __launch_bounds__(kBlock) void k_gather_rows(const float *V, const float *w, const int32_t *ids, int64_t n, int32_t kp,
+                                                       float *out_v, float *out_w) {
+    const int lpr = kp / 4;
+    const int64_t total = n * lpr;
+    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kBlock) {
+        const int64_t j = idx / lpr;
+        const int c = (int)(idx % lpr);
+        const int64_t i = ids[j];
+        reinterpret_cast<float4 *>(out_v)[idx] = reinterpret_cast<const float4 *>(V)[i * lpr + c];
+        if (c == 0) out_w[j] = w[i];
+    }
+}
+
 }  // namespace
+
+hipError_t launch_gather_rows(int Kp, const float *V, const float *w, const int32_t *ids, int64_t n, float *out_v, float *out_w,
+                              hipStream_t s) {
+    int64_t blocks = (n * (Kp / 4) + kBlock - 1) / kBlock;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)blocks), dim3(kBlock), 0, s, V, w, ids, n, Kp, out_v, out_w);
+    return hipGetLastError();
+}
 
 hipError_t launch_init_normal(int Kp, float *V, float *w, float *w0, int64_t n1, int64_t n1p, int32_t k, uint64_t seed, float mean,
                               float stdev, hipStream_t s) {

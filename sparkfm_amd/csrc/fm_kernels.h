@@ -155,6 +155,9 @@ hipError_t launch_forward(int Kp, FwdMode mode, const FwdArgs &a, hipStream_t s,
 // V[i][f] = mean + stdev * N(0,1) for f < k (a hash of (seed, i, f) through Box-Muller), padding and w = 0
 hipError_t launch_init_normal(int Kp, float *V, float *w, float *w0, int64_t n1, int64_t n1p, int32_t k, uint64_t seed, float mean,
                               float stdev, hipStream_t s);
+// out_v[j*Kp + f] = V[ids[j]][f], out_w[j] = w[ids[j]] (raw stored values; the caller applies scales / packed slots)
+hipError_t launch_gather_rows(int Kp, const float *V, const float *w, const int32_t *ids, int64_t n, float *out_v, float *out_w,
+                              hipStream_t s);
 // dense V *= sv, w *= sw (packed rows: the w slot of a V row by sw): brings lazily decayed tables back to scale 1
 hipError_t launch_rescale(int Kp, float *V, float *w, int64_t n1, int32_t pack_k, float sv, float sw, hipStream_t s);
 hipError_t launch_backward(int Kp, const BwdArgs &a, hipStream_t s);

@@ -1151,6 +1151,31 @@ int fmhip_model_init_normal(fmhip_model_t m, uint64_t seed, double mean, double 
     return FMHIP_OK;
 }
 
+int fmhip_model_get_rows(fmhip_model_t m, int64_t n, const int32_t *ids, double *w, double *v) {
+    if (!m || n < 0 || (n > 0 && !ids)) return fail(FMHIP_ERR_INVALID, "NULL argument or negative count");
+    for (int64_t j = 0; j < n; ++j)
+        if (ids[j] < 0 || ids[j] > m->n) return fail(FMHIP_ERR_SHAPE, "feature id %d outside [0, %lld]", ids[j], (long long)m->n);
+    if (n == 0) return FMHIP_OK;
+    TRY(set_device(m->device));
+    DevBuf<int32_t> dids;
+    DevBuf<float> dv, dw;
+    TRY(dids.alloc((size_t)n));
+    TRY(dv.alloc((size_t)n * m->Kp));
+    TRY(dw.alloc((size_t)n));
+    HIP_TRY(hipMemcpyAsync(dids.p, ids, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(launch_gather_rows(m->Kp, m->V.p, m->w.p, dids.p, n, dv.p, dw.p, m->stream));
+    std::vector<float> hv((size_t)n * m->Kp), hw((size_t)n);
+    HIP_TRY(hipMemcpyAsync(hv.data(), dv.p, hv.size() * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(hw.data(), dw.p, hw.size() * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    for (int64_t j = 0; j < n; ++j) {       // scales of a lazily decayed model, packed rows: as get_params
+        if (w) w[j] = (double)(m->pack_k() >= 0 ? hv[(size_t)j * m->Kp + m->k] : hw[(size_t)j]) * m->sw;
+        if (v)
+            for (int f = 0; f < m->k; ++f) v[f + j * (int64_t)m->k] = (double)hv[(size_t)j * m->Kp + f] * m->sv;
+    }
+    return FMHIP_OK;
+}
+
 int fmhip_model_set_params(fmhip_model_t m, double w0, const double *w, const double *v) { return set_params_impl<double>(m, w0, w, v); }
 int fmhip_model_get_params(fmhip_model_t m, double *w0, double *w, double *v) { return get_params_impl<double>(m, w0, w, v); }
 int fmhip_model_set_params_f32(fmhip_model_t m, float w0, const float *w, const float *v) { return set_params_impl<float>(m, w0, w, v); }

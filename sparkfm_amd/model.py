@@ -116,6 +116,15 @@ class FMModel(Model):
         self._v = np.asfortranarray(x)
         self._dev_fresh = False
 
+    def rows(self, ids):
+        """(w[ids], v[:, ids]) straight from the device — `fm.w(i)`, `fm.v(::, i)` of the reference for a few features,
+        without copying a model that may not fit the host (fmhip_model_get_rows)."""
+        ids = np.ascontiguousarray(ids, np.int32)
+        w = np.empty(len(ids))
+        v = np.empty(len(ids) * self.num_factor)
+        _ffi.check(_ffi.load().fmhip_model_get_rows(self.handle, len(ids), _ffi.ptr(ids), _ffi.ptr(w), _ffi.ptr(v)))
+        return w, v.reshape((self.num_factor, len(ids)), order="F")
+
     def touch(self):
         """Declare that the host arrays were modified in place."""
         self._pull()

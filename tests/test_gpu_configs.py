@@ -475,3 +475,44 @@ def test_permutation_of_a_rows_nonzeros(fmhip):
         np.testing.assert_array_equal(u, v)
     oy = oracle.predict(a["w0"], a["w"], a["v"], a["row_ptr"], a["col"], a["val"])
     assert (np.abs(res[1][0] - oy) <= TOL_Y * sc).all()
+
+
+def test_c5_real_width_on_the_rows_a_small_dataset_touches(fmhip):
+    """BASELINE config 5's REAL width — 2^25 hashed slots x k=64, V = 8.6 GB, so the forward takes its flat-address
+    kernels by size (not through the test knob) — with a dataset small enough for the oracle: the model is drawn on
+    the device, the parameters of the ~10^5 touched features are fetched (fmhip_model_get_rows), and the oracle runs the
+    equivalent compact problem (feature ids remapped to 0..m-1).  Predictions and one epoch of 3 steps with (lazy) weight
+    decay must agree on every touched row; untouched rows must have decayed by (1 - eta*lambda)^3 and nothing else."""
+    from sparkfm_amd import synth
+    n1, k, br = 1 << 25, 64, 10_000
+    d = synth.make_config("C5", rows=30_000)
+    assert d["col"].max() < n1 and d["col"].max() > (1 << 24)            # really uses the upper half of the id space
+    ds = fmhip.DataSet.from_arrays(d, batch_rows=br).cache()
+    fm = fmhip.FMModel(n1 - 1, k, init_stdev=0.02, seed=3, init_on_device=True)
+    feats = np.unique(d["col"]).astype(np.int32)
+    ccol = np.searchsorted(feats, d["col"]).astype(np.int32)
+    rp, val, y = d["row_ptr"], d["val"].astype(np.float64), d["y"].astype(np.float64)
+    w_t, v_t = fm.rows(feats)
+    assert not w_t.any() and abs(v_t.std() - 0.02) < 2e-4
+    rng = np.random.default_rng(0)
+    others = np.setdiff1d(rng.integers(0, n1, 3000).astype(np.int32), feats)[:1000]
+    _, v_u0 = fm.rows(others)
+    # forward at full width
+    yh = fm.predict(ds)
+    oy = oracle.predict(0.0, w_t, v_t, rp, ccol, val, threads=8)
+    sc = term_scale(dict(y=oy[:2000], row_ptr=rp[:2001], col=ccol, val=val, w0=0.0, w=w_t, v=v_t))
+    assert (np.abs(yh[:2000] - oy[:2000]) <= TOL_Y * sc).all()
+    assert np.abs(yh - oy).max() <= 1e-4 * (1 + np.abs(oy).max())
+    # one epoch = 3 steps with weight decay: rows-only update + lazy decay on the GPU, eager dense decay in the oracle
+    eta, regs = 0.05, (0.0, 1e-3, 1e-3)
+    sgd = fmhip.HipSGD(eta=eta, reg0=regs[0], regw=regs[1], regv=regs[2])
+    sgd.learn(fm, ds)
+    ow0, ow, ov, osse = oracle.sgd_epoch(0.0, w_t, v_t, br, rp, ccol, val, y, eta, *regs, threads=8)
+    assert sgd.last_stats["sse"] == pytest.approx(osse, rel=2e-5) and sgd.last_stats["nonfinite"] == 0
+    w_g, v_g = fm.rows(feats)
+    assert rel(v_g, ov) <= 1e-5 and rel(w_g, ow) <= 1e-5 and fm.w0 == pytest.approx(ow0, rel=1e-5, abs=1e-7)
+    _, v_u = fm.rows(others)
+    np.testing.assert_allclose(v_u, v_u0 * (1.0 - eta * regs[2]) ** 3, rtol=2e-6, atol=0)
+    assert fm.computeRMSE(ds) == pytest.approx(oracle.rmse(ow0, ow, ov, rp, ccol, val, y, threads=8), rel=1e-5)
+    ds.unpersist()
+    fm.close()
