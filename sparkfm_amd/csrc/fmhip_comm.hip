@@ -235,17 +235,24 @@ int dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, d
         HIP_TRY(hipEventCreate(&pr->wait_b));
         HIP_TRY(hipEventRecord(pr->wait_a, m->stream));
     }
-    // update every interval as its slice arrives (identical on all ranks: replicas stay bit-identical)
+    // update every interval as its slice arrives (identical on all ranks: replicas stay bit-identical); intervals of
+    // less than an eighth of the rows wait for the next one and share its launch (a launch costs more than they do)
+    int64_t pend_hi = -1;
     for (int i = n_int - 1; i >= 0; --i) {
+        const int64_t lo = edge[(size_t)i], hi = edge[(size_t)i + 1];
+        if (pend_hi < 0) pend_hi = hi;
+        const bool last = i == 0;
         HIP_TRY(hipStreamWaitEvent(m->stream, c->ev_done[i], 0));
+        if (!last && (pend_hi - lo) * 8 < m->n1) continue;
         if (pr) {
             const int ai = pr->n_apply++;
             HIP_TRY(hipEventCreate(&pr->a0[ai]));
             HIP_TRY(hipEventCreate(&pr->a1[ai]));
             HIP_TRY(hipEventRecord(pr->a0[ai], m->stream));
         }
-        TRY(step_apply_interval(m, eta, reg0, regw, regv, edge[(size_t)i], edge[(size_t)i + 1], c->rows_dev, i == 0));
+        TRY(step_apply_interval(m, eta, reg0, regw, regv, lo, pend_hi, c->rows_dev, last));
         if (pr) HIP_TRY(hipEventRecord(pr->a1[pr->n_apply - 1], m->stream));
+        pend_hi = -1;
     }
     if (pr) HIP_TRY(hipEventRecord(pr->wait_b, m->stream));
     return FMHIP_OK;
