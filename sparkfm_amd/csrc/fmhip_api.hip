@@ -706,9 +706,6 @@ void hot_attach(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm, BwdArgs
     m->hot_pending = false;
 }
 
-// (the hot block's arguments are a copy inside BwdArgs: nothing to patch for the merged finish, kept as a hook)
-inline void hot_attach_fin(BwdArgs &) {}
-
 // backward + fixup of the columns whose feature id lies in [feat_lo, feat_hi) into the packed
 // gradient.  The CSC stream is sorted by feature, so the interval is a contiguous run of entries;
 // the range holding its first entry is walked by THIS call in full (the entries of lower features
@@ -769,7 +766,6 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
             ba.fin_blocks = (int32_t)std::min<int64_t>(std::max<int64_t>(blocks, 1), FMHIP_FIN_BLOCKS);
             ba.fin_own = d->own_bits.p + bm.own_off;
             ba.fin_own_bits = (int32_t)std::min<int64_t>(d->own_words * 32, INT32_MAX);
-            hot_attach_fin(ba);
         }
         {
             ProfScope ps(m, FMHIP_K_FIXUP, bm.nnz_total, bm.rows);
