@@ -8,10 +8,12 @@
 #include "csc_build.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <thread>
@@ -154,6 +156,19 @@ int host_threads(int64_t work_items) {
     return (int)std::max<int64_t>(t, 1);
 }
 
+// FMHIP_BUILD_TIMING=1: the phases of fmhip_dataset_create on stderr (what `DataSet.cache()` costs, and where)
+struct PhaseTimer {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    PhaseTimer() : on(getenv("FMHIP_BUILD_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void lap(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[fmhip build] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 // f(tid, lo, hi) over [0, n) cut into one contiguous chunk per thread
 template <class F>
 void parallel_chunks(int64_t n, int threads, F f) {
@@ -182,6 +197,7 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     if (!row_ptr) return fail(FMHIP_ERR_INVALID, "row_ptr is NULL");
     if (row_ptr[0] != 0) return fail(FMHIP_ERR_INVALID, "row_ptr[0] must be 0");
     const int T = host_threads(n_rows);
+    PhaseTimer pt;
     {
         std::vector<int64_t> bad((size_t)T, -1);
         parallel_chunks(n_rows, T, [&](int t, int64_t lo, int64_t hi) {
@@ -211,6 +227,7 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
             if (p >= 0) return fail(FMHIP_ERR_INVALID, "negative feature index at entry %lld", (long long)p);
         for (int32_t m : mx) dim = std::max(dim, m);
     }
+    pt.lap("validate");
     TRY(set_device(device));
     fmhip_dataset *d = new (std::nothrow) fmhip_dataset();
     if (!d) return fail(FMHIP_ERR_NOMEM, "out of host memory");
@@ -229,8 +246,8 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     // whole transpose) are never split.
     const int64_t *orig_row_ptr = row_ptr;
     std::vector<int64_t> sp_ptr;
-    std::vector<int32_t> sp_col;
-    std::vector<float> sp_val, xhot;
+    std::unique_ptr<int32_t[]> sp_col_buf;
+    std::unique_ptr<float[]> sp_val_buf, xhot_buf;
     std::vector<uint32_t> hot_masks;
     bool split = false;
     if (want_hot && nb > 1 && nnz > 0 && !scoring) {
@@ -238,10 +255,26 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
         // choice of hot features is a layout decision — any set that passes the checks below is valid —
         // and a feature in >= 10 % of the rows cannot hide from a sample of millions of entries).
         const int64_t stride = nnz > ((int64_t)8 << 20) ? std::max<int64_t>(1, nnz / ((int64_t)4 << 20)) : 1;
+        const int64_t sampled_rows = (n_rows + stride - 1) / stride;
         std::vector<int32_t> cnt((size_t)dim + 1, 0);
-        int64_t sampled_rows = 0;
-        for (int64_t r = 0; r < n_rows; r += stride, ++sampled_rows)
-            for (int64_t p = row_ptr[r]; p < row_ptr[r + 1]; ++p) ++cnt[(size_t)col[p]];
+        {
+            // per-thread histograms while they stay small (<= 256 MB in all), merged in thread order
+            const int Ts = ((int64_t)(dim + 1) * T * 4 <= ((int64_t)256 << 20)) ? std::min<int>(T, (int)std::max<int64_t>(sampled_rows / 4096, 1)) : 1;
+            std::vector<std::vector<int32_t>> part((size_t)(Ts > 1 ? Ts : 0));
+            parallel_chunks(sampled_rows, Ts, [&](int t, int64_t lo, int64_t hi) {
+                int32_t *c = cnt.data();
+                if (Ts > 1) { part[(size_t)t].assign((size_t)dim + 1, 0); c = part[(size_t)t].data(); }
+                for (int64_t i = lo; i < hi; ++i) {
+                    const int64_t r = i * stride;
+                    for (int64_t p = row_ptr[r]; p < row_ptr[r + 1]; ++p) ++c[(size_t)col[p]];
+                }
+            });
+            if (Ts > 1)
+                parallel_chunks((int64_t)dim + 1, Ts, [&](int, int64_t lo, int64_t hi) {
+                    for (const auto &pc : part)
+                        for (int64_t f = lo; f < hi; ++f) cnt[(size_t)f] += pc[(size_t)f];
+                });
+        }
         std::vector<int32_t> cand;
         for (int32_t f = 0; f <= dim; ++f)
             if ((int64_t)cnt[(size_t)f] * 10 >= sampled_rows) cand.push_back(f);
@@ -249,26 +282,31 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
         if (cand.size() > (size_t)kHotT) cand.resize(kHotT);
         std::vector<int32_t>().swap(cnt);
         std::vector<int8_t> slot((size_t)dim + 1, -1);
-        if (!cand.empty()) {
-            // a candidate that occurs twice in one row, or is stored with an explicit zero, keeps the
-            // sparse path (its G row must have exactly one writer)
+        sp_ptr.assign((size_t)n_rows + 1, 0);
+        // pass 1 (one sweep): the sparse length of every row if the candidates leave the streams, and which
+        // candidates may not — one that occurs twice in a row, or is stored with an explicit zero, keeps the
+        // sparse path (its G row must have exactly one writer); if any is refused the sweep runs again without it
+        while (cand.size() >= 2) {
             for (size_t h = 0; h < cand.size(); ++h) slot[(size_t)cand[h]] = (int8_t)h;
             std::vector<uint32_t> badv((size_t)T, 0u);
             parallel_chunks(n_rows, T, [&](int t, int64_t lo, int64_t hi) {
                 uint32_t bad = 0;
                 for (int64_t r = lo; r < hi; ++r) {
                     uint32_t seen = 0;
+                    int64_t keep = 0;
                     for (int64_t p = row_ptr[r]; p < row_ptr[r + 1]; ++p) {
                         const int8_t h = slot[(size_t)col[p]];
-                        if (h < 0) continue;
+                        if (h < 0) { ++keep; continue; }
                         if ((seen >> h & 1u) || (float)val[p] == 0.f) bad |= 1u << h;
                         seen |= 1u << h;
                     }
+                    sp_ptr[(size_t)r + 1] = keep;
                 }
                 badv[(size_t)t] = bad;
             });
             uint32_t bad = 0;
             for (uint32_t x : badv) bad |= x;
+            if (!bad) break;
             std::vector<int32_t> ok;
             for (size_t h = 0; h < cand.size(); ++h) {
                 slot[(size_t)cand[h]] = -1;
@@ -277,33 +315,30 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
             cand.swap(ok);
         }
         if (cand.size() >= 2) {
+            // slots in ascending feature order (the sweep above does not depend on the numbering)
             std::sort(cand.begin(), cand.end());
             d->hot_ids.assign(kHotT, -1);
             for (size_t h = 0; h < cand.size(); ++h) { d->hot_ids[h] = cand[h]; slot[(size_t)cand[h]] = (int8_t)h; }
-            xhot.assign((size_t)n_rows * kHotT, 0.f);
-            sp_ptr.assign((size_t)n_rows + 1, 0);
             hot_masks.assign((size_t)nb, 0u);
-            // pass 1: sparse length of every row; pass 2 (after the prefix sum): fill
-            parallel_chunks(n_rows, T, [&](int, int64_t lo, int64_t hi) {
-                for (int64_t r = lo; r < hi; ++r) {
-                    int64_t keep = 0;
-                    for (int64_t p = row_ptr[r]; p < row_ptr[r + 1]; ++p) keep += slot[(size_t)col[p]] < 0;
-                    sp_ptr[(size_t)r + 1] = keep;
-                }
-            });
             for (int64_t r = 0; r < n_rows; ++r) sp_ptr[(size_t)r + 1] += sp_ptr[(size_t)r];
-            sp_col.resize((size_t)sp_ptr[(size_t)n_rows]);
-            sp_val.resize((size_t)sp_ptr[(size_t)n_rows]);
+            // pass 2: fill (buffers left uninitialised: every element is written exactly once)
+            sp_col_buf.reset(new int32_t[(size_t)std::max<int64_t>(sp_ptr[(size_t)n_rows], 1)]);
+            sp_val_buf.reset(new float[(size_t)std::max<int64_t>(sp_ptr[(size_t)n_rows], 1)]);
+            xhot_buf.reset(new float[(size_t)std::max<int64_t>(n_rows, 1) * kHotT]);
+            int32_t *sp_col = sp_col_buf.get();
+            float *sp_val = sp_val_buf.get(), *xhot = xhot_buf.get();
             std::vector<std::vector<uint32_t>> tmask((size_t)T, std::vector<uint32_t>((size_t)nb, 0u));
             parallel_chunks(n_rows, T, [&](int t, int64_t lo, int64_t hi) {
                 for (int64_t r = lo; r < hi; ++r) {
                     uint32_t seen = 0;
                     int64_t o = sp_ptr[(size_t)r];
+                    float *xr = xhot + (size_t)r * kHotT;
+                    for (int h = 0; h < kHotT; ++h) xr[h] = 0.f;
                     for (int64_t p = row_ptr[r]; p < row_ptr[r + 1]; ++p) {
                         const int8_t h = slot[(size_t)col[p]];
                         if (h >= 0) {
                             seen |= 1u << h;
-                            xhot[(size_t)r * kHotT + h] = (float)val[p];
+                            xr[h] = (float)val[p];
                         } else {
                             sp_col[(size_t)o] = col[p];
                             sp_val[(size_t)o] = (float)val[p];
@@ -319,11 +354,12 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
             d->hot_T = kHotT;
         }
     }
+    pt.lap("hot block: choose + split");
     if (split) {
         row_ptr = sp_ptr.data();
-        col = sp_col.data();
+        col = sp_col_buf.get();
     }
-    const int64_t nnz_s = split ? (int64_t)sp_col.size() : nnz;
+    const int64_t nnz_s = split ? sp_ptr[(size_t)n_rows] : nnz;
     d->nnz_sparse = nnz_s;
     d->batches.resize((size_t)nb);
     for (int64_t b = 0; b < nb; ++b) {
@@ -366,11 +402,12 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
             return rc0;
         }
     }
+    pt.lap("row order + upload");
     // fp32 copies of the streams (device arithmetic is fp32)
     std::vector<float> valf, yf((size_t)n_rows, 0.f);
     const float *val_up = nullptr;
     if (split) {
-        val_up = sp_val.data();
+        val_up = sp_val_buf.get();
     } else if (std::is_same<FT, float>::value) {
         val_up = reinterpret_cast<const float *>(val);
     } else {
@@ -387,12 +424,14 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     if ((rc = upload(d->row_ptr, row_ptr, (size_t)n_rows + 1)) || (rc = upload(d->col, col, (size_t)nnz_s)) ||
         (rc = upload(d->val, val_up, (size_t)nnz_s)) || (rc = upload(d->y, yf.data(), (size_t)n_rows)) ||
         (!scoring && ((rc = d->crow.alloc((size_t)nnz_s)) || (rc = d->cval.alloc((size_t)nnz_s)))) ||
-        (split && ((rc = upload(d->xhot, xhot.data(), xhot.size())) || (rc = upload(d->d_hot_ids, d->hot_ids.data(), d->hot_ids.size()))))) {
+        (split && ((rc = upload(d->xhot, xhot_buf.get(), (size_t)n_rows * kHotT)) || (rc = upload(d->d_hot_ids, d->hot_ids.data(), d->hot_ids.size()))))) {
         delete d;
         return rc;
     }
     std::vector<float>().swap(valf);
-    std::vector<float>().swap(xhot);
+    xhot_buf.reset();
+    sp_val_buf.reset();
+    pt.lap("fp32 re-pack + H2D");
     if (scoring) {
         *out = d;
         return FMHIP_OK;
@@ -492,6 +531,7 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
             finish_batch_meta(hb, bm.nnz, cnt, base);
         }
     }
+    pt.lap("device transposes + metadata");
     // bitmap of the features whose gradient rows the fixup launch assembles (cut columns + hot block), per batch:
     // the merged finish skips them in its dense pass.  Kept for models of up to 2^24 features (2 MiB per batch).
     std::vector<uint32_t> own;
@@ -549,6 +589,7 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
         delete d;
         return rc;
     }
+    pt.lap("pack + upload column index");
     *out = d;
     return FMHIP_OK;
 }
