@@ -265,7 +265,8 @@ int fmhip_step_stats(fmhip_model_t m, fmhip_stats *stats);
  * the last message carries the head with the hottest interval; every rank applies the identical update
  * with |B| = the summed row count, so the replicas stay bit-identical.  `batch` < 0: this rank has run
  * out of rows and contributes zeros.  All ranks must call with the same (eta, reg*) and the same cuts
- * (fmhip_dp_plan). */
+ * (fmhip_dp_plan).  The summed row count travels as one fp32 word: a global batch (rows x world) must stay
+ * below 2^24 rows, larger ones are refused. */
 #define FMHIP_UNIQUE_ID_BYTES 128
 int fmhip_comm_unique_id(void *id /* FMHIP_UNIQUE_ID_BYTES out */);
 int fmhip_comm_create(fmhip_model_t m, const void *id, int rank, int world, fmhip_comm_t *out);
@@ -275,7 +276,8 @@ int fmhip_comm_info(fmhip_comm_t c, int *rank, int *world);
  * upper_fractions[i], ascending: the share of rank 0's stored nonzeros that lies at or above cut i — e.g.
  * {0.25} = two intervals, the first (ids >= cut) a quarter of the work and nearly all of the gradient's
  * bytes; {0.15, 0.5} = three.  n_fractions = 0: whole backward, one all-reduce.  cuts (nullable, room for
- * n_fractions): the ids chosen, first cut first (0 = that cut collapsed). */
+ * n_fractions): the ids chosen, first cut first (0 = that cut collapsed).  If any rank's dataset was built
+ * row-blocked (fmhip_dataset_opts.row_block_rows) nobody cuts: every rank issues the same collectives. */
 #define FMHIP_DP_MAX_CUTS 7
 int fmhip_dp_plan(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, int n_fractions, const double *upper_fractions,
                   int64_t *cuts);

@@ -186,6 +186,13 @@ int reduce_regions(fmhip_model_t m, fmhip_comm_t c, const Region *reg, int n_reg
 
 int dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0, double regw, double regv) {
     const bool live = batch >= 0;
+    if (d->rb_rows != 0 && !c->cuts.empty())
+        return fail(FMHIP_ERR_INVALID, "the communicator's plan cuts the backward, but this dataset's transposes are row-blocked: "
+                                       "call fmhip_dp_plan with this dataset (every rank)");
+    // the global row count travels as one fp32 sum: exact below 2^24 rows per global batch
+    if (live && (double)d->batches[(size_t)batch].rows * c->world >= 16777216.0)
+        return fail(FMHIP_ERR_INVALID, "a global batch of %lld x %d rows exceeds 2^24: use smaller batches",
+                    (long long)d->batches[(size_t)batch].rows, c->world);
     // |B| first: every interval's update divides by the GLOBAL row count, so it is exchanged on its own (4 bytes,
     // hidden under the forward) instead of waiting for the head in the last message
     const float my_rows = live ? (float)d->batches[(size_t)batch].rows : 0.f;
@@ -209,9 +216,8 @@ int dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, d
     }
     // intervals [edge[i], edge[i+1]) from the top down; the lowest one carries the statistics scalars
     std::vector<int64_t> edge{0};
-    if (d->rb_rows == 0)
-        for (int64_t x : c->cuts)
-            if (x > edge.back() && x < m->n1) edge.push_back(x);
+    for (int64_t x : c->cuts)
+        if (x > edge.back() && x < m->n1) edge.push_back(x);
     edge.push_back(m->n1);
     const int n_int = (int)edge.size() - 1;
     for (int i = n_int - 1; i >= 0; --i) {
@@ -373,8 +379,11 @@ int fmhip_dp_plan(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, int n_frac
         }
     }
     TRY(control_i64(m, c, cuts, kMaxCuts + 1, true));
+    // a rank whose transposes are row-blocked cannot cut its backward: then nobody does (same collectives everywhere)
+    int64_t blocked = d->rb_rows != 0;
+    TRY(control_i64(m, c, &blocked, 1, false));
     c->cuts.clear();
-    for (int i = 0; i < n_fractions; ++i)
+    for (int i = 0; i < n_fractions && !blocked; ++i)
         if (cuts[i] > 0 && cuts[i] < m->n1) c->cuts.push_back(cuts[i]);
     std::sort(c->cuts.begin(), c->cuts.end());
     c->cuts.erase(std::unique(c->cuts.begin(), c->cuts.end()), c->cuts.end());
