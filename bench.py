@@ -68,7 +68,12 @@ def gather_ceiling(table_bytes, l2_hit=None):
     committed profile exists, else the uniform-gather share min(1, 4 MiB / table)); tables beyond the
     Infinity Cache gather at the HBM rate."""
     if table_bytes > MALL_BYTES:
-        return "hbm_gather", CEIL["hbm_gather"], None
+        if l2_hit is None:
+            return "hbm_gather", CEIL["hbm_gather"], None
+        # skewed gathers from a table in HBM: the measured share hits L2; what misses is served by the Infinity Cache or by
+        # HBM in a proportion no counter separates — priced at the faster of the two, so this stays an upper bound
+        c = 1.0 / (l2_hit / CEIL["l2_gather"] + (1.0 - l2_hit) / CEIL["mall_gather"])
+        return "l2_gather x %.2f + mall_gather x %.2f (L2 misses priced at the Infinity-Cache rate: upper bound)" % (l2_hit, 1.0 - l2_hit), c, l2_hit
     h = l2_hit if l2_hit is not None else min(1.0, L2_BYTES_PER_XCD / max(table_bytes, 1))
     c = 1.0 / (h / CEIL["l2_gather"] + (1.0 - h) / CEIL["mall_gather"])
     return "l2_gather x %.2f + mall_gather x %.2f" % (h, 1.0 - h), c, h
@@ -161,9 +166,11 @@ def committed_pmc(config, k, batch_rows):
     except (OSError, ValueError, KeyError):
         return {}
     out = {}
-    for e in entries:
-        if (e.get("config"), e.get("k"), e.get("batch_rows")) == (config, k, batch_rows):
-            out[e["kernel"]] = e
+    # C5's kernels, width and batch are those of the HBM-resident leg ("C5hbm": the passes wrap tools/run_c5_shape.py)
+    for name in (config, config + "hbm"):
+        for e in entries:
+            if (e.get("config"), e.get("k"), e.get("batch_rows")) == (name, k, batch_rows):
+                out.setdefault(e["kernel"], e)
     return out
 
 
@@ -213,10 +220,12 @@ def hbm_resident_leg(device, steps=24, rows=500_000, batch_rows=250_000):
     """A model that does NOT fit the caches: C5's width (2^25 hashed slots, k=64 -> V = 8.6 GB, packed
     gradient 8.9 GB) on one GPU, Criteo-shaped rows, weight decay on (lazy rows-only update).  The one
     place where algorithmic bytes are HBM bytes."""
-    from sparkfm_amd import DataSet, FMModel, _ffi, synth
+    from sparkfm_amd import DataSet, FeatureOrder, FMModel, _ffi, synth
     L = _ffi.load()
     n1, k = 1 << 25, 64
     d = synth.make_config("C5", rows=rows)
+    # hashed slots come in no particular order: relabel by frequency at load (a pure renaming, sparkfm_amd.FeatureOrder)
+    d["col"] = FeatureOrder.fit(d["col"], n1).relabel(d["col"])
     ds = DataSet.from_arrays(d, batch_rows=batch_rows, device=device).cache()
     fm = FMModel(n1 - 1, k, seed=5, device=device, init_on_device=True)
     hm, hd, nb = fm.handle, ds.handle, ds.n_batches
@@ -243,20 +252,25 @@ def hbm_resident_leg(device, steps=24, rows=500_000, batch_rows=250_000):
     share = lay["nnz_sparse"] / max(int(d["row_ptr"][-1]), 1)          # what stayed in the sparse streams
     req = requested_bytes(64, bi["rows"], bi["nnz"], int(bi["nnz"] * share), bi["n_columns"], bool(lay["hot_ids"]),
                           bi["n_columns"], False, n1, False)
-    kern = kernel_table(prof, k, 64, req, {}, {"forward": n1 * 64 * 4, "backward": bi["rows"] * 64 * 4})
+    pmc = committed_pmc("C5hbm", k, batch_rows)
+    kern = kernel_table(prof, k, 64, req, pmc, {"forward": n1 * 64 * 4, "backward": bi["rows"] * 64 * 4})
     step_req = sum(e.get("requested_bytes_per_launch", 0) for e in kern.values())
     step_ms = dt / steps * 1e3
-    out = {"workload": "C5 width on one GPU: %d Criteo-shaped rows x 2^25 hashed slots, k=64 (V = %.1f GB), batch %d rows, "
-                       "eta 0.02, regw = regv = 1e-4 (lazy rows-only update)" % (rows, n1 * k * 4 / 1e9, batch_rows),
+    fabric = pmc.get("step", {}).get("traffic_bytes")
+    out = {"workload": "C5 width on one GPU: %d Criteo-shaped rows x 2^25 hashed slots (relabelled by frequency at load), k=64 "
+                       "(V = %.1f GB), batch %d rows, eta 0.02, regw = regv = 1e-4 (lazy rows-only update)" % (rows, n1 * k * 4 / 1e9, batch_rows),
            "value": value, "unit": "nnz/s", "ms_per_step": step_ms, "steps": steps,
            "hot_block_features": len(lay["hot_ids"]), "share_of_nonzeros_in_sparse_streams": share,
            "alg_bytes_per_nnz": ab["step"], "alg_GBps": value * ab["step"] / 1e9,
            "requested_bytes_per_step": step_req, "requested_GBps": step_req / (step_ms * 1e-3) / 1e9,
-           "frac_of_8TBps": step_req / (step_ms * 1e-3) / HBM_PEAK,
-           "note": "the algorithmic figure counts 8k+16 B for EVERY stored nonzero; the 13 numeric fields and the small categorical "
-                   "vocabularies sit in the dense hot block (LDS / one streamed 64-B record per row), so the bytes the kernels really "
-                   "request are fewer: frac_of_8TBps is requested bytes / time / 8 TB/s.  V's rows are gathered from an 8.6 GB table "
-                   "(HBM; the popular slots hit the caches), P's from 64 MB (Infinity Cache).",
+           "fabric_traffic_bytes_per_step_from_committed_profile": fabric,
+           "fabric_GBps": fabric / (step_ms * 1e-3) / 1e9 if fabric else None,
+           "frac_of_8TBps": fabric / (step_ms * 1e-3) / HBM_PEAK if fabric else None,
+           "note": "three byte counts, never to be mixed: ALGORITHMIC (8k+16 B for every stored nonzero: the 13 numeric fields and the "
+                   "small vocabularies sit in the dense hot block, popular slots hit the caches, so this exceeds what HBM moves), REQUESTED "
+                   "(our own count of the kernels' loads and stores, whatever level serves them) and FABRIC (rocprofv3 FETCH_SIZE x2 + "
+                   "WRITE_SIZE of the committed passes over this very workload, profiles/pmc_traffic.json: Infinity-Cache hits included, "
+                   "so an upper bound on HBM bytes).  frac_of_8TBps = fabric bytes / this run's step time / 8 TB/s.",
            "kernels": kern, "last_batch_mse": st.sse / max(st.rows, 1), "nonfinite": st.nonfinite}
     ds.unpersist()
     fm.close()
@@ -328,6 +342,8 @@ def main():
                     help="RANKS:BUSBW_GBps, one-rank runs only (with --force-dp): hold the comm stream after every collective for "
                          "the time a ring all-reduce over RANKS GPUs at that bus bandwidth would take (fmhip_comm_emulate), so the "
                          "overlap schedule and the cut tuning can be timed on a one-GPU box")
+    ap.add_argument("--no-relabel", action="store_true",
+                    help="C5 only: keep the hashed ids as generated instead of relabelling them by frequency at load")
     ap.add_argument("--cpu-budget", type=float, default=30.0)
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -373,6 +389,12 @@ def main():
     synth.set_threads(max(1, host_cores() // max(1, min(world, 8))) if world > 1 else host_cores())
     t0 = time.time()
     d = synth.make_config(config, rows=rows, row_begin=rank * rows)
+    relabelled = bool(cfg.get("criteo")) and not args.no_relabel
+    if relabelled:
+        # hashed slots come in no particular order: relabel by frequency at load (a pure renaming of the features;
+        # the counts are summed over the ranks so that every replica uses the same numbering)
+        from sparkfm_amd import FeatureOrder
+        d["col"] = FeatureOrder.fit(d["col"], cfg["features"], distributed=world > 1).relabel(d["col"])
     t_gen = time.time() - t0
     t0 = time.time()
     ds = DataSet.from_arrays(d, name=config, batch_rows=batch_rows, device=local_rank).cache()
@@ -588,7 +610,8 @@ def main():
             "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d rows x %d features per GPU, k=%d, %s, fp32 mini-batch SGD" %
-                                   (config, rows, n1, k, "39 hashed Criteo-shaped fields" if cfg.get("criteo") else
+                                   (config, rows, n1, k, ("39 hashed Criteo-shaped fields" + (", ids relabelled by frequency at load" if relabelled else ""))
+                                    if cfg.get("criteo") else
                                     "nnz/row U{%d..%d}, ids Zipf(%.2f)" % (cfg["nnz_lo"], cfg["nnz_hi"], cfg["zipf_s"])),
                        "rows_per_gpu": rows, "features": n1, "k": k, "batch_rows_per_gpu": batch_rows,
                        "batches_per_gpu": nb, "nnz_per_gpu": int(d["row_ptr"][-1]), "eta": args.eta, "regs": regs,

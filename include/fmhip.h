@@ -305,6 +305,24 @@ int fmhip_comm_profile_end(fmhip_comm_t c, fmhip_comm_profile *p);
  * partitioning a data-parallel caller applies before fmhip_dataset_create (pure host arithmetic). */
 int fmhip_shard_rows(int64_t n_rows, const int64_t *row_ptr, int world, int rank, int64_t *lo, int64_t *hi);
 
+/* ---- feature relabelling by frequency (pure host arithmetic, no GPU needed) ------------ */
+/* The kernels do best when small feature ids are the frequent ones: the forward stages the linear weights of the
+ * lowest ids in LDS, frequent rows then share cache lines and pages, and fmhip_dp_plan cuts the backward by id so
+ * that the first interval is "few nonzeros, most of the gradient's rows".  Ids that come in another order (hashed,
+ * dictionary order) cost ~20 % of the forward (tools/id_order_time.py).  A caller that wants the fast layout
+ * relabels: rank = position of a feature in descending order of its stored-nonzero count (ties: ascending id), the
+ * dataset is created from rank[col], and parameters move between the two numberings with `by_rank`
+ * (internal row r = the caller's feature by_rank[r]).  A pure renaming: the model and its updates are the same.
+ * Not for fmhip_als_epoch, whose Gauss-Seidel sweep runs in id order (S/fm/lib/ALS.scala:38,52).
+ *
+ *   fmhip_feature_counts   counts[c] += occurrences of c in col[0..nnz)   (caller zeroes `counts`; call once per
+ *                          partition, or sum the tables of all ranks: every rank must end up with the SAME order)
+ *   fmhip_rank_from_counts rank[n1] and, if not NULL, its inverse by_rank[n1]
+ *   fmhip_relabel_columns  out[i] = rank[col[i]]; `out` may be `col` itself */
+int fmhip_feature_counts(int64_t nnz, const int32_t *col, int64_t n1, int64_t *counts);
+int fmhip_rank_from_counts(int64_t n1, const int64_t *counts, int32_t *rank, int32_t *by_rank);
+int fmhip_relabel_columns(int64_t nnz, const int32_t *col, int64_t n1, const int32_t *rank, int32_t *out);
+
 /* ---- measurement ------------------------------------------------------------------ */
 /* How the library laid a dataset out (for byte accounting; not needed to use it): the number of
  * features held in the dense hot block (0 = none) with their ids (ids: room for 16, nullable), and

@@ -23,6 +23,10 @@ class HipSGD protected (eta: Double, reg0: Double, regw: Double, regv: Double, b
   @transient private var data: Long = 0L      // fmhip_dataset_t
   @transient private var comm: Long = 0L      // fmhip_comm_t (world > 1)
   @transient private var cached: DataSet = null
+  /** relabel feature ids by descending frequency before the upload (off: ids go to the GPU as the loader produced them) */
+  var relabel: Boolean = false
+  @transient private var rank: Array[Int] = null
+  @transient private var byRank: Array[Int] = null
 
   override def learn(fm: FMModel, dataset: DataSet): FMModel = {
     if (cached ne dataset) {                   // first call: flatten the RDD rows to CSR and upload them once
@@ -39,6 +43,14 @@ class HipSGD protected (eta: Double, reg0: Double, regw: Double, regv: Double, b
         System.arraycopy(sv.index, 0, col, o, sv.used); System.arraycopy(sv.data, 0, value, o, sv.used)
         y(r) = rows(r)._1; o += sv.used; r += 1
       }
+      if (relabel) {                           // ids by descending frequency: internal row r = the caller's feature byRank(r)
+        val n1 = fm.num_attribute + 1
+        val counts = new Array[Long](n1)
+        HipSGD.featureCounts(col, n1, counts)  // world > 1: sum `counts` over the ranks here (rdd.treeReduce / allreduce)
+        rank = new Array[Int](n1); byRank = new Array[Int](n1)
+        HipSGD.rankFromCounts(counts, rank, byRank)
+        HipSGD.relabelColumns(col, rank)
+      }
       if (data != 0L) HipSGD.datasetDestroy(data)
       data = HipSGD.datasetCreate(device, rows.length, rowPtr, col, value, y, batchRows)
       if (model == 0L) model = HipSGD.modelCreate(device, fm.num_attribute, fm.num_factor)
@@ -48,11 +60,24 @@ class HipSGD protected (eta: Double, reg0: Double, regw: Double, regv: Double, b
       }
       cached = dataset
     }
-    HipSGD.setParams(model, fm.w0, fm.w.data, fm.v.data)          // breeze column-major == ABI layout (f + i*k)
+    val k = fm.num_factor
+    if (!relabel) HipSGD.setParams(model, fm.w0, fm.w.data, fm.v.data)   // breeze column-major == ABI layout (f + i*k)
+    else {                                                          // the same arrays in the internal numbering
+      val n1 = byRank.length; val wi = new Array[Double](n1); val vi = new Array[Double](n1 * k)
+      var r = 0
+      while (r < n1) { wi(r) = fm.w.data(byRank(r)); System.arraycopy(fm.v.data, byRank(r) * k, vi, r * k, k); r += 1 }
+      HipSGD.setParams(model, fm.w0, wi, vi)
+    }
     if (world > 1) HipSGD.dpEpoch(model, data, comm, eta, reg0, regw, regv)
     else HipSGD.sgdEpoch(model, data, eta, reg0, regw, regv)
     val w0 = new Array[Double](1)
-    HipSGD.getParams(model, w0, fm.w.data, fm.v.data)              // mutate in place and return, as ALS does (:27,:40,:64,:74)
+    if (!relabel) HipSGD.getParams(model, w0, fm.w.data, fm.v.data)  // mutate in place and return, as ALS does (:27,:40,:64,:74)
+    else {
+      val n1 = byRank.length; val wi = new Array[Double](n1); val vi = new Array[Double](n1 * k)
+      HipSGD.getParams(model, w0, wi, vi)
+      var r = 0
+      while (r < n1) { fm.w.data(byRank(r)) = wi(r); System.arraycopy(vi, r * k, fm.v.data, byRank(r) * k, k); r += 1 }
+    }
     fm.w0 = w0(0)
     fm
   }
@@ -109,4 +134,9 @@ object HipSGD {
   @native def dpEpoch(model: Long, data: Long, comm: Long, eta: Double, reg0: Double, regw: Double, regv: Double): Unit
   /** [lo, hi) of `rank`, balanced by stored nonzeros (fmhip_shard_rows). */
   @native def shardRows(rowPtr: Array[Long], world: Int, rank: Int): Array[Long]
+  // feature relabelling by frequency (a pure renaming; ids that arrive hashed or in dictionary order cost ~20 % of the forward):
+  // counts accumulate into `counts` (sum the tables of all ranks before ranking), relabelColumns rewrites `col` in place
+  @native def featureCounts(col: Array[Int], n1: Long, counts: Array[Long]): Unit
+  @native def rankFromCounts(counts: Array[Long], rank: Array[Int], byRank: Array[Int]): Unit
+  @native def relabelColumns(col: Array[Int], rank: Array[Int]): Unit
 }

@@ -174,3 +174,37 @@ JNIEXPORT jlongArray JNI_FN(shardRows)(JNIEnv *env, jobject o, jlongArray rp, ji
     if (a) (*env)->SetLongArrayRegion(env, a, 0, 2, out);
     return a;
 }
+
+/* feature relabelling by frequency (include/fmhip.h): counts accumulate into `counts`; rankFromCounts fills rank and
+ * byRank; relabelColumns rewrites `col` in place */
+JNIEXPORT void JNI_FN(featureCounts)(JNIEnv *env, jobject o, jintArray col, jlong n1, jlongArray counts) {
+    jsize nnz = (*env)->GetArrayLength(env, col);
+    jint *c = (*env)->GetPrimitiveArrayCritical(env, col, NULL);
+    jlong *k = (*env)->GetPrimitiveArrayCritical(env, counts, NULL);
+    int rc = fmhip_feature_counts((int64_t)nnz, (const int32_t *)c, (int64_t)n1, (int64_t *)k);
+    (*env)->ReleasePrimitiveArrayCritical(env, counts, k, 0);
+    (*env)->ReleasePrimitiveArrayCritical(env, col, c, JNI_ABORT);
+    raise(env, rc);
+}
+
+JNIEXPORT void JNI_FN(rankFromCounts)(JNIEnv *env, jobject o, jlongArray counts, jintArray rank, jintArray byRank) {
+    jsize n1 = (*env)->GetArrayLength(env, counts);
+    jlong *k = (*env)->GetPrimitiveArrayCritical(env, counts, NULL);
+    jint *r = (*env)->GetPrimitiveArrayCritical(env, rank, NULL);
+    jint *b = (*env)->GetPrimitiveArrayCritical(env, byRank, NULL);
+    int rc = fmhip_rank_from_counts((int64_t)n1, (const int64_t *)k, (int32_t *)r, (int32_t *)b);
+    (*env)->ReleasePrimitiveArrayCritical(env, byRank, b, 0);
+    (*env)->ReleasePrimitiveArrayCritical(env, rank, r, 0);
+    (*env)->ReleasePrimitiveArrayCritical(env, counts, k, JNI_ABORT);
+    raise(env, rc);
+}
+
+JNIEXPORT void JNI_FN(relabelColumns)(JNIEnv *env, jobject o, jintArray col, jintArray rank) {
+    jsize nnz = (*env)->GetArrayLength(env, col), n1 = (*env)->GetArrayLength(env, rank);
+    jint *c = (*env)->GetPrimitiveArrayCritical(env, col, NULL);
+    jint *r = (*env)->GetPrimitiveArrayCritical(env, rank, NULL);
+    int rc = fmhip_relabel_columns((int64_t)nnz, (const int32_t *)c, (int64_t)n1, (const int32_t *)r, (int32_t *)c);
+    (*env)->ReleasePrimitiveArrayCritical(env, rank, r, JNI_ABORT);
+    (*env)->ReleasePrimitiveArrayCritical(env, col, c, 0);
+    raise(env, rc);
+}

@@ -9,7 +9,8 @@ from .model import FMModel, Model  # noqa: F401
 from .learn import FMLearn, HipALS, HipSGD  # noqa: F401
 from .fm import FM, FactorizationMachines, Task  # noqa: F401
 from .datacollection import DataCollection  # noqa: F401
+from .feature_order import FeatureOrder  # noqa: F401
 from . import fmutils as FMUtils  # noqa: F401
 
 __all__ = ["DataSet", "Features", "FMModel", "Model", "FMLearn", "HipSGD", "HipALS", "FM", "FactorizationMachines", "Task",
-           "DataCollection", "FMUtils"]
+           "DataCollection", "FMUtils", "FeatureOrder"]

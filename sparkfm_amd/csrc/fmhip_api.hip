@@ -8,6 +8,7 @@
 #include "csc_build.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -15,6 +16,7 @@
 #include <cstring>
 #include <memory>
 #include <new>
+#include <numeric>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -1698,6 +1700,65 @@ int fmhip_profile_end(fmhip_model_t m, fmhip_profile *p) {
         (void)hipEventDestroy(r.b);
     }
     m->prof.clear();
+    return FMHIP_OK;
+}
+
+// ---- feature relabelling by frequency (host arithmetic; see include/fmhip.h) -----------------------------------
+int fmhip_feature_counts(int64_t nnz, const int32_t *col, int64_t n1, int64_t *counts) {
+    if (nnz < 0 || n1 < 1 || n1 > INT32_MAX || !counts || (nnz > 0 && !col)) return fail(FMHIP_ERR_INVALID, "bad arguments");
+    const int T = host_threads(nnz);
+    std::atomic<int64_t> bad{-1};
+    // a private table per thread while that stays small (<= 64 MiB each), one shared table with atomic adds beyond
+    const bool private_tables = T > 1 && n1 <= (int64_t)1 << 23;
+    std::vector<std::vector<int64_t>> part(private_tables ? (size_t)T : 0);
+    parallel_chunks(nnz, T, [&](int t, int64_t lo, int64_t hi) {
+        int64_t *dst = counts;
+        if (private_tables) {
+            part[(size_t)t].assign((size_t)n1, 0);
+            dst = part[(size_t)t].data();
+        }
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t c = col[i];
+            if (c < 0 || c >= n1) { bad.store(i); return; }
+            if (private_tables || T == 1) ++dst[c];
+            else __atomic_fetch_add(&dst[c], (int64_t)1, __ATOMIC_RELAXED);
+        }
+    });
+    if (bad.load() >= 0) return fail(FMHIP_ERR_INVALID, "col[%lld] = %d outside [0, %lld)", (long long)bad.load(), col[bad.load()], (long long)n1);
+    if (private_tables)
+        parallel_chunks(n1, T, [&](int, int64_t lo, int64_t hi) {
+            for (int t = 0; t < T; ++t) {
+                const int64_t *src = part[(size_t)t].data();
+                for (int64_t f = lo; f < hi; ++f) counts[f] += src[f];
+            }
+        });
+    return FMHIP_OK;
+}
+
+int fmhip_rank_from_counts(int64_t n1, const int64_t *counts, int32_t *rank, int32_t *by_rank) {
+    if (n1 < 1 || n1 > INT32_MAX || !counts || !rank) return fail(FMHIP_ERR_INVALID, "bad arguments");
+    std::vector<int32_t> order((size_t)n1);
+    std::iota(order.begin(), order.end(), 0);
+    // descending count, ties by ascending id: every rank of a job derives the same order from the same counts
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return counts[a] > counts[b]; });
+    for (int64_t r = 0; r < n1; ++r) {
+        rank[order[(size_t)r]] = (int32_t)r;
+        if (by_rank) by_rank[r] = order[(size_t)r];
+    }
+    return FMHIP_OK;
+}
+
+int fmhip_relabel_columns(int64_t nnz, const int32_t *col, int64_t n1, const int32_t *rank, int32_t *out) {
+    if (nnz < 0 || n1 < 1 || !rank || (nnz > 0 && (!col || !out))) return fail(FMHIP_ERR_INVALID, "bad arguments");
+    std::atomic<int64_t> bad{-1};
+    parallel_chunks(nnz, host_threads(nnz), [&](int, int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t c = col[i];
+            if (c < 0 || c >= n1) { bad.store(i); return; }
+            out[i] = rank[c];
+        }
+    });
+    if (bad.load() >= 0) return fail(FMHIP_ERR_INVALID, "col[%lld] outside [0, %lld): nothing can be relied on in `out`", (long long)bad.load(), (long long)n1);
     return FMHIP_OK;
 }
 

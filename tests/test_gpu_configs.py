@@ -520,3 +520,40 @@ def test_c5_real_width_on_the_rows_a_small_dataset_touches(fmhip):
     assert fm.computeRMSE(ds) == pytest.approx(oracle.rmse(ow0, ow, ov, rp, ccol, val, y, threads=8), rel=1e-5)
     ds.unpersist()
     fm.close()
+
+
+@pytest.mark.parametrize("regs", [(0.0, 0.0, 0.0), (0.0, 0.05, 0.05)])
+def test_training_on_relabelled_ids_is_the_same_model(fmhip, regs):
+    """FeatureOrder (fmhip_feature_counts / _rank_from_counts / _relabel_columns): ids that arrive in an arbitrary
+    order are relabelled by frequency, the model trains in the internal numbering, parameters come back in the
+    caller's — a pure renaming, so the oracle run on the CALLER's ids must be matched (prediction, two epochs of SGD
+    with and without decay, RMSE), and the frequent features really end up at the small ids (hot block = ids 0..15)."""
+    from sparkfm_amd import FeatureOrder, synth
+    d = synth.make_zipf(909, 3000, 700, 0, 30, zipf_s=1.05)
+    rng = np.random.default_rng(2)
+    a = dict(n1=700, k=32, row_ptr=d["row_ptr"], col=d["col"], val=d["val"].astype(np.float64), y=d["y"].astype(np.float64),
+             w0=0.05, w=rng.normal(0, 0.1, 700), v=rng.normal(0, 0.1, (32, 700)))
+    perm = rng.permutation(a["n1"]).astype(np.int32)
+    col = perm[a["col"]]                                           # the caller's (scrambled) ids
+    w, v = np.empty_like(a["w"]), np.empty_like(a["v"])
+    w[perm], v[:, perm] = a["w"], a["v"]                           # the same model under those ids
+    order = FeatureOrder.fit(col, a["n1"])
+    ds = fmhip.DataSet(a["row_ptr"], order.relabel(col), a["val"], a["y"], batch_rows=1000).cache()
+    hot = ds.layout()["hot_ids"]
+    assert len(hot) > 0 and max(hot) < 2 * len(hot)                # the hot block's features are the lowest ids
+    fm = fmhip.FMModel(a["n1"] - 1, a["k"])
+    order.set_params(fm, a["w0"], w, v)
+    yh = fm.predict(ds)
+    oy = oracle.predict(a["w0"], w, v, a["row_ptr"], col, a["val"])
+    assert (np.abs(yh - oy) <= TOL_Y * term_scale(dict(a, col=col, w=w, v=v))).all()
+    sgd = fmhip.HipSGD(eta=0.05, reg0=regs[0], regw=regs[1], regv=regs[2])
+    ow0, ow, ov = a["w0"], w, v
+    for _ in range(2):
+        sgd.learn(fm, ds)
+        ow0, ow, ov, _ = oracle.sgd_epoch(ow0, ow, ov, 1000, a["row_ptr"], col, a["val"], a["y"], 0.05, *regs)
+    g0, gw, gv = order.get_params(fm)
+    assert np.abs(gv - ov).max() <= 2e-4 * np.abs(ov).max() and np.abs(gw - ow).max() <= 2e-4 * max(np.abs(ow).max(), 1e-30)
+    assert g0 == pytest.approx(ow0, rel=1e-4, abs=1e-6)
+    assert fm.computeRMSE(ds) == pytest.approx(oracle.rmse(ow0, ow, ov, a["row_ptr"], col, a["val"], a["y"]), rel=1e-4)
+    ds.unpersist()
+    fm.close()

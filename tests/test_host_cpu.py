@@ -257,3 +257,43 @@ def test_committed_bench_line_keeps_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "nnz/s" and c["sample"]
     assert d["sustained"]["seconds"] >= 2.0 and d["extra"]["hbm_resident"]["frac_of_8TBps"] <= 1.0
+
+
+def test_feature_order_utilities_are_host_arithmetic():
+    """fmhip_feature_counts / fmhip_rank_from_counts / fmhip_relabel_columns against numpy (no GPU involved):
+    descending count, ties by ascending id; accumulation over partitions; in-place relabelling; bad ids refused."""
+    from sparkfm_amd import FeatureOrder, _ffi
+    rng = np.random.Generator(np.random.PCG64(11))
+    for n1, nnz in ((7, 0), (50, 400), (5000, 300_000), ((1 << 23) + 3, 200_000)):
+        col = (rng.zipf(1.3, nnz) % n1).astype(np.int32)
+        perm = rng.permutation(n1).astype(np.int32)
+        col = perm[col]                                   # frequent ids anywhere in the id space
+        cnt = FeatureOrder.counts(col[: nnz // 2], n1)
+        FeatureOrder.counts(col[nnz // 2:], n1, into=cnt)  # two partitions into one table
+        assert np.array_equal(cnt, np.bincount(col, minlength=n1))
+        order = FeatureOrder.from_counts(cnt)
+        want = np.lexsort((np.arange(n1), -cnt)).astype(np.int32)      # by count descending, then id ascending
+        assert np.array_equal(order.by_rank, want)
+        assert np.array_equal(order.rank[order.by_rank], np.arange(n1))
+        new = order.relabel(col)
+        assert np.array_equal(order.by_rank[new], col)
+        if nnz:
+            c2 = np.bincount(new, minlength=n1)
+            assert np.all(np.diff(c2) <= 0)               # counts now fall with the id
+        buf = col.copy()
+        order.relabel(buf, out=buf)                       # `out` may be `col`
+        assert np.array_equal(buf, new)
+        w = rng.normal(size=n1) if n1 < 10_000 else np.zeros(n1)
+        v = rng.normal(size=(3, n1)) if n1 < 10_000 else np.zeros((3, n1))
+        wi, vi = order.to_internal(w, v)
+        assert np.array_equal(wi[order.rank], w) and np.array_equal(vi[:, order.rank], v)
+        wb, vb = order.to_caller(wi, vi)
+        assert np.array_equal(wb, w) and np.array_equal(vb, v)
+    bad = np.array([0, 3, 9], np.int32)
+    L = _ffi.load()
+    cnt = np.zeros(5, np.int64)
+    assert L.fmhip_feature_counts(3, bad.ctypes.data, 5, cnt.ctypes.data) == -1
+    assert b"outside" in L.fmhip_last_error()
+    assert L.fmhip_relabel_columns(3, bad.ctypes.data, 5, np.arange(5, dtype=np.int32).ctypes.data, bad.ctypes.data) == -1
+    ident = FeatureOrder.identity(6)
+    assert np.array_equal(ident.relabel(np.array([5, 0, 2], np.int32)), [5, 0, 2])

@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (through gpurun): kernel-trace statistics plus the PMC passes of the bench workload and of
 # the HBM-resident leg, one rocprofv3 run per counter group (FETCH_SIZE and WRITE_SIZE do not fit one pass;
 # never together with a trace domain).  Raw CSVs land in gpurun_out/<tag>_*; tools/make_pmc_json.py condenses them.
-#   tools/profile_round.sh <tag> [bench args...]
+#   tools/profile_round.sh <tag> [bench args...]      (SKIP_C5=1 / ONLY_C5=1: one of the two workloads only)
 set -e
 tag=${1:-r02}; shift || true
 cd "$(dirname "$0")/.."
@@ -14,11 +14,13 @@ run() { # name, rocprof args...
   (cd /tmp && rocprofv3 "$@" -d $root/gpurun_out/${tag}_$name -o $name --output-format csv -- $BENCH > $root/gpurun_out/${tag}_$name.log 2>&1) || { echo "$name failed"; tail -5 $root/gpurun_out/${tag}_$name.log; return 1; }
   echo "$name ok"
 }
-run stats --kernel-trace --stats
-run fetch --pmc FETCH_SIZE
-run write --pmc WRITE_SIZE
-run l2 --pmc TCC_HIT_sum TCC_MISS_sum
-run sq --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
+if [ -z "$ONLY_C5" ]; then
+  run stats --kernel-trace --stats
+  run fetch --pmc FETCH_SIZE
+  run write --pmc WRITE_SIZE
+  run l2 --pmc TCC_HIT_sum TCC_MISS_sum
+  run sq --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
+fi
 # the HBM-resident leg (C5 width) on its own
 if [ -z "$SKIP_C5" ]; then
   BENCH="python3 $root/tools/run_c5_shape.py 16"
