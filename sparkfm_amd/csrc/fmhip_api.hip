@@ -445,7 +445,7 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
         // feature-sorted copy of every row (stable: equal ids keep their stored order)
         std::vector<int32_t> scol((size_t)nnz);
         std::vector<double> sval((size_t)nnz);
-        std::vector<bool> dupv((size_t)T, false);
+        std::vector<char> dupv((size_t)T, 0);      // one byte per thread (vector<bool> packs bits: concurrent writes would race)
         parallel_chunks(n_rows, T, [&](int t, int64_t lo, int64_t hi) {
             std::vector<int32_t> idx;
             bool dup = false;
@@ -460,9 +460,9 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
                     if (j && scol[(size_t)(p0 + j)] == scol[(size_t)(p0 + j - 1)]) dup = true;
                 }
             }
-            dupv[(size_t)t] = dup;
+            dupv[(size_t)t] = dup ? 1 : 0;
         });
-        for (bool b : dupv) d->als_dup = d->als_dup || b;
+        for (char b : dupv) d->als_dup = d->als_dup || b != 0;
         if ((rc = upload(d->val64, val64.data(), val64.size())) || (rc = upload(d->y64, y64.data(), y64.size())) ||
             (rc = d->cval64.alloc((size_t)nnz)) || (rc = upload(d->scol, scol.data(), scol.size())) ||
             (rc = upload(d->sval64, sval.data(), sval.size()))) {
