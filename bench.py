@@ -344,6 +344,8 @@ def main():
                          "overlap schedule and the cut tuning can be timed on a one-GPU box")
     ap.add_argument("--no-relabel", action="store_true",
                     help="C5 only: keep the hashed ids as generated instead of relabelling them by frequency at load")
+    ap.add_argument("--hot-pages", type=int, default=0,
+                    help="A/B: pages of the dense hot block (fmhip_tune key 12; 1 = the two-sided page only, default = library's 3)")
     ap.add_argument("--cpu-budget", type=float, default=30.0)
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -386,6 +388,8 @@ def main():
     batch_rows = min(args.batch_rows or (625_000 if use_dp else 250_000), rows)
     regs = (0.0, 1e-4, 1e-4)
 
+    if args.hot_pages:
+        _ffi.check(_ffi.load().fmhip_tune(12, args.hot_pages))
     synth.set_threads(max(1, host_cores() // max(1, min(world, 8))) if world > 1 else host_cores())
     t0 = time.time()
     d = synth.make_config(config, rows=rows, row_begin=rank * rows)

@@ -29,7 +29,7 @@ SYMBOLS = (
     "fmhip_rows_create", "fmhip_rows_create_f32", "fmhip_predict_rows", "fmhip_model_init_normal", "fmhip_dataset_layout", "fmhip_dataset_create_opts", "fmhip_model_get_rows",
     "fmhip_comm_unique_id", "fmhip_comm_create", "fmhip_comm_destroy", "fmhip_comm_info", "fmhip_dp_plan",
     "fmhip_dp_step", "fmhip_dp_epoch", "fmhip_comm_profile_begin", "fmhip_comm_profile_end", "fmhip_shard_rows", "fmhip_comm_emulate",
-    "fmhip_feature_counts", "fmhip_rank_from_counts", "fmhip_relabel_columns",
+    "fmhip_feature_counts", "fmhip_rank_from_counts", "fmhip_relabel_columns", "fmhip_dataset_hot_pages",
 )
 UNIQUE_ID_BYTES = 128
 
@@ -146,6 +146,7 @@ def load():
     L.fmhip_comm_profile_begin.argtypes = [vp]
     L.fmhip_comm_profile_end.argtypes = [vp, P(CommProfile)]
     L.fmhip_shard_rows.argtypes = [i64, vp, C.c_int, C.c_int, P(i64), P(i64)]
+    L.fmhip_dataset_hot_pages.argtypes = [vp, P(C.c_int32), P(C.c_int32), vp, P(i64)]
     L.fmhip_feature_counts.argtypes = [i64, vp, i64, vp]
     L.fmhip_rank_from_counts.argtypes = [i64, vp, vp, vp]
     L.fmhip_relabel_columns.argtypes = [i64, vp, i64, vp, vp]

@@ -27,9 +27,12 @@ hipError_t csc_scratch_bytes(size_t max_nnz, int key_bits, size_t *bytes);
 // result as SparkFM's zipWithIndex + flatMap + groupByKey (S/DataSet.scala:31-38) with the
 // unspecified groupByKey order fixed to ascending rows.  Leaves the column starts / feature ids /
 // column count in the scratch (device) for the caller to read back.
+// `drop` (nullable): bitmap over the feature ids whose entries are to stay OUT of the transpose (the gradient-side pages
+// of the dense hot block): they are keyed `drop_key` (an id above every real one, inside key_bits; not with row blocks)
+// and so form one last pseudo-column that the caller cuts off.
 hipError_t csc_build_batch(hipStream_t s, const CscScratch &sc, const int64_t *row_ptr, const int32_t *col,
                            const float *val, const double *val64, int64_t row0, int64_t rows, int64_t nnz0,
                            int32_t nnz, int key_bits, int32_t rb_rows, int rb_bits, uint32_t *crow, float *cval,
-                           double *cval64);
+                           double *cval64, const uint32_t *drop = nullptr, int32_t drop_key = 0);
 
 }  // namespace fmhip

@@ -17,7 +17,7 @@ namespace {
 
 __global__ __launch_bounds__(256) void k_expand(const int64_t *row_ptr, const int32_t *col, int64_t row0, int64_t rows,
                                                 int64_t nnz0, int32_t rb_rows, int key_bits, int32_t *keys, uint32_t *idx,
-                                                int32_t *rowid) {
+                                                int32_t *rowid, const uint32_t *drop, int32_t drop_key) {
     // one 8-lane group per row: coalesced 32-B pieces of the row's entries
     const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
     const int l = threadIdx.x & 7;
@@ -26,7 +26,9 @@ __global__ __launch_bounds__(256) void k_expand(const int64_t *row_ptr, const in
     for (int64_t p = p0 + l; p < p1; p += 8) {
         const int64_t o = p - nnz0;
         // sort key: (row block, feature id) — row blocks keep a block's P rows L2-resident in the backward
-        keys[o] = col[p] | (int32_t)((r / rb_rows) << key_bits);
+        const int32_t c = col[p];
+        const bool out = drop && (drop[c >> 5] >> (c & 31) & 1u);
+        keys[o] = out ? drop_key : (c | (int32_t)((r / rb_rows) << key_bits));
         idx[o] = (uint32_t)o;
         rowid[o] = (int32_t)r;
     }
@@ -70,13 +72,13 @@ hipError_t csc_scratch_bytes(size_t max_nnz, int key_bits, size_t *bytes) {
 hipError_t csc_build_batch(hipStream_t s, const CscScratch &sc, const int64_t *row_ptr, const int32_t *col,
                            const float *val, const double *val64, int64_t row0, int64_t rows, int64_t nnz0,
                            int32_t nnz, int key_bits, int32_t rb_rows, int rb_bits, uint32_t *crow, float *cval,
-                           double *cval64) {
+                           double *cval64, const uint32_t *drop, int32_t drop_key) {
     hipError_t e = hipMemsetAsync(sc.count, 0, sizeof(int32_t), s);
     if (e != hipSuccess || nnz == 0) return e;
     {
         const int64_t threads = rows * 8;
         hipLaunchKernelGGL(k_expand, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, row_ptr, col, row0, rows, nnz0,
-                           rb_rows, key_bits, sc.keys_a, sc.idx_a, sc.rowid);
+                           rb_rows, key_bits, sc.keys_a, sc.idx_a, sc.rowid, drop, drop_key);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     size_t tb = sc.tmp_bytes;

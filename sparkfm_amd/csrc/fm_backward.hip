@@ -131,8 +131,10 @@ __device__ __forceinline__ void slots_reduce(float4 (&acc)[J], float &sa, float 
 // gather-bound column walk of the other workgroups, no extra launch); the reduction rides in k_fixup.
 template <int NJ>
 __device__ __forceinline__ void hot_backward_body(const HotArgs &a, int bx, int nbx) {
-    static_assert(kHotT == 16 && kBlock == 256, "tile mapping below assumes a 16-slot hot block and 4 waves");
+    static_assert(kHotT == 16 && kBlock == 256, "tile mapping below assumes 16-slot pages and 4 waves");
     constexpr int KP = 16 * NJ, PR = KP + kPartPad, W = kBlock / 64;
+    constexpr int PG = hot_pages_max(KP);                      // pages one pass over P carries (its accumulators); wider
+                                                               // rows take the pages one pass each
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int kk = lane >> 4, jj = lane & 15;
@@ -141,61 +143,83 @@ __device__ __forceinline__ void hot_backward_body(const HotArgs &a, int bx, int 
     const int64_t beg64 = (int64_t)(bx * W + wv) * per;
     const int r_beg = beg64 < a.n_rows ? (int)beg64 : a.n_rows;
     const int r_end = r_beg + per < a.n_rows ? r_beg + per : a.n_rows;
-    f32x4 acc[NJ];
+    __shared__ float red[W][kHotT][17];
+    __shared__ float reds[W][kHotT][2];
+    float *out = a.part + (size_t)bx * (a.pages * kHotT) * PR;
+    const int oh = threadIdx.x >> 4, of = threadIdx.x & 15;
+    for (int p0 = 0; p0 < a.pages; p0 += PG) {
+        const int pages = a.pages - p0 < PG ? a.pages - p0 : PG;   // wave-uniform: the branches on it below are scalar
+        const float *xh = a.xhot + (size_t)p0 * a.page_stride;
+        f32x4 acc[PG][NJ];
+        float sa[PG], sb[PG];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float sa = 0.f, sb = 0.f;
-    constexpr int U = NJ <= 4 ? 4 : 2;                         // 4-row steps whose loads are in flight together
-    for (int r0 = r_beg; r0 < r_end; r0 += 4 * U) {
-        float x[U], e[U], b[U][NJ];
+        for (int p = 0; p < PG; ++p) {
+            sa[p] = 0.f;
+            sb[p] = 0.f;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int r = r0 + 4 * u + kk;
-            x[u] = 0.f;
-            e[u] = 0.f;
+            for (int j = 0; j < NJ; ++j) acc[p][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        constexpr int U = NJ <= 4 ? 4 : 2;                     // 4-row steps whose loads are in flight together
+        for (int r0 = r_beg; r0 < r_end; r0 += 4 * U) {
+            float x[U][PG], e[U], b[U][NJ];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) b[u][j] = 0.f;
-            if (r < r_end) {
-                x[u] = a.xhot[(size_t)r * kHotT + jj];
-                const float *pr = a.P + (size_t)r * KP;
-                e[u] = a.pack_k >= 0 ? pr[a.pack_k] : a.e[r];
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + 4 * u + kk;
+                e[u] = 0.f;
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) b[u][j] = pr[j * 16 + jj];
+                for (int p = 0; p < PG; ++p) x[u][p] = 0.f;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[u][j] = 0.f;
+                if (r < r_end) {
+#pragma unroll
+                    for (int p = 0; p < PG; ++p)
+                        if (p < pages) x[u][p] = xh[(size_t)p * a.page_stride + (size_t)r * kHotT + jj];
+                    const float *pr = a.P + (size_t)r * KP;
+                    e[u] = a.pack_k >= 0 ? pr[a.pack_k] : a.e[r];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) b[u][j] = pr[j * 16 + jj];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int p = 0; p < PG; ++p) {
+                    if (p >= pages) continue;
+                    accum_scalars(sa[p], sb[p], e[u], x[u][p]);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u][p], b[u][j], acc[p][j], 0, 0, 0);
+                }
             }
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            accum_scalars(sa, sb, e[u], x[u]);
+        for (int p = 0; p < PG; ++p) {
+            if (p >= pages) continue;
+            float s0 = sa[p], s1 = sb[p];
+            s0 += __shfl_xor(s0, 16, 64);
+            s1 += __shfl_xor(s1, 16, 64);
+            s0 += __shfl_xor(s0, 32, 64);
+            s1 += __shfl_xor(s1, 32, 64);                      // lanes 0..15: the sums of slot `lane` of this page
+            float *po = out + (size_t)((p0 + p) * kHotT) * PR;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u], b[u][j], acc[j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j) {
+                __syncthreads();                               // the previous round's readers are done with `red`
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) red[wv][kk * 4 + reg][jj] = acc[p][j][reg];   // C/D: row = (lane>>4)*4 + reg, col = lane&15
+                __syncthreads();
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < W; ++w) t += red[w][oh][of];
+                po[(size_t)oh * PR + j * 16 + of] = t;
+            }
+            if (lane < kHotT) { reds[wv][lane][0] = s0; reds[wv][lane][1] = s1; }
+            __syncthreads();
+            if (threadIdx.x < kHotT * 2) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < W; ++w) t += reds[w][threadIdx.x >> 1][threadIdx.x & 1];
+                po[(size_t)(threadIdx.x >> 1) * PR + KP + (threadIdx.x & 1)] = t;
+            }
         }
-    }
-    sa += __shfl_xor(sa, 16, 64);
-    sb += __shfl_xor(sb, 16, 64);
-    sa += __shfl_xor(sa, 32, 64);
-    sb += __shfl_xor(sb, 32, 64);                              // lanes 0..15: the sums of hot slot `lane`
-    __shared__ float red[W][kHotT][17];
-    __shared__ float reds[W][kHotT][2];
-    float *out = a.part + (size_t)bx * kHotT * PR;
-    const int oh = threadIdx.x >> 4, of = threadIdx.x & 15;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        if (j) __syncthreads();
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) red[wv][kk * 4 + reg][jj] = acc[j][reg];   // C/D: row = (lane>>4)*4 + reg, col = lane&15
-        __syncthreads();
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < W; ++w) t += red[w][oh][of];
-        out[(size_t)oh * PR + j * 16 + of] = t;
-    }
-    if (lane < kHotT) { reds[wv][lane][0] = sa; reds[wv][lane][1] = sb; }
-    __syncthreads();
-    if (threadIdx.x < kHotT * 2) {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < W; ++w) t += reds[w][threadIdx.x >> 1][threadIdx.x & 1];
-        out[(size_t)(threadIdx.x >> 1) * PR + KP + (threadIdx.x & 1)] = t;
     }
 }
 
@@ -210,7 +234,7 @@ __device__ __forceinline__ void hot_reduce_body(const HotArgs &a, int h, int kp,
     const int f = threadIdx.x % R4, g = threadIdx.x / R4;
     float4 t = f4zero();
     if (g < G)
-        for (int b = g; b < a.nblk; b += G) f4add(t, reinterpret_cast<const float4 *>(a.part + ((size_t)b * kHotT + h) * PR)[f]);
+        for (int b = g; b < a.nblk; b += G) f4add(t, reinterpret_cast<const float4 *>(a.part + ((size_t)b * (a.pages * kHotT) + h) * PR)[f]);
     sh[threadIdx.x] = t;
     __syncthreads();
     float4 u = f4zero();
@@ -611,8 +635,8 @@ __global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
         return;
     }
     if (HOT) {
-        // kHotT more workgroups finish the dense hot block's gradient rows
-        const int hot0 = fin0 - kHotT;
+        // one more workgroup per hot slot finishes the dense hot block's gradient rows
+        const int hot0 = fin0 - a.hot.pages * kHotT;
         if ((int)blockIdx.x >= hot0) {
             hot_reduce_body(a.hot, (int)blockIdx.x - hot0, KP, a.fin, a.fin_blocks > 0);
             return;
@@ -761,7 +785,7 @@ template <int LPN, int J>
 hipError_t fix_dispatch(const BwdArgs &a, hipStream_t s) {
     constexpr int SLOTS = kBlock / LPN;
     const int extra = a.red_bsum ? 1 : 0;
-    const int hot = a.hot_blocks > 0 ? kHotT : 0;
+    const int hot = a.hot_blocks > 0 ? a.hot.pages * kHotT : 0;
     if (a.n_split < 1 && a.n_split_short < 1 && !extra && !hot && a.fin_blocks < 1) return hipSuccess;
     dim3 g((unsigned)((a.n_split_short + SLOTS - 1) / SLOTS + a.n_split + hot + a.fin_blocks + extra)), b(kBlock);
     if (hot) hipLaunchKernelGGL((k_fixup<LPN, J, true>), g, b, 0, s, a);

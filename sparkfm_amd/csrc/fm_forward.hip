@@ -5,7 +5,7 @@
 
 namespace fmhip {
 
-int g_tune[kTuneCount] = {60, 1, 0, 0, 0, 1, 0, 1, 0, 1, 0, 1};   // forward: w-tile kernel; backward: pipelined; tile rows: auto; row blocks, XCD placement: off; hot block: on; row order: on; forced flat loads: off; lazy decay: on; fused update: off; merged finish: on
+int g_tune[kTuneCount] = {60, 1, 0, 0, 0, 1, 0, 1, 0, 1, 0, 1, kHotPages};   // forward: w-tile kernel; backward: pipelined; tile rows: auto; row blocks, XCD placement: off; hot block: on; row order: on; forced flat loads: off; lazy decay: on; fused update: off; merged finish: on; hot pages: all
 
 int padded_factors(int k) {
     int kp = 32;   // a row is at least one 128-B line: the cost of a gather is per line, not per byte

@@ -13,8 +13,16 @@ constexpr int kGradHead = 32;      // floats reserved for them at the front of t
 
 // runtime kernel-variant knobs (diagnostics / A-B benchmarking; fmhip_tune)
 enum { kTuneFwd = 0, kTuneBwd = 1, kTuneTile = 2, kTuneRowBlock = 3, kTuneXcd = 4, kTuneHot = 5, kTuneFwdOcc = 6, kTuneRowOrder = 7,
-       kTuneFlat = 8, kTuneLazy = 9, kTuneFused = 10, kTuneMerged = 11, kTuneCount = 12 };
-constexpr int kHotT = 16;           // slots of the dense hot block (fp32 per row: one 64-B half line)
+       kTuneFlat = 8, kTuneLazy = 9, kTuneFused = 10, kTuneMerged = 11, kTuneHotPages = 12, kTuneCount = 13 };
+constexpr int kHotT = 16;           // slots of one page of the dense hot block (fp32 per row: one 64-B half line)
+// Pages of the dense hot block.  Page 0 (the 16 most frequent features) is dense on BOTH sides: its entries leave the
+// CSR and the CSC streams.  Pages 1.. (the next most frequent ones that still pass the density test) are dense on the
+// GRADIENT side only: their entries stay in the CSR stream the forward walks (a longer dense prologue costs the forward
+// its occupancy — profiles/r02_experiments.md §18) but leave the CSC stream, where every entry costs the backward a P-row
+// gather; the MFMA block product below forms their gradient rows in the same pass over P as page 0's.
+constexpr int kHotPages = 3;
+// pages the gradient-side block product can carry for a padded factor count (its accumulators: pages x Kp/16 x 4 VGPRs)
+constexpr int hot_pages_max(int Kp) { return Kp <= 64 ? kHotPages : 1; }
 extern int g_tune[kTuneCount];
 
 // padded factor count: 4 * LPN * J with LPN = lanes per row-slot (<= 16), J float4 per lane
@@ -67,13 +75,15 @@ struct FusedUpd {
 struct HotArgs {
     const float *P;          // [n_rows][Kp] = e*q (slot pack_k = e for packed rows)
     const float *e;          // [n_rows]
-    const float *xhot;       // [n_rows][kHotT]
-    const int32_t *hot_ids;  // [kHotT], -1 = unused slot
-    float *part;             // [hot_blocks][kHotT][Kp + kPartPad] per-workgroup partial sums
+    const float *xhot;       // page p: [n_rows][kHotT] at xhot + p * page_stride (this batch's slice)
+    int64_t page_stride;     // floats between the pages of xhot
+    const int32_t *hot_ids;  // [pages * kHotT], -1 = unused slot
+    float *part;             // [hot_blocks][pages * kHotT][Kp + kPartPad] per-workgroup partial sums
     float *GV, *Gw, *Gb;
     int32_t n_rows;
     int32_t pack_k;
     int32_t nblk;            // hot_blocks(Kp, n_rows)
+    int32_t pages;           // 1 .. hot_pages_max(Kp)
     FusedUpd upd;
 };
 struct ApplyArgs {
@@ -142,7 +152,7 @@ struct BwdArgs {
     float red_eta, red_reg0;
     FusedUpd upd;
     // dense hot block (hot_blocks > 0): the first hot_blocks workgroups of the backward launch form its
-    // partial sums while the others walk the sparse stream; kHotT extra workgroups of k_fixup finish it
+    // partial sums while the others walk the sparse stream; pages * kHotT extra workgroups of k_fixup finish it
     HotArgs hot;
     int32_t hot_blocks;
 };

@@ -186,12 +186,14 @@ void parallel_chunks(int64_t n, int threads, F f) {
 
 // scoring = true: rows + labels only (FMModel.predict / Model.computeRMSE on held-out data,
 // S/driver.scala:100-112) — no transposes, no hot block, nothing a training step needs
-// hot_opt / rb_opt: -1 = the process-wide defaults (fmhip_tune keys 5 / 3)
+// hot_opt: -1 = the process-wide defaults (fmhip_tune keys 5, 12), 0 = no hot block, n >= 1 = up to n pages of it;
+// rb_opt: -1 = the default (key 3)
 template <typename FT>
 int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const FT *val,
                         const FT *y, int64_t batch_rows, bool scoring, fmhip_dataset_t *out, int hot_opt = -1,
                         int64_t rb_opt = -1) {
     const bool want_hot = hot_opt < 0 ? g_tune[kTuneHot] > 0 : hot_opt > 0;
+    const int max_hot_pages = std::max(1, std::min(kHotPages, hot_opt > 0 ? hot_opt : g_tune[kTuneHotPages]));
     const int64_t want_rb = rb_opt < 0 ? (g_tune[kTuneRowBlock] > 0 ? g_tune[kTuneRowBlock] : 0) : rb_opt;
     if (!out) return fail(FMHIP_ERR_INVALID, "out is NULL");
     *out = nullptr;
@@ -242,15 +244,19 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     if (batch_rows <= 0 || batch_rows > n_rows) batch_rows = std::max<int64_t>(n_rows, 1);
     d->batch_rows = batch_rows;
     const int64_t nb = n_rows > 0 ? (n_rows + batch_rows - 1) / batch_rows : 0;
-    // ---- dense hot block (fmhip_tune key 5): features present in >= 10 % of the rows (the kHotT most
-    // frequent of them) leave the sparse streams; x_rh sits in xhot[r][slot].  A second occurrence of a
-    // hot feature inside one row stays sparse.  Single-batch datasets (the ALS learner walks their
-    // whole transpose) are never split.
+    // ---- dense hot block (fmhip_tune keys 5, 12): features present in >= 10 % of the rows, the most frequent first, fill
+    // up to `max_pages` pages of kHotT slots; x_rh sits in xhot[page][r][slot].  Page 0's entries leave the sparse
+    // streams altogether; the entries of pages 1.. stay in the CSR stream (the forward walks them like any other entry)
+    // and leave only the transposes (fm_kernels.h, kHotPages).  A feature that occurs twice in a row, or is stored with
+    // an explicit zero, keeps the sparse path.  Single-batch datasets (the ALS learner walks their whole transpose) and
+    // row-blocked ones (gradient-side pages) are never split.
     const int64_t *orig_row_ptr = row_ptr;
     std::vector<int64_t> sp_ptr;
     std::unique_ptr<int32_t[]> sp_col_buf;
     std::unique_ptr<float[]> sp_val_buf, xhot_buf;
-    std::vector<uint32_t> hot_masks;
+    std::vector<uint64_t> hot_masks;
+    std::vector<int64_t> bwd_out;          // per batch: entries of the gradient-side pages (in the CSR, not in the CSC)
+    std::vector<uint32_t> drop_bits;       // bitmap over feature ids: the gradient-side pages' features
     bool split = false;
     if (want_hot && nb > 1 && nnz > 0 && !scoring) {
         // Frequencies: exact for datasets of up to 8 M nonzeros; beyond that from every s-th row (the
@@ -277,83 +283,107 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
                         for (int64_t f = lo; f < hi; ++f) cnt[(size_t)f] += pc[(size_t)f];
                 });
         }
+        // candidates in descending order of frequency (ties: ascending id): the first kHotT form page 0
         std::vector<int32_t> cand;
         for (int32_t f = 0; f <= dim; ++f)
             if ((int64_t)cnt[(size_t)f] * 10 >= sampled_rows) cand.push_back(f);
         std::sort(cand.begin(), cand.end(), [&](int32_t x, int32_t y) { return cnt[(size_t)x] != cnt[(size_t)y] ? cnt[(size_t)x] > cnt[(size_t)y] : x < y; });
-        if (cand.size() > (size_t)kHotT) cand.resize(kHotT);
+        const size_t max_slots = (size_t)kHotT * (size_t)(want_rb > 0 ? 1 : max_hot_pages);
         std::vector<int32_t>().swap(cnt);
         std::vector<int8_t> slot((size_t)dim + 1, -1);
         sp_ptr.assign((size_t)n_rows + 1, 0);
-        // pass 1 (one sweep): the sparse length of every row if the candidates leave the streams, and which
-        // candidates may not — one that occurs twice in a row, or is stored with an explicit zero, keeps the
-        // sparse path (its G row must have exactly one writer); if any is refused the sweep runs again without it
-        while (cand.size() >= 2) {
-            for (size_t h = 0; h < cand.size(); ++h) slot[(size_t)cand[h]] = (int8_t)h;
-            std::vector<uint32_t> badv((size_t)T, 0u);
+        // pass 1 (one sweep): the CSR length of every row if page 0 leaves the streams, and which candidates may not be
+        // dense — one that occurs twice in a row, or is stored with an explicit zero (its G row must have exactly one
+        // writer); if any is refused the sweep runs again without it (the ranking moves up)
+        size_t used = 0;       // the first `used` candidates are the ones being tried; the rest wait to move up
+        while ((used = std::min(cand.size(), max_slots)) >= 2) {
+            for (size_t h = 0; h < used; ++h) slot[(size_t)cand[h]] = (int8_t)h;
+            std::vector<uint64_t> badv((size_t)T, 0u);
             parallel_chunks(n_rows, T, [&](int t, int64_t lo, int64_t hi) {
-                uint32_t bad = 0;
+                uint64_t bad = 0;
                 for (int64_t r = lo; r < hi; ++r) {
-                    uint32_t seen = 0;
+                    uint64_t seen = 0;
                     int64_t keep = 0;
                     for (int64_t p = row_ptr[r]; p < row_ptr[r + 1]; ++p) {
                         const int8_t h = slot[(size_t)col[p]];
-                        if (h < 0) { ++keep; continue; }
-                        if ((seen >> h & 1u) || (float)val[p] == 0.f) bad |= 1u << h;
-                        seen |= 1u << h;
+                        if (h < 0 || h >= kHotT) ++keep;
+                        if (h < 0) continue;
+                        if ((seen >> h & 1u) || (float)val[p] == 0.f) bad |= (uint64_t)1 << h;
+                        seen |= (uint64_t)1 << h;
                     }
                     sp_ptr[(size_t)r + 1] = keep;
                 }
                 badv[(size_t)t] = bad;
             });
-            uint32_t bad = 0;
-            for (uint32_t x : badv) bad |= x;
+            uint64_t bad = 0;
+            for (uint64_t x : badv) bad |= x;
             if (!bad) break;
             std::vector<int32_t> ok;
             for (size_t h = 0; h < cand.size(); ++h) {
-                slot[(size_t)cand[h]] = -1;
-                if (!(bad >> h & 1u)) ok.push_back(cand[h]);
+                if (h < used) slot[(size_t)cand[h]] = -1;
+                if (h >= used || !(bad >> h & 1u)) ok.push_back(cand[h]);
             }
             cand.swap(ok);
         }
+        cand.resize(used >= 2 ? used : 0);
         if (cand.size() >= 2) {
-            // slots in ascending feature order (the sweep above does not depend on the numbering)
-            std::sort(cand.begin(), cand.end());
-            d->hot_ids.assign(kHotT, -1);
-            for (size_t h = 0; h < cand.size(); ++h) { d->hot_ids[h] = cand[h]; slot[(size_t)cand[h]] = (int8_t)h; }
+            // slots in ascending feature order inside every page (the sweep above does not depend on the numbering)
+            const int pages = (int)((cand.size() + kHotT - 1) / kHotT);
+            d->hot_ids.assign((size_t)(pages * kHotT), -1);
+            for (int pg = 0; pg < pages; ++pg) {
+                const size_t lo = (size_t)pg * kHotT, hi = std::min(cand.size(), lo + kHotT);
+                std::sort(cand.begin() + (std::ptrdiff_t)lo, cand.begin() + (std::ptrdiff_t)hi);
+                for (size_t h = lo; h < hi; ++h) { d->hot_ids[h] = cand[h]; slot[(size_t)cand[h]] = (int8_t)h; }
+            }
+            if (pages > 1) {
+                drop_bits.assign((size_t)(dim + 1) / 32 + 2, 0u);
+                for (size_t h = kHotT; h < cand.size(); ++h) drop_bits[(size_t)cand[h] >> 5] |= 1u << (cand[h] & 31);
+            }
             hot_masks.assign((size_t)nb, 0u);
+            bwd_out.assign((size_t)nb, 0);
             for (int64_t r = 0; r < n_rows; ++r) sp_ptr[(size_t)r + 1] += sp_ptr[(size_t)r];
             // pass 2: fill (buffers left uninitialised: every element is written exactly once)
+            const size_t page_floats = (size_t)std::max<int64_t>(n_rows, 1) * kHotT;
             sp_col_buf.reset(new int32_t[(size_t)std::max<int64_t>(sp_ptr[(size_t)n_rows], 1)]);
             sp_val_buf.reset(new float[(size_t)std::max<int64_t>(sp_ptr[(size_t)n_rows], 1)]);
-            xhot_buf.reset(new float[(size_t)std::max<int64_t>(n_rows, 1) * kHotT]);
+            xhot_buf.reset(new float[page_floats * (size_t)pages]);
             int32_t *sp_col = sp_col_buf.get();
             float *sp_val = sp_val_buf.get(), *xhot = xhot_buf.get();
-            std::vector<std::vector<uint32_t>> tmask((size_t)T, std::vector<uint32_t>((size_t)nb, 0u));
+            std::vector<std::vector<uint64_t>> tmask((size_t)T, std::vector<uint64_t>((size_t)nb, 0u));
+            std::vector<std::vector<int64_t>> tout((size_t)T, std::vector<int64_t>((size_t)nb, 0));
             parallel_chunks(n_rows, T, [&](int t, int64_t lo, int64_t hi) {
                 for (int64_t r = lo; r < hi; ++r) {
-                    uint32_t seen = 0;
-                    int64_t o = sp_ptr[(size_t)r];
-                    float *xr = xhot + (size_t)r * kHotT;
-                    for (int h = 0; h < kHotT; ++h) xr[h] = 0.f;
+                    uint64_t seen = 0;
+                    int64_t o = sp_ptr[(size_t)r], outb = 0;
+                    for (int pg = 0; pg < pages; ++pg) {
+                        float *xr = xhot + (size_t)pg * page_floats + (size_t)r * kHotT;
+                        for (int h = 0; h < kHotT; ++h) xr[h] = 0.f;
+                    }
                     for (int64_t p = row_ptr[r]; p < row_ptr[r + 1]; ++p) {
                         const int8_t h = slot[(size_t)col[p]];
                         if (h >= 0) {
-                            seen |= 1u << h;
-                            xr[h] = (float)val[p];
-                        } else {
+                            seen |= (uint64_t)1 << h;
+                            xhot[(size_t)(h / kHotT) * page_floats + (size_t)r * kHotT + (h % kHotT)] = (float)val[p];
+                        }
+                        if (h < 0 || h >= kHotT) {
                             sp_col[(size_t)o] = col[p];
                             sp_val[(size_t)o] = (float)val[p];
                             ++o;
+                            if (h >= 0) ++outb;
                         }
                     }
                     tmask[(size_t)t][(size_t)(r / batch_rows)] |= seen;
+                    tout[(size_t)t][(size_t)(r / batch_rows)] += outb;
                 }
             });
-            for (const auto &tm : tmask)
-                for (int64_t b = 0; b < nb; ++b) hot_masks[(size_t)b] |= tm[(size_t)b];
+            for (int t = 0; t < T; ++t)
+                for (int64_t b = 0; b < nb; ++b) {
+                    hot_masks[(size_t)b] |= tmask[(size_t)t][(size_t)b];
+                    bwd_out[(size_t)b] += tout[(size_t)t][(size_t)b];
+                }
             split = true;
             d->hot_T = kHotT;
+            d->hot_pages = pages;
         }
     }
     pt.lap("hot block: choose + split");
@@ -372,12 +402,14 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
         bm.nnz_total = orig_row_ptr[bm.row0 + bm.rows] - orig_row_ptr[bm.row0];
         bm.hot_mask = split ? hot_masks[(size_t)b] : 0u;
         const int64_t bn = row_ptr[bm.row0 + bm.rows] - bm.nnz0;
+        d->nnz_sparse_bwd += bn - (split ? bwd_out[(size_t)b] : 0);
         if (bn > (int64_t)0x7fffffff - 2 * kRangeLen || bm.rows > 0x7fffffff) {
             delete d;
             return fail(FMHIP_ERR_UNSUPPORTED, "batch %lld holds %lld nonzeros; the per-batch limit is 2^31", (long long)b,
                         (long long)bn);
         }
         bm.nnz = (int32_t)bn;
+        bm.cnnz = (int32_t)(bn - (split ? bwd_out[(size_t)b] : 0));
         d->max_rows = std::max(d->max_rows, bm.rows);
     }
     // forward walk order of each batch: rows by (sparse) length, longest first, ties in row order
@@ -426,7 +458,8 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     if ((rc = upload(d->row_ptr, row_ptr, (size_t)n_rows + 1)) || (rc = upload(d->col, col, (size_t)nnz_s)) ||
         (rc = upload(d->val, val_up, (size_t)nnz_s)) || (rc = upload(d->y, yf.data(), (size_t)n_rows)) ||
         (!scoring && ((rc = d->crow.alloc((size_t)nnz_s)) || (rc = d->cval.alloc((size_t)nnz_s)))) ||
-        (split && ((rc = upload(d->xhot, xhot_buf.get(), (size_t)n_rows * kHotT)) || (rc = upload(d->d_hot_ids, d->hot_ids.data(), d->hot_ids.size()))))) {
+        (split && ((rc = upload(d->xhot, xhot_buf.get(), (size_t)std::max<int64_t>(n_rows, 1) * kHotT * (size_t)d->hot_pages)) ||
+                   (rc = upload(d->d_hot_ids, d->hot_ids.data(), d->hot_ids.size()))))) {
         delete d;
         return rc;
     }
@@ -477,8 +510,16 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
         int32_t max_nnz = 0;
         for (const BatchMeta &bm : d->batches) max_nnz = std::max(max_nnz, bm.nnz);
         const size_t max_cols = (size_t)max_nnz;   // row-blocked streams repeat a feature once per block
+        // gradient-side hot pages: their entries are keyed dim + 1 and sort behind every real column
+        const bool drop = !drop_bits.empty();
+        const int32_t drop_key = dim + 1;
+        DevBuf<uint32_t> d_drop;
+        if (drop && (rc = upload(d_drop, drop_bits.data(), drop_bits.size()))) {
+            delete d;
+            return rc;
+        }
         int key_bits = 1;
-        while (key_bits < 31 && ((int64_t)1 << key_bits) <= (int64_t)dim) ++key_bits;
+        while (key_bits < 31 && ((int64_t)1 << key_bits) <= (int64_t)dim + (drop ? 1 : 0)) ++key_bits;
         // optional row blocking of the transposes (fmhip_tune key 3): entries sorted by (row block,
         // feature) so that a block's slice of P stays L2-resident while its columns are walked
         int64_t rb_rows = want_rb;
@@ -514,7 +555,8 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
             const BatchMeta &bm = d->batches[(size_t)b];
             HostBatch &hb = hbs[(size_t)b];
             he = csc_build_batch(nullptr, sc, d->row_ptr.p, d->col.p, d->val.p, keep64 ? d->val64.p : nullptr, bm.row0, bm.rows,
-                                 bm.nnz0, bm.nnz, key_bits, rb_div, rb_bits, d->crow.p, d->cval.p, keep64 ? d->cval64.p : nullptr);
+                                 bm.nnz0, bm.nnz, key_bits, rb_div, rb_bits, d->crow.p, d->cval.p, keep64 ? d->cval64.p : nullptr,
+                                 drop ? d_drop.p : nullptr, drop_key);
             int32_t nc = 0;
             if (he == hipSuccess) he = hipMemcpy(&nc, sc.count, sizeof nc, hipMemcpyDeviceToHost);
             if (he == hipSuccess) {
@@ -525,12 +567,22 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
                     if (he == hipSuccess) he = hipMemcpy(hb.cptr.data(), sc.starts, (size_t)nc * sizeof(int32_t), hipMemcpyDeviceToHost);
                 }
                 hb.cptr[(size_t)nc] = bm.nnz;
+                if (he == hipSuccess && drop && nc > 0 && hb.cfeat[(size_t)nc - 1] == drop_key) {
+                    // the pseudo-column of the dropped entries: the stream ends where it starts
+                    hb.cfeat.pop_back();
+                    hb.cptr.pop_back();
+                }
+                if (he == hipSuccess && hb.cptr.back() != bm.cnnz) {
+                    delete d;
+                    return fail(FMHIP_ERR_HIP, "batch %lld: the transpose holds %d entries, the host counted %d", (long long)b,
+                                hb.cptr.back(), bm.cnnz);
+                }
             }
             if (he != hipSuccess) {
                 delete d;
                 return fail(FMHIP_ERR_HIP, "device transpose of batch %lld failed: %s", (long long)b, hipGetErrorString(he));
             }
-            finish_batch_meta(hb, bm.nnz, cnt, base);
+            finish_batch_meta(hb, bm.cnnz, cnt, base);
         }
     }
     pt.lap("device transposes + metadata");
@@ -627,7 +679,7 @@ int ensure_workspace(fmhip_model_t m, fmhip_dataset_t d) {
     TRY(m->part.ensure((size_t)std::max<int32_t>(d->max_ranges, 1) * 2 * (m->Kp + kPartPad)));
     TRY(m->pieces.ensure((size_t)std::max<int32_t>(d->max_pieces, 1) * (m->Kp + kPartPad)));
     TRY(m->bsum.ensure((size_t)kMaxFwdBlocks * 4));
-    if (d->hot_T) TRY(m->hot_part.ensure((size_t)hot_blocks(m->Kp, d->max_rows) * kHotT * (m->Kp + kPartPad)));
+    if (d->hot_T) TRY(m->hot_part.ensure((size_t)hot_blocks(m->Kp, d->max_rows) * d->hot_pages * kHotT * (m->Kp + kPartPad)));
     return FMHIP_OK;
 }
 
@@ -688,7 +740,7 @@ BwdArgs bwd_args(fmhip_model_t m, fmhip_dataset_t d, int64_t b) {
     a.split_seg = d->split_seg.p + bm.split_off;
     a.split_short = d->split_short.p + bm.split_short_off;
     a.n_split_short = bm.n_split_short;
-    a.nnz = bm.nnz;
+    a.nnz = bm.cnnz;
     a.n_ranges = bm.n_ranges;
     a.rho_lo = 0;
     a.rho_hi = bm.n_ranges;
@@ -736,6 +788,8 @@ void hot_attach(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm, BwdArgs
     h.P = m->P.p;
     h.e = m->e.p;
     h.xhot = d->xhot.p + (size_t)bm.row0 * kHotT;
+    h.page_stride = std::max<int64_t>(d->n_rows, 1) * kHotT;
+    h.pages = d->hot_pages;
     h.hot_ids = d->d_hot_ids.p;
     h.part = m->hot_part.p;
     h.GV = m->GV();
@@ -877,7 +931,7 @@ bool plan_fused(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double eta, doubl
     }
     // merged finish (key 11): when the step's update is the DENSE pass (the batch touches most of the model, or decay
     // cannot ride in the scale) it runs inside the fixup launch, beside the fixups, instead of as a launch of its own
-    const int64_t touched = (int64_t)bm0.n_cols + (d->hot_T ? kHotT : 0);
+    const int64_t touched = (int64_t)bm0.n_cols + d->hot_pages * kHotT;
     const bool rows_only = lazy_ok && touched * 2 <= m->n1;
     if (g_tune[kTuneMerged] && !g_tune[kTuneFused] && d->rb_rows == 0 && !rows_only && bm0.own_off >= 0 && d->dimension <= m->n) {
         p->mode = 2;
@@ -929,12 +983,12 @@ int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double reg
     const bool decay = regw != 0.0 || regv != 0.0;
     if (d && b >= 0 && d->rb_rows == 0 && (!decay || (g_tune[kTuneLazy] && dv >= 0.5 && dw >= 0.5 && dv <= 1.0 && dw <= 1.0))) {
         const BatchMeta &bm = d->batches[(size_t)b];
-        const int64_t touched = (int64_t)bm.n_cols + (d->hot_T ? kHotT : 0);
+        const int64_t touched = (int64_t)bm.n_cols + d->hot_pages * kHotT;
         if (touched * 2 <= m->n1) {     // otherwise the dense, perfectly coalesced pass is as cheap
             a.feat = d->cfeat.p + bm.col_off;
             a.n_feat = bm.n_cols;
             a.hot_ids = d->d_hot_ids.p;
-            a.n_hot = d->hot_T ? kHotT : 0;
+            a.n_hot = d->hot_pages * kHotT;
             sv_out = m->sv * dv;
             sw_out = m->sw * dw;
         }
@@ -1281,7 +1335,7 @@ int fmhip_dataset_batch_info(fmhip_dataset_t d, int64_t batch, int64_t *row0, in
     if (row0) *row0 = bm.row0;
     if (rows) *rows = bm.rows;
     if (nnz) *nnz = bm.nnz_total;
-    if (n_columns) *n_columns = bm.n_feats + __builtin_popcount(bm.hot_mask);
+    if (n_columns) *n_columns = bm.n_feats + __builtin_popcountll(bm.hot_mask);
     return FMHIP_OK;
 }
 
@@ -1294,35 +1348,43 @@ int fmhip_dataset_get_transpose(fmhip_dataset_t d, int64_t batch, int32_t *feat,
     const BatchMeta &bm = d->batches[(size_t)batch];
     // read the stream back and merge the pieces of a feature (one per row block, in row-block = row
     // order) so the caller sees one column per feature whatever the device layout
-    std::vector<int32_t> hrow((size_t)bm.nnz);
-    std::vector<float> hval((size_t)bm.nnz);
-    if (bm.nnz) {
-        HIP_TRY(hipMemcpy(hrow.data(), d->crow.p + bm.nnz0, (size_t)bm.nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(hval.data(), d->cval.p + bm.nnz0, (size_t)bm.nnz * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<int32_t> hrow((size_t)bm.cnnz);
+    std::vector<float> hval((size_t)bm.cnnz);
+    if (bm.cnnz) {
+        HIP_TRY(hipMemcpy(hrow.data(), d->crow.p + bm.nnz0, (size_t)bm.cnnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hval.data(), d->cval.p + bm.nnz0, (size_t)bm.cnnz * sizeof(float), hipMemcpyDeviceToHost));
     }
     const int32_t *hf = d->h_cfeat.data() + bm.col_off, *hp = d->h_cptr.data() + bm.col_off + batch;
     std::vector<int32_t> order((size_t)bm.n_cols);
     for (int32_t s = 0; s < bm.n_cols; ++s) order[(size_t)s] = s;
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return hf[x] < hf[y]; });
-    // the dense hot block's columns (never present in the sparse stream) are merged in by feature id
+    // the dense hot block's columns (never present in the transposed stream) are merged in by feature id
+    const int n_slots = d->hot_pages * kHotT;
+    const size_t page_floats = (size_t)std::max<int64_t>(d->n_rows, 1) * kHotT;
     std::vector<float> hx;
+    std::vector<int> hslots;               // the batch's live slots, by ascending feature id
     if (bm.hot_mask) {
-        hx.resize((size_t)bm.rows * kHotT);
-        HIP_TRY(hipMemcpy(hx.data(), d->xhot.p + (size_t)bm.row0 * kHotT, hx.size() * sizeof(float), hipMemcpyDeviceToHost));
+        hx.resize((size_t)bm.rows * n_slots);
+        for (int pg = 0; pg < d->hot_pages; ++pg)
+            HIP_TRY(hipMemcpy(hx.data() + (size_t)pg * bm.rows * kHotT, d->xhot.p + (size_t)pg * page_floats + (size_t)bm.row0 * kHotT,
+                              (size_t)bm.rows * kHotT * sizeof(float), hipMemcpyDeviceToHost));
+        for (int h = 0; h < n_slots; ++h)
+            if (d->hot_ids[(size_t)h] >= 0 && (bm.hot_mask >> h & 1u)) hslots.push_back(h);
+        std::sort(hslots.begin(), hslots.end(), [&](int x, int y) { return d->hot_ids[(size_t)x] < d->hot_ids[(size_t)y]; });
     }
     int32_t nf = 0, pos = 0;
-    int hnext = 0;
+    size_t hnext = 0;
     auto emit_hot_below = [&](int64_t bound) {
-        for (; hnext < kHotT; ++hnext) {
-            if (!bm.hot_mask) { hnext = kHotT; break; }
-            const int32_t id = d->hot_ids[(size_t)hnext];
-            if (id < 0 || !(bm.hot_mask >> hnext & 1u)) continue;
+        for (; hnext < hslots.size(); ++hnext) {
+            const int h = hslots[hnext];
+            const int32_t id = d->hot_ids[(size_t)h];
             if ((int64_t)id >= bound) break;
             if (feat) feat[nf] = id;
             if (ptr) ptr[nf] = pos;
             ++nf;
+            const float *xp = hx.data() + (size_t)(h / kHotT) * bm.rows * kHotT + (h % kHotT);
             for (int64_t r = 0; r < bm.rows; ++r) {
-                const float x = hx[(size_t)r * kHotT + hnext];
+                const float x = xp[(size_t)r * kHotT];
                 if (x != 0.f) {
                     if (rows) rows[pos] = (int32_t)r;
                     if (vals) vals[pos] = x;
@@ -1646,13 +1708,27 @@ int fmhip_step_stats(fmhip_model_t m, fmhip_stats *stats) {
 int fmhip_dataset_layout(fmhip_dataset_t d, int32_t *n_hot, int32_t *hot_ids, int64_t *nnz_sparse) {
     if (!d) return fail(FMHIP_ERR_INVALID, "dataset is NULL");
     int32_t n = 0;
-    for (int h = 0; h < (int)d->hot_ids.size(); ++h)
+    for (int h = 0; h < (int)std::min<size_t>(d->hot_ids.size(), kHotT); ++h)      // page 0: the two-sided page
         if (d->hot_ids[(size_t)h] >= 0) {
             if (hot_ids) hot_ids[n] = d->hot_ids[(size_t)h];
             ++n;
         }
     if (n_hot) *n_hot = n;
     if (nnz_sparse) *nnz_sparse = d->nnz_sparse;
+    return FMHIP_OK;
+}
+
+int fmhip_dataset_hot_pages(fmhip_dataset_t d, int32_t *n_pages, int32_t *n_ids, int32_t *ids, int64_t *nnz_sparse_backward) {
+    if (!d) return fail(FMHIP_ERR_INVALID, "dataset is NULL");
+    int32_t n = 0;
+    for (size_t h = 0; h < d->hot_ids.size(); ++h)
+        if (d->hot_ids[h] >= 0) {
+            if (ids) ids[n] = d->hot_ids[h];
+            ++n;
+        }
+    if (n_pages) *n_pages = d->hot_pages;
+    if (n_ids) *n_ids = n;
+    if (nnz_sparse_backward) *nnz_sparse_backward = d->scoring_only ? 0 : d->nnz_sparse_bwd;
     return FMHIP_OK;
 }
 

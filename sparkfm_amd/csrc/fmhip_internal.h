@@ -59,7 +59,8 @@ constexpr int64_t kAlsMaxNnz = (int64_t)1 << 27;
 struct BatchMeta {
     int64_t row0 = 0, rows = 0;
     int64_t nnz0 = 0;   // offset of the batch in the global CSR/CSC entry arrays
-    int32_t nnz = 0;
+    int32_t nnz = 0;        // entries of the batch in the CSR stream (what the forward walks)
+    int32_t cnnz = 0;       // ... in the CSC stream (<= nnz: the gradient-side hot pages' entries are not in it)
     int32_t n_cols = 0;     // compressed columns (features present in the batch)
     int64_t col_off = 0;    // offset into cfeat; cptr offset is col_off + batch index
     int32_t n_ranges = 0;
@@ -73,7 +74,7 @@ struct BatchMeta {
     int64_t mp_off = 0;     // offset into mp_feat; mp_ptr offset is mp_off + batch index
     int32_t n_pieces = 0;   // piece rows those features need
     int64_t nnz_total = 0;  // stored nonzeros of the batch incl. those held in the dense hot block
-    uint32_t hot_mask = 0;  // hot slots with at least one nonzero in this batch
+    uint64_t hot_mask = 0;  // hot slots (all pages) with at least one nonzero in this batch
     int64_t own_off = -1;   // offset (in words) of the batch's bitmap of fixup-owned features, -1 = none
 };
 
@@ -108,13 +109,16 @@ struct fmhip_dataset {
     std::vector<int32_t> h_cfeat, h_cptr, h_split, h_split_short;   // host copies (feature-chunked backward needs them)
     int64_t rb_rows = 0;       // rows per row block of the transposes (0 = not row-blocked)
     int32_t max_pieces = 0;
-    // dense hot block: the entries of the (up to kHotT) most frequent features are held as a dense
-    // [n_rows][kHotT] fp32 array instead of in the sparse streams (0 where the feature is absent)
+    // dense hot block: the entries of the most frequent features are held as dense [n_rows][kHotT] fp32 pages
+    // (0 where the feature is absent).  Page 0 (up to kHotT features) is out of both sparse streams; pages 1.. are out
+    // of the CSC stream only (fm_kernels.h, kHotPages)
     int32_t hot_T = 0;                 // 0 = no hot block
-    std::vector<int32_t> hot_ids;      // [kHotT] feature id per slot, -1 = unused slot
-    DevBuf<float> xhot;
+    int32_t hot_pages = 0;             // pages in use (0 = no hot block)
+    std::vector<int32_t> hot_ids;      // [hot_pages * kHotT] feature id per slot, -1 = unused slot
+    DevBuf<float> xhot;                // [hot_pages][n_rows][kHotT]
     DevBuf<int32_t> d_hot_ids;
-    int64_t nnz_sparse = 0;
+    int64_t nnz_sparse = 0;            // entries of the CSR stream
+    int64_t nnz_sparse_bwd = 0;        // entries of the CSC streams
     bool scoring_only = false;   // rows + labels only (fmhip_rows_create): no transposes, cannot train
     // fp64 copies of the values (CSR order, CSC order) and labels for the fp64 ALS learner; kept only
     // for single-batch datasets of at most kAlsMaxNnz stored nonzeros

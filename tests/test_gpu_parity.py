@@ -225,14 +225,17 @@ def hot_problem(seed, n_rows, n1, k, n_hot, dup_feature=None, zero_feature=None)
                 col=np.concatenate(rows), val=np.concatenate(vals), y=rng.normal(0, 1, n_rows)), hot_ids
 
 
-@pytest.mark.parametrize("k,n_hot,dup,zero", [(32, 16, None, None), (32, 20, None, None), (16, 5, None, None),
-                                                (64, 9, 2, None), (100, 16, None, 3), (8, 12, 0, 1)])
+@pytest.mark.parametrize("k,n_hot,dup,zero,pages", [(32, 16, None, None, 3), (32, 20, None, None, 3), (32, 20, None, None, 1),
+                                                      (16, 5, None, None, 3), (64, 9, 2, None, 3), (100, 16, None, 3, 3),
+                                                      (8, 12, 0, 1, 3), (32, 48, None, None, 3), (32, 41, 20, 30, 2),
+                                                      (64, 45, 3, None, 3), (16, 35, None, 1, 3), (100, 40, 25, None, 3)])
 @pytest.mark.parametrize("flat", [0, 1])
-def test_dense_hot_block(fmhip, request, k, n_hot, dup, zero, flat):
-    """fmhip_tune(5, 1): the most frequent features (>= 10 % of the rows, at most 16, none that occurs
-    twice in a row or with a stored zero) leave the sparse streams for a dense [rows][16] block.
-    Forward, gradient, transposes, epochs and the feature-chunked backward must not notice.
-    flat=1: the same on the flat-address kernels (fmhip_tune key 8)."""
+def test_dense_hot_block(fmhip, request, k, n_hot, dup, zero, pages, flat):
+    """fmhip_tune(5, 1): the most frequent features (>= 10 % of the rows, none that occurs twice in a row or with a stored
+    zero) are held in dense [rows][16] pages: the 16 most frequent leave the sparse streams on both sides, up to 32 more
+    (fmhip_tune key 12 = pages) leave the transposes only and get their gradient rows from the same MFMA block product.
+    Forward, gradient, transposes, epochs and the feature-chunked backward must not notice.  k = 100 (Kp = 128) takes the
+    pages one pass over P each.  flat=1: the same on the flat-address kernels (fmhip_tune key 8)."""
     from sparkfm_amd import _ffi
     L = _ffi.load()
     L.fmhip_tune(8, flat)
@@ -242,9 +245,18 @@ def test_dense_hot_block(fmhip, request, k, n_hot, dup, zero, flat):
     n_rows, br = 3000, 700
     try:
         L.fmhip_tune(5, 1)
+        L.fmhip_tune(12, pages)
         ds, fm = make(fmhip, a, batch_rows=br)
     finally:
         L.fmhip_tune(5, 1)
+        L.fmhip_tune(12, 3)
+    lay = ds.layout()
+    refused = {int(hot_ids[i]) for i in (dup, zero) if i is not None}
+    dense = set(lay["hot_ids_all"])
+    assert dense <= {int(x) for x in hot_ids} - refused and set(lay["hot_ids"]) <= dense
+    assert len(dense) == min(n_hot - len(refused), 16 * pages) and lay["hot_pages"] == (len(dense) + 15) // 16
+    assert lay["nnz_sparse_backward"] == int((~np.isin(a["col"], sorted(dense))).sum())
+    assert lay["nnz_sparse"] == int((~np.isin(a["col"], lay["hot_ids"])).sum())
     # scoring
     yh = fm.predict(ds)
     oy = oracle.predict(a["w0"], a["w"], a["v"], a["row_ptr"], a["col"], a["val"])
