@@ -50,13 +50,17 @@ def alg_bytes(k):
     return {"forward": 4 * k + 12, "backward": 4 * k + 4, "step": 8 * k + 16}
 
 
-def requested_bytes(kp, rows, nnz, nnz_sparse, n_cols, hot, touched_rows, dense_apply, n1p, packed):
+def requested_bytes(kp, rows, nnz, nnz_sparse, n_cols, hot, touched_rows, dense_apply, n1p, packed, nnz_sparse_bwd=None, hot_pages=1):
     """Bytes each kernel of one step actually ASKS the memory system for (our own count of its loads and
-    stores, whatever level serves them), and the table its gathers hit."""
+    stores, whatever level serves them), and the table its gathers hit.  nnz_sparse / nnz_sparse_bwd: the entries
+    of the batch in the CSR stream (forward) / in the transposed stream (backward: fewer, the gradient-side pages
+    of the dense hot block are not in it); the block product streams P once and 64 B per row and page."""
     row = 4 * kp
     hot_b = 64 * rows if hot else 0
+    if nnz_sparse_bwd is None:
+        nnz_sparse_bwd = nnz_sparse
     fwd = nnz_sparse * (8 + row + (0 if packed else 4)) + rows * (8 + 4 + row + 4) + hot_b
-    bwd = nnz_sparse * (8 + row + (0 if packed else 4)) + n_cols * (row + 8) + (rows * row + hot_b if hot else 0)
+    bwd = nnz_sparse_bwd * (8 + row + (0 if packed else 4)) + n_cols * (row + 8) + (rows * row + hot_b * max(hot_pages, 1) if hot else 0)
     apply_rows = n1p if dense_apply else touched_rows
     app = apply_rows * (3 * row + 16)          # V read+write, G read (+ zero store counted with the write)
     return {"forward": fwd, "backward": bwd, "apply": app}
@@ -249,9 +253,10 @@ def hbm_resident_leg(device, steps=24, rows=500_000, batch_rows=250_000):
     ab = alg_bytes(k)
     lay = ds.layout()
     bi = ds.batch_info(0)
-    share = lay["nnz_sparse"] / max(int(d["row_ptr"][-1]), 1)          # what stayed in the sparse streams
+    share = lay["nnz_sparse"] / max(int(d["row_ptr"][-1]), 1)          # what stayed in the sparse streams (forward)
+    share_b = lay["nnz_sparse_backward"] / max(int(d["row_ptr"][-1]), 1)  # ... in the transposes (backward)
     req = requested_bytes(64, bi["rows"], bi["nnz"], int(bi["nnz"] * share), bi["n_columns"], bool(lay["hot_ids"]),
-                          bi["n_columns"], False, n1, False)
+                          bi["n_columns"], False, n1, False, int(bi["nnz"] * share_b), lay["hot_pages"])
     pmc = committed_pmc("C5hbm", k, batch_rows)
     kern = kernel_table(prof, k, 64, req, pmc, {"forward": n1 * 64 * 4, "backward": bi["rows"] * 64 * 4})
     step_req = sum(e.get("requested_bytes_per_launch", 0) for e in kern.values())
@@ -260,7 +265,8 @@ def hbm_resident_leg(device, steps=24, rows=500_000, batch_rows=250_000):
     out = {"workload": "C5 width on one GPU: %d Criteo-shaped rows x 2^25 hashed slots (relabelled by frequency at load), k=64 "
                        "(V = %.1f GB), batch %d rows, eta 0.02, regw = regv = 1e-4 (lazy rows-only update)" % (rows, n1 * k * 4 / 1e9, batch_rows),
            "value": value, "unit": "nnz/s", "ms_per_step": step_ms, "steps": steps,
-           "hot_block_features": len(lay["hot_ids"]), "share_of_nonzeros_in_sparse_streams": share,
+           "hot_block_features": len(lay["hot_ids"]), "hot_block_features_gradient_side": len(lay["hot_ids_all"]),
+           "share_of_nonzeros_in_sparse_streams": share, "share_of_nonzeros_in_transposes": share_b,
            "alg_bytes_per_nnz": ab["step"], "alg_GBps": value * ab["step"] / 1e9,
            "requested_bytes_per_step": step_req, "requested_GBps": step_req / (step_ms * 1e-3) / 1e9,
            "fabric_traffic_bytes_per_step_from_committed_profile": fabric,
@@ -597,8 +603,9 @@ def main():
         n_cols = bi["n_columns"]
         nnz0, rows0 = bi["nnz"], bi["rows"]
         nnz0_sparse = int(round(nnz0 * lay["nnz_sparse"] / max(int(d["row_ptr"][-1]), 1)))   # batch 0's share of the sparse streams
+        nnz0_sparse_b = int(round(nnz0 * lay["nnz_sparse_backward"] / max(int(d["row_ptr"][-1]), 1)))   # ... of the transposes
         dense_apply = use_dp or n_cols * 2 > n1
-        req = requested_bytes(kp, rows0, nnz0, nnz0_sparse, n_cols, hot, n_cols, dense_apply, n1, packed)
+        req = requested_bytes(kp, rows0, nnz0, nnz0_sparse, n_cols, hot, n_cols, dense_apply, n1, packed, nnz0_sparse_b, lay["hot_pages"])
         table_bytes = {"forward": n1 * kp * 4, "backward": rows0 * kp * 4}
         kern = kernel_table(prof, k, kp, req, pmc, table_bytes)
         dom = max(("forward", "backward"), key=lambda n: prof.as_dict()[n]["ms"])
@@ -619,6 +626,10 @@ def main():
                                     "nnz/row U{%d..%d}, ids Zipf(%.2f)" % (cfg["nnz_lo"], cfg["nnz_hi"], cfg["zipf_s"])),
                        "rows_per_gpu": rows, "features": n1, "k": k, "batch_rows_per_gpu": batch_rows,
                        "batches_per_gpu": nb, "nnz_per_gpu": int(d["row_ptr"][-1]), "eta": args.eta, "regs": regs,
+                       "dense_hot_block": {"pages": lay["hot_pages"], "features_forward_and_backward": len(lay["hot_ids"]),
+                                           "features_backward": len(lay["hot_ids_all"]),
+                                           "share_of_nonzeros_left_to_the_forward": lay["nnz_sparse"] / max(int(d["row_ptr"][-1]), 1),
+                                           "share_of_nonzeros_left_to_the_backward": lay["nnz_sparse_backward"] / max(int(d["row_ptr"][-1]), 1)},
                        "parallelism": "dp%d" % world, "exchange": exchange,
                        "allreduce": ("inside the library (RCCL), overlapped with the feature-chunked backward, cuts at features %s" % dp.cuts
                                      if exchange == "rccl" and dp.cuts else

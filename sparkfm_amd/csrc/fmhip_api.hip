@@ -283,21 +283,27 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
                         for (int64_t f = lo; f < hi; ++f) cnt[(size_t)f] += pc[(size_t)f];
                 });
         }
-        // candidates in descending order of frequency (ties: ascending id): the first kHotT form page 0
+        // candidates in descending order of frequency (ties: ascending id).  Page 0 is dense for the forward too, where a
+        // slot costs every row a multiply-add chain: it takes features present in >= 10 % of the rows.  A gradient-side slot
+        // costs a row 4 streamed bytes and saves a P-row gather per entry: those pages take features down to 5 %.
         std::vector<int32_t> cand;
         for (int32_t f = 0; f <= dim; ++f)
-            if ((int64_t)cnt[(size_t)f] * 10 >= sampled_rows) cand.push_back(f);
+            if ((int64_t)cnt[(size_t)f] * 20 >= sampled_rows) cand.push_back(f);
         std::sort(cand.begin(), cand.end(), [&](int32_t x, int32_t y) { return cnt[(size_t)x] != cnt[(size_t)y] ? cnt[(size_t)x] > cnt[(size_t)y] : x < y; });
-        const size_t max_slots = (size_t)kHotT * (size_t)(want_rb > 0 ? 1 : max_hot_pages);
-        std::vector<int32_t>().swap(cnt);
+        const size_t max_rest = (size_t)kHotT * (size_t)((want_rb > 0 ? 1 : max_hot_pages) - 1);
         std::vector<int8_t> slot((size_t)dim + 1, -1);
         sp_ptr.assign((size_t)n_rows + 1, 0);
         // pass 1 (one sweep): the CSR length of every row if page 0 leaves the streams, and which candidates may not be
         // dense — one that occurs twice in a row, or is stored with an explicit zero (its G row must have exactly one
         // writer); if any is refused the sweep runs again without it (the ranking moves up)
-        size_t used = 0;       // the first `used` candidates are the ones being tried; the rest wait to move up
-        while ((used = std::min(cand.size(), max_slots)) >= 2) {
-            for (size_t h = 0; h < used; ++h) slot[(size_t)cand[h]] = (int8_t)h;
+        size_t used = 0, p0 = 0;   // candidates being tried: the first p0 in page 0 (slots 0..), the next ones in slots kHotT..
+        auto slot_of = [&](size_t j) { return (int8_t)(j < p0 ? j : kHotT + (j - p0)); };
+        for (;;) {
+            p0 = 0;
+            while (p0 < cand.size() && p0 < (size_t)kHotT && (int64_t)cnt[(size_t)cand[p0]] * 10 >= sampled_rows) ++p0;
+            used = p0 < 2 ? 0 : p0 + std::min(cand.size() - p0, max_rest);
+            if (!used) break;
+            for (size_t j = 0; j < used; ++j) slot[(size_t)cand[j]] = slot_of(j);
             std::vector<uint64_t> badv((size_t)T, 0u);
             parallel_chunks(n_rows, T, [&](int t, int64_t lo, int64_t hi) {
                 uint64_t bad = 0;
@@ -319,25 +325,32 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
             for (uint64_t x : badv) bad |= x;
             if (!bad) break;
             std::vector<int32_t> ok;
-            for (size_t h = 0; h < cand.size(); ++h) {
-                if (h < used) slot[(size_t)cand[h]] = -1;
-                if (h >= used || !(bad >> h & 1u)) ok.push_back(cand[h]);
+            for (size_t j = 0; j < cand.size(); ++j) {
+                if (j < used) slot[(size_t)cand[j]] = -1;
+                if (j >= used || !(bad >> slot_of(j) & 1u)) ok.push_back(cand[j]);
             }
             cand.swap(ok);
         }
-        cand.resize(used >= 2 ? used : 0);
-        if (cand.size() >= 2) {
+        std::vector<int32_t>().swap(cnt);
+        cand.resize(used);
+        if (used) {
             // slots in ascending feature order inside every page (the sweep above does not depend on the numbering)
-            const int pages = (int)((cand.size() + kHotT - 1) / kHotT);
+            const int pages = 1 + (int)((used - p0 + kHotT - 1) / kHotT);
             d->hot_ids.assign((size_t)(pages * kHotT), -1);
-            for (int pg = 0; pg < pages; ++pg) {
-                const size_t lo = (size_t)pg * kHotT, hi = std::min(cand.size(), lo + kHotT);
+            std::sort(cand.begin(), cand.begin() + (std::ptrdiff_t)p0);
+            for (size_t j = 0; j < p0; ++j) { d->hot_ids[j] = cand[j]; slot[(size_t)cand[j]] = (int8_t)j; }
+            for (size_t lo = p0; lo < used; lo += kHotT) {
+                const size_t hi = std::min(used, lo + kHotT);
                 std::sort(cand.begin() + (std::ptrdiff_t)lo, cand.begin() + (std::ptrdiff_t)hi);
-                for (size_t h = lo; h < hi; ++h) { d->hot_ids[h] = cand[h]; slot[(size_t)cand[h]] = (int8_t)h; }
+                for (size_t j = lo; j < hi; ++j) {
+                    const size_t h = kHotT + (j - p0);
+                    d->hot_ids[h] = cand[j];
+                    slot[(size_t)cand[j]] = (int8_t)h;
+                }
             }
             if (pages > 1) {
                 drop_bits.assign((size_t)(dim + 1) / 32 + 2, 0u);
-                for (size_t h = kHotT; h < cand.size(); ++h) drop_bits[(size_t)cand[h] >> 5] |= 1u << (cand[h] & 31);
+                for (size_t j = p0; j < used; ++j) drop_bits[(size_t)cand[j] >> 5] |= 1u << (cand[j] & 31);
             }
             hot_masks.assign((size_t)nb, 0u);
             bwd_out.assign((size_t)nb, 0);
@@ -384,6 +397,7 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
             split = true;
             d->hot_T = kHotT;
             d->hot_pages = pages;
+            for (int32_t f : d->hot_ids) d->hot_max_id = std::max(d->hot_max_id, (int64_t)f);
         }
     }
     pt.lap("hot block: choose + split");
@@ -817,8 +831,11 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
         if (fused->mode == 1) ba.upd = fused->upd;
         if (finish) { ba.red_w0 = m->w0.p; ba.red_eta = (float)fused->eta; ba.red_reg0 = (float)fused->reg0; }
     }
-    hot_attach(m, d, bm, ba);
     const bool whole = feat_lo <= 0 && feat_hi >= m->n1;
+    // the block product rides in the first call whose interval reaches down to the highest hot id (callers that cut the
+    // backward go from the top down: every hot row is complete before the interval holding it is exchanged, and the
+    // cold intervals in front — whose exchange the rest of the backward hides — are not held up by it)
+    if (whole || finish || d->hot_max_id >= feat_lo) hot_attach(m, d, bm, ba);
     if (d->rb_rows > 0 && !whole)
         return fail(FMHIP_ERR_UNSUPPORTED, "feature-interval backward is not available on a row-blocked dataset");
     if (whole) {   // the common case needs no host-side searches

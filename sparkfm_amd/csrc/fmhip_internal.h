@@ -114,6 +114,7 @@ struct fmhip_dataset {
     // of the CSC stream only (fm_kernels.h, kHotPages)
     int32_t hot_T = 0;                 // 0 = no hot block
     int32_t hot_pages = 0;             // pages in use (0 = no hot block)
+    int64_t hot_max_id = -1;           // the largest feature id held in any page
     std::vector<int32_t> hot_ids;      // [hot_pages * kHotT] feature id per slot, -1 = unused slot
     DevBuf<float> xhot;                // [hot_pages][n_rows][kHotT]
     DevBuf<int32_t> d_hot_ids;
