@@ -834,7 +834,7 @@ hipError_t launch_fixup2(int Kp, const BwdArgs &a, hipStream_t s) {
 int hot_blocks(int Kp, int64_t n_rows) {
     (void)Kp;
     int64_t b = (n_rows + 63) / 64;       // at least 16 rows per wave
-    if (b > 256) b = 256;                 // one hot workgroup per CU, next to the column walkers
+    if (b > 256) b = 256;                 // one hot workgroup per CU, next to the column walkers (128 / 512 / 1024: no better)
     return b < 1 ? 1 : (int)b;
 }
 

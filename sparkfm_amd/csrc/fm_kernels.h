@@ -20,8 +20,8 @@ constexpr int kHotT = 16;           // slots of one page of the dense hot block 
 // GRADIENT side only: their entries stay in the CSR stream the forward walks (a longer dense prologue costs the forward
 // its occupancy — profiles/r02_experiments.md §18) but leave the CSC stream, where every entry costs the backward a P-row
 // gather; the MFMA block product below forms their gradient rows in the same pass over P as page 0's.
-constexpr int kHotPages = 3;
-// pages the gradient-side block product can carry for a padded factor count (its accumulators: pages x Kp/16 x 4 VGPRs)
+constexpr int kHotPages = 4;
+// pages the gradient-side block product carries through one pass over P (its accumulators: pages x Kp/16 x 4 VGPRs)
 constexpr int hot_pages_max(int Kp) { return Kp <= 64 ? kHotPages : 1; }
 extern int g_tune[kTuneCount];
 

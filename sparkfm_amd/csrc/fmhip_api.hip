@@ -28,6 +28,7 @@ using namespace fmhip;
 #define FMHIP_FIN_BLOCKS 2048     // cap on the merged finish's update workgroups (beside ~2k fixup workgroups at C3)
 #endif
 
+static_assert(FMHIP_HOT_PAGES == kHotPages && kHotPages * kHotT <= 64, "header and kernels disagree on the hot pages (64-bit slot masks)");
 static_assert(FMHIP_RANGE_LEN == kRangeLen, "header and kernels disagree on the CSC range length");
 
 namespace fmhip {

@@ -115,7 +115,7 @@ class DataSet(Features):
                               _ffi.ptr(self.y), C.byref(h)))
             elif self.hot_block is not None or self.row_block_rows is not None:
                 # hot_block: None = library default, False = off, True = on (all pages), n = on with up to n pages
-                hb = -1 if self.hot_block is None else (3 if self.hot_block is True else int(self.hot_block))
+                hb = -1 if self.hot_block is None else (4 if self.hot_block is True else int(self.hot_block))
                 opts = _ffi.DatasetOpts(C.sizeof(_ffi.DatasetOpts), hb,
                                         self.batch_rows, -1 if self.row_block_rows is None else int(self.row_block_rows))
                 val64, y64 = self.val.astype(np.float64, copy=False), self.y.astype(np.float64, copy=False)
@@ -163,7 +163,7 @@ class DataSet(Features):
         """How the library laid the rows out: ids held in the dense hot block, nonzeros left in the sparse streams."""
         n, ids, sp = C.c_int32(), np.full(16, -1, np.int32), C.c_int64()
         _ffi.check(_ffi.load().fmhip_dataset_layout(self.handle, C.byref(n), _ffi.ptr(ids), C.byref(sp)))
-        pages, n_all, all_ids, spb = C.c_int32(), C.c_int32(), np.full(48, -1, np.int32), C.c_int64()
+        pages, n_all, all_ids, spb = C.c_int32(), C.c_int32(), np.full(64, -1, np.int32), C.c_int64()
         _ffi.check(_ffi.load().fmhip_dataset_hot_pages(self.handle, C.byref(pages), C.byref(n_all), _ffi.ptr(all_ids), C.byref(spb)))
         # hot_ids: the two-sided page; hot_ids_all: with the gradient-side pages; nnz_sparse(_backward): entries left in the
         # rows the forward walks / in the transposes the backward walks
