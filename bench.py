@@ -641,8 +641,11 @@ def main():
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this configuration; not measured in this run)",
                          "alg_bytes_per_nnz": ab[dom], "nnz_per_launch": pd[dom]["nnz"] / max(pd[dom]["launches"], 1),
                          "avg_launch_ms": kern[dom]["avg_ms"] if dom in kern else None,
-                         "note": "achieved = ALGORITHMIC bytes (SURVEY §8(d)) / launch time; at this size V, P and the gradient live in "
-                                 "L2 / Infinity Cache, so the binding ceiling is the gather rate of those levels: see kernels[*].ceiling",
+                         "note": "achieved = ALGORITHMIC bytes (SURVEY §8(d): 4k+4 B for EVERY stored nonzero of the batch) / launch time. "
+                                 "It is not an HBM rate and may pass the HBM peak: at this size V, P and the gradient live in L2 / Infinity "
+                                 "Cache, and the nonzeros of the dense hot block (config.dense_hot_block) cost one streamed value instead of a "
+                                 "gathered row.  The bytes the kernel really asks for and the ceiling that binds them: requested_GBps, ceiling, "
+                                 "frac_of_ceiling (<= 1)",
                          "requested_GBps": kern.get(dom, {}).get("requested_GBps"),
                          "ceiling": kern.get(dom, {}).get("ceiling"),
                          "frac_of_ceiling": kern.get(dom, {}).get("frac_of_ceiling")},
