@@ -34,6 +34,7 @@
  */
 #ifndef FMHIP_H
 #define FMHIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -275,6 +276,25 @@ int fmhip_comm_unique_id(void *id /* FMHIP_UNIQUE_ID_BYTES out */);
 int fmhip_comm_create(fmhip_model_t m, const void *id, int rank, int world, fmhip_comm_t *out);
 int fmhip_comm_destroy(fmhip_comm_t c);
 int fmhip_comm_info(fmhip_comm_t c, int *rank, int *world);
+/* The same communicator over a transport of the caller's own instead of RCCL (MPI, UCX, a JVM-side channel; the
+ * two-ranks-on-one-GPU test of this repo stages through the host and torch.distributed/gloo).  `fn` is called from
+ * fmhip_dp_step / _plan / _epoch on the calling thread and must leave in EVERY rank's `device_buf` the result over all
+ * ranks, in place, ordered after the work already queued on `hip_stream` (a hipStream_t) and before anything queued
+ * later — it may enqueue its own kernels there, or wait for the stream and work from the host (the overlap with the
+ * backward is then lost, the result is the same).  All ranks see the same sequence of calls.  Return 0 = done.
+ *   FMHIP_COLL_SUM_F32     element-wise sum of `count` floats (the gradient slices, the row count)
+ *   FMHIP_COLL_MAX_I64     element-wise maximum of `count` int64 (step counts)
+ *   FMHIP_COLL_BCAST0_I64  every rank receives rank 0's `count` int64 (the cuts) */
+#define FMHIP_COLL_SUM_F32 0
+#define FMHIP_COLL_MAX_I64 1
+#define FMHIP_COLL_BCAST0_I64 2
+typedef int (*fmhip_collective_fn)(void *ctx, void *device_buf, size_t count, int kind, void *hip_stream);
+int fmhip_comm_create_external(fmhip_model_t m, int rank, int world, fmhip_collective_fn fn, void *ctx, fmhip_comm_t *out);
+/* What a host-staged transport needs and cannot reach from the JVM / ctypes by itself: wait for a stream; copy
+ * device -> host / host -> device behind the work queued on the stream (both return when the copy has finished). */
+int fmhip_stream_wait(void *hip_stream);
+int fmhip_device_read(void *host_dst, const void *device_src, size_t bytes, void *hip_stream);
+int fmhip_device_write(void *device_dst, const void *host_src, size_t bytes, void *hip_stream);
 /* Chooses the feature ids that cut the backward into intervals and broadcasts them from rank 0 (collective).
  * upper_fractions[i], ascending: the share of rank 0's stored nonzeros that lies at or above cut i — e.g.
  * {0.25} = two intervals, the first (ids >= cut) a quarter of the work and nearly all of the gradient's

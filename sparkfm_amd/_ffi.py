@@ -30,6 +30,7 @@ SYMBOLS = (
     "fmhip_comm_unique_id", "fmhip_comm_create", "fmhip_comm_destroy", "fmhip_comm_info", "fmhip_dp_plan",
     "fmhip_dp_step", "fmhip_dp_epoch", "fmhip_comm_profile_begin", "fmhip_comm_profile_end", "fmhip_shard_rows", "fmhip_comm_emulate",
     "fmhip_feature_counts", "fmhip_rank_from_counts", "fmhip_relabel_columns", "fmhip_dataset_hot_pages",
+    "fmhip_comm_create_external", "fmhip_stream_wait", "fmhip_device_read", "fmhip_device_write",
 )
 UNIQUE_ID_BYTES = 128
 
@@ -53,6 +54,11 @@ class Profile(C.Structure):
 
 class DatasetOpts(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("hot_block", C.c_int32), ("batch_rows", C.c_int64), ("row_block_rows", C.c_int64)]
+
+
+# int fn(void *ctx, void *device_buf, size_t count, int kind, void *hip_stream) — fmhip_comm_create_external
+CollectiveFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+COLL_SUM_F32, COLL_MAX_I64, COLL_BCAST0_I64 = 0, 1, 2
 
 
 class CommProfile(C.Structure):
@@ -146,6 +152,10 @@ def load():
     L.fmhip_comm_profile_begin.argtypes = [vp]
     L.fmhip_comm_profile_end.argtypes = [vp, P(CommProfile)]
     L.fmhip_shard_rows.argtypes = [i64, vp, C.c_int, C.c_int, P(i64), P(i64)]
+    L.fmhip_comm_create_external.argtypes = [vp, C.c_int, C.c_int, CollectiveFn, vp, P(vp)]
+    L.fmhip_stream_wait.argtypes = [vp]
+    L.fmhip_device_read.argtypes = [vp, vp, C.c_size_t, vp]
+    L.fmhip_device_write.argtypes = [vp, vp, C.c_size_t, vp]
     L.fmhip_dataset_hot_pages.argtypes = [vp, P(C.c_int32), P(C.c_int32), vp, P(i64)]
     L.fmhip_feature_counts.argtypes = [i64, vp, i64, vp]
     L.fmhip_rank_from_counts.argtypes = [i64, vp, vp, vp]

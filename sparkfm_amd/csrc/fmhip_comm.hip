@@ -118,7 +118,9 @@ struct CommProf {
 
 struct fmhip_comm {
     int device = 0, rank = 0, world = 1;
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;                // RCCL communicator, or ...
+    fmhip_collective_fn ext = nullptr;        // ... the caller's own transport (fmhip_comm_create_external)
+    void *ext_ctx = nullptr;
     hipStream_t cs = nullptr;                 // the collectives' stream
     hipEvent_t ev_ready[kMaxCuts + 1] = {};   // compute stream: interval i of the gradient is final
     hipEvent_t ev_done[kMaxCuts + 1] = {};    // comm stream: interval i's slice has been exchanged
@@ -140,6 +142,22 @@ void destroy_events(CommProf &p) {
     for (int i = 0; i <= kMaxCuts; ++i)
         for (hipEvent_t e : {p.c0[i], p.c1[i], p.a0[i], p.a1[i]})
             if (e) (void)hipEventDestroy(e);
+}
+
+// one collective on `s`: through RCCL, or handed to the caller's transport
+int collective(fmhip_comm_t c, void *buf, size_t count, int kind, hipStream_t s) {
+    if (c->ext) {
+        const int rc = c->ext(c->ext_ctx, buf, count, kind, reinterpret_cast<void *>(s));
+        if (rc != 0) return fail(FMHIP_ERR_COMM, "the caller's collective (kind %d, %zu elements) returned %d", kind, count, rc);
+        return FMHIP_OK;
+    }
+    switch (kind) {
+        case FMHIP_COLL_SUM_F32: NCCL_TRY(rccl().AllReduce(buf, buf, count, ncclFloat, ncclSum, c->comm, s)); break;
+        case FMHIP_COLL_MAX_I64: NCCL_TRY(rccl().AllReduce(buf, buf, count, ncclInt64, ncclMax, c->comm, s)); break;
+        case FMHIP_COLL_BCAST0_I64: NCCL_TRY(rccl().Broadcast(buf, buf, count, ncclInt64, 0, c->comm, s)); break;
+        default: return fail(FMHIP_ERR_INVALID, "unknown collective kind %d", kind);
+    }
+    return FMHIP_OK;
 }
 
 int check_comm(fmhip_model_t m, fmhip_comm_t c) {
@@ -166,13 +184,14 @@ int reduce_regions(fmhip_model_t m, fmhip_comm_t c, const Region *reg, int n_reg
         HIP_TRY(hipEventRecord(pr->c0[pi], c->cs));
     }
     size_t bytes = 0;
-    if (n_reg > 1) NCCL_TRY(rccl().GroupStart());
+    const bool group = n_reg > 1 && !c->ext;      // RCCL: the regions of an interval travel as one grouped call
+    if (group) NCCL_TRY(rccl().GroupStart());
     for (int i = 0; i < n_reg; ++i) {
         if (!reg[i].n) continue;
-        NCCL_TRY(rccl().AllReduce(reg[i].p, reg[i].p, reg[i].n, ncclFloat, ncclSum, c->comm, c->cs));
+        TRY(collective(c, reg[i].p, reg[i].n, FMHIP_COLL_SUM_F32, c->cs));
         bytes += reg[i].n * sizeof(float);
     }
-    if (n_reg > 1) NCCL_TRY(rccl().GroupEnd());
+    if (group) NCCL_TRY(rccl().GroupEnd());
     if (c->emu_bytes_per_us > 0.0) {
         const double us = (double)bytes / c->emu_bytes_per_us;
         hipLaunchKernelGGL(k_comm_delay, dim3(1), dim3(64), 0, c->cs, (uint64_t)(us * 100.0));
@@ -200,7 +219,7 @@ int dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, d
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_rows, m->stream));
     HIP_TRY(hipStreamWaitEvent(c->cs, c->ev_rows, 0));
-    NCCL_TRY(rccl().AllReduce(c->rows_dev, c->rows_dev, 1, ncclFloat, ncclSum, c->comm, c->cs));
+    TRY(collective(c, c->rows_dev, 1, FMHIP_COLL_SUM_F32, c->cs));
     if (live) {
         TRY(step_forward(m, d, batch));
     } else {
@@ -267,8 +286,7 @@ int dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, d
 // small control collectives (a count, a cut) through a device scratch word
 int control_i64(fmhip_model_t m, fmhip_comm_t c, int64_t *value, int count, bool broadcast_from_0) {
     HIP_TRY(hipMemcpyAsync(c->scratch, value, count * sizeof(int64_t), hipMemcpyHostToDevice, m->stream));
-    if (broadcast_from_0) NCCL_TRY(rccl().Broadcast(c->scratch, c->scratch, (size_t)count, ncclInt64, 0, c->comm, m->stream));
-    else NCCL_TRY(rccl().AllReduce(c->scratch, c->scratch, (size_t)count, ncclInt64, ncclMax, c->comm, m->stream));
+    TRY(collective(c, c->scratch, (size_t)count, broadcast_from_0 ? FMHIP_COLL_BCAST0_I64 : FMHIP_COLL_MAX_I64, m->stream));
     HIP_TRY(hipMemcpyAsync(value, c->scratch, count * sizeof(int64_t), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return FMHIP_OK;
@@ -284,6 +302,17 @@ int fmhip_comm_unique_id(void *id) {
     ncclUniqueId u;
     NCCL_TRY(rccl().GetUniqueId(&u));
     memcpy(id, &u, sizeof u);
+    return FMHIP_OK;
+}
+
+static int comm_resources(fmhip_comm *c) {
+    hipError_t e = hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking);
+    for (int i = 0; i <= kMaxCuts && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_ready[i], hipEventDisableTiming);
+    for (int i = 0; i <= kMaxCuts && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->scratch), (kMaxCuts + 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->rows_dev), 32 * sizeof(float));
+    if (e != hipSuccess) return fail(FMHIP_ERR_HIP, "communicator resources: %s", hipGetErrorString(e));
     return FMHIP_OK;
 }
 
@@ -306,17 +335,56 @@ int fmhip_comm_create(fmhip_model_t m, const void *id, int rank, int world, fmhi
         delete c;
         return fail(FMHIP_ERR_COMM, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, rccl().GetErrorString(r));
     }
-    hipError_t e = hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking);
-    for (int i = 0; i <= kMaxCuts && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_ready[i], hipEventDisableTiming);
-    for (int i = 0; i <= kMaxCuts && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->scratch), (kMaxCuts + 1) * sizeof(int64_t));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->rows_dev), 32 * sizeof(float));
-    if (e != hipSuccess) {
+    const int rc = comm_resources(c);
+    if (rc != FMHIP_OK) {
         fmhip_comm_destroy(c);
-        return fail(FMHIP_ERR_HIP, "communicator resources: %s", hipGetErrorString(e));
+        return rc;
     }
     *out = c;
+    return FMHIP_OK;
+}
+
+int fmhip_comm_create_external(fmhip_model_t m, int rank, int world, fmhip_collective_fn fn, void *ctx, fmhip_comm_t *out) {
+    if (!out) return fail(FMHIP_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!m || !fn) return fail(FMHIP_ERR_INVALID, "model or collective function is NULL");
+    if (world < 1 || rank < 0 || rank >= world) return fail(FMHIP_ERR_INVALID, "rank %d outside a world of %d", rank, world);
+    TRY(set_device(m->device));
+    fmhip_comm *c = new (std::nothrow) fmhip_comm();
+    if (!c) return fail(FMHIP_ERR_NOMEM, "out of host memory");
+    c->device = m->device;
+    c->rank = rank;
+    c->world = world;
+    c->ext = fn;
+    c->ext_ctx = ctx;
+    const int rc = comm_resources(c);
+    if (rc != FMHIP_OK) {
+        fmhip_comm_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return FMHIP_OK;
+}
+
+// what a host-staged transport needs and a JVM / ctypes caller cannot reach by itself
+int fmhip_stream_wait(void *hip_stream) {
+    HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(hip_stream)));
+    return FMHIP_OK;
+}
+
+int fmhip_device_read(void *host_dst, const void *device_src, size_t bytes, void *hip_stream) {
+    if (bytes && (!host_dst || !device_src)) return fail(FMHIP_ERR_INVALID, "NULL buffer");
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    HIP_TRY(hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return FMHIP_OK;
+}
+
+int fmhip_device_write(void *device_dst, const void *host_src, size_t bytes, void *hip_stream) {
+    if (bytes && (!device_dst || !host_src)) return fail(FMHIP_ERR_INVALID, "NULL buffer");
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    HIP_TRY(hipMemcpyAsync(device_dst, host_src, bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return FMHIP_OK;
 }
 

@@ -253,6 +253,46 @@ class RcclComm:
             pass
 
 
+class HostStagedComm(RcclComm):
+    """The library's data-parallel step over a transport of the caller's own (fmhip_comm_create_external): here every
+    collective is staged through the host and summed by torch.distributed on CPU tensors (gloo).  No overlap with the
+    backward and PCIe-bound — it exists for nodes without RCCL and for the two-ranks-on-one-GPU test, which RCCL refuses
+    (`ncclCommInitRank: invalid usage`); the schedule, the cuts, the global row count and the update are the library's
+    own, exactly as over RCCL."""
+
+    def __init__(self, fm, rank, world, group=None):   # noqa: D107 — does not call RcclComm.__init__ (no unique id)
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        L = _ffi.load()
+        self.rank, self.world = rank, world
+        self.calls = []                        # (kind, count) of every collective: what the ranks must agree on
+
+        def collective(_ctx, dev, count, kind, stream):
+            try:
+                self.calls.append((kind, count))
+                dt = np.float32 if kind == _ffi.COLL_SUM_F32 else np.int64
+                host = np.empty(count, dt)
+                _ffi.check(L.fmhip_device_read(_ffi.ptr(host), dev, host.nbytes, stream))
+                t = torch.from_numpy(host)
+                if kind == _ffi.COLL_SUM_F32:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                elif kind == _ffi.COLL_MAX_I64:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+                else:
+                    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                _ffi.check(L.fmhip_device_write(dev, _ffi.ptr(host), host.nbytes, stream))
+                return 0
+            except Exception:   # noqa: BLE001 — an exception must not cross the C ABI
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._fn = _ffi.CollectiveFn(collective)     # kept alive as long as the communicator
+        self._h = C.c_void_p()
+        _ffi.check(L.fmhip_comm_create_external(fm.handle, rank, world, self._fn, None, C.byref(self._h)))
+
+
 class HipDataParallelSGD(FMLearn):
     """FMLearn whose `learn` runs one data-parallel epoch over this rank's row shard INSIDE the library:
     forward -> feature-chunked backward overlapped with the RCCL all-reduce -> identical update

@@ -1,6 +1,7 @@
-"""Worker for test_library_side_exchange_two_ranks: one rank = one GPU, the exchange runs INSIDE the
-library (fmhip_comm_create + fmhip_dp_epoch over RCCL); torch.distributed (gloo) only ships the
-128-byte unique id and the final barrier."""
+"""Worker for test_library_side_exchange_two_ranks*: the data-parallel step runs INSIDE the library (fmhip_dp_epoch).
+Transport "rccl": one rank = one GPU, fmhip_comm_create over RCCL; torch.distributed (gloo) only ships the 128-byte
+unique id and the final barrier.  Transport "host": both ranks on GPU 0, fmhip_comm_create_external with a
+host-staged gloo all-reduce (RCCL refuses two ranks on one device) — same schedule, cuts, row counts and update."""
 import os
 import sys
 
@@ -12,11 +13,12 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
-    # FMHIP_TEST_ONE_GPU=1: every rank on device 0 (only works where RCCL accepts two ranks on one device)
-    dev = 0 if os.environ.get("FMHIP_TEST_ONE_GPU") else rank
+    transport = sys.argv[5] if len(sys.argv) > 5 else "rccl"
+    fractions = tuple(float(x) for x in sys.argv[6].split(",") if x) if len(sys.argv) > 6 else None
+    dev = 0 if transport == "host" else rank
     import torch.distributed as dist
     from sparkfm_amd import DataSet, FMModel, synth
-    from sparkfm_amd.distributed import HipDataParallelSGD, RcclComm
+    from sparkfm_amd.distributed import HipDataParallelSGD, HostStagedComm, RcclComm
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % port, rank=rank, world_size=world)
     # uneven shards: rank 1 has 2 batches against rank 0's 3
     d = synth.make_zipf(77, 3000 if rank == 0 else 1700, 800, 4, 24, zipf_s=1.05, row_begin=rank * 3000)
@@ -25,11 +27,14 @@ def main():
     w = np.random.default_rng(9).normal(0, 0.05, 800)
     fm = FMModel(799, 32, device=dev)
     fm.w0, fm.w, fm.v = w0, w, v
-    comm = RcclComm(fm, rank, world)
-    dp = HipDataParallelSGD(comm, eta=0.05, regw=1e-3, regv=1e-3)
+    comm = HostStagedComm(fm, rank, world) if transport == "host" else RcclComm(fm, rank, world)
+    kw = {} if fractions is None else {"upper_fractions": fractions}
+    dp = HipDataParallelSGD(comm, eta=0.05, regw=1e-3, regv=1e-3, **kw)
     for _ in range(2):
         dp.learn(fm, ds)
-    np.savez(out + ".%d.npz" % rank, w0=fm.w0, w=fm.w, v=fm.v, cuts=np.array(dp.cuts))
+    calls = np.array(getattr(comm, "calls", []), np.int64).reshape(-1, 2)
+    np.savez(out + ".%d.npz" % rank, w0=fm.w0, w=fm.w, v=fm.v, cuts=np.array(dp.cuts), calls=calls,
+             rows=dp.last_stats["rows"], steps=dp.last_stats["steps"])
     dist.barrier()
     comm.close()
     dist.destroy_process_group()

@@ -324,7 +324,6 @@ def test_library_side_exchange_two_ranks():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs")
     import tempfile
-    from sparkfm_amd import synth
     port, out = str(_free_port()), os.path.join(tempfile.mkdtemp(), "dp")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_rccl_worker.py"), str(r), "2", port, out]) for r in range(2)]
     for p in procs:
@@ -333,6 +332,13 @@ def test_library_side_exchange_two_ranks():
     np.testing.assert_array_equal(r0["v"], r1["v"])
     np.testing.assert_array_equal(r0["w"], r1["w"])
     assert float(r0["w0"]) == float(r1["w0"])
+    w0, w, v = _oracle_two_rank_epochs()
+    assert rel(r0["v"], v) <= 1e-5 and rel(r0["w"], w) <= 1e-5 and float(r0["w0"]) == pytest.approx(w0, rel=1e-5, abs=1e-7)
+
+
+def _oracle_two_rank_epochs():
+    """The oracle over the global batches of dist_rccl_worker's two uneven shards (2 epochs of 3 steps)."""
+    from sparkfm_amd import synth
     shards = [synth.make_zipf(77, 3000, 800, 4, 24, zipf_s=1.05, row_begin=0),
               synth.make_zipf(77, 1700, 800, 4, 24, zipf_s=1.05, row_begin=3000)]
     w0, w, v = synth.init_params(5, 800, 32, stdev=0.05)
@@ -350,6 +356,35 @@ def test_library_side_exchange_two_ranks():
                     ys.append(float(d["y"][r]))
             w0, w, v, _ = oracle.sgd_step(w0, w, v, 0, len(ys), np.array(rp, np.int64), np.concatenate(cols),
                                           np.concatenate(vals), np.array(ys), 0.05, 0.0, 1e-3, 1e-3)
+    return w0, w, v
+
+
+@pytest.mark.parametrize("fractions", ["", "0.3", "0.05,0.15,0.3,0.55"])
+def test_library_side_exchange_two_ranks_on_one_gpu_host_staged(fractions):
+    """The library's data-parallel step with TWO real ranks on the one GPU of the test box: fmhip_dp_epoch over
+    fmhip_comm_create_external, every collective staged through the host and summed by gloo (RCCL refuses two ranks on
+    one device).  Everything but the transport is the RCCL path: the plan broadcast from rank 0, the global row count,
+    the interval schedule with 0 / 1 / 4 cuts, the rank that runs out of rows and contributes zeros, the step count
+    agreed by a max-reduce.  Replicas bit-identical, same sequence of collectives on both ranks, oracle matched."""
+    import tempfile
+    port, out = str(_free_port()), os.path.join(tempfile.mkdtemp(), "dp")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_rccl_worker.py"), str(r), "2", port, out, "host", fractions])
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
+    np.testing.assert_array_equal(r0["v"], r1["v"])
+    np.testing.assert_array_equal(r0["w"], r1["w"])
+    assert float(r0["w0"]) == float(r1["w0"])
+    np.testing.assert_array_equal(r0["calls"], r1["calls"])
+    np.testing.assert_array_equal(r0["cuts"], r1["cuts"])
+    n_cuts = len([x for x in fractions.split(",") if x])
+    assert len(r0["cuts"]) == n_cuts and int(r0["steps"]) == 3 and int(r0["rows"]) == 1000      # last global batch: 1000 + 0 rows
+    # per epoch: 1 step-count max-reduce; per step: the row count + (1 region, or 3 per interval); per plan: cuts + blocked flag
+    sums = r0["calls"][r0["calls"][:, 0] == 0]
+    per_step = 1 + (1 if n_cuts == 0 else 3 * (n_cuts + 1))
+    assert len(sums) == 2 * 3 * per_step
+    w0, w, v = _oracle_two_rank_epochs()
     assert rel(r0["v"], v) <= 1e-5 and rel(r0["w"], w) <= 1e-5 and float(r0["w0"]) == pytest.approx(w0, rel=1e-5, abs=1e-7)
 
 
