@@ -20,8 +20,11 @@ def main():
     from sparkfm_amd import DataSet, FMModel, synth
     from sparkfm_amd.distributed import HipDataParallelSGD, HostStagedComm, RcclComm
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % port, rank=rank, world_size=world)
-    # uneven shards: rank 1 has 2 batches against rank 0's 3
-    d = synth.make_zipf(77, 3000 if rank == 0 else 1700, 800, 4, 24, zipf_s=1.05, row_begin=rank * 3000)
+    # uneven shards: rank 1 has 2 batches against rank 0's 3; a third rank has no rows at all
+    if rank < 2:
+        d = synth.make_zipf(77, 3000 if rank == 0 else 1700, 800, 4, 24, zipf_s=1.05, row_begin=rank * 3000)
+    else:
+        d = dict(row_ptr=np.zeros(1, np.int64), col=np.zeros(0, np.int32), val=np.zeros(0, np.float32), y=np.zeros(0, np.float32))
     ds = DataSet.from_arrays(d, batch_rows=1000, device=dev).cache()
     w0, w, v = synth.init_params(5, 800, 32, stdev=0.05)
     w = np.random.default_rng(9).normal(0, 0.05, 800)

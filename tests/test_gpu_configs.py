@@ -359,25 +359,27 @@ def _oracle_two_rank_epochs():
     return w0, w, v
 
 
-@pytest.mark.parametrize("fractions", ["", "0.3", "0.05,0.15,0.3,0.55"])
-def test_library_side_exchange_two_ranks_on_one_gpu_host_staged(fractions):
-    """The library's data-parallel step with TWO real ranks on the one GPU of the test box: fmhip_dp_epoch over
+@pytest.mark.parametrize("fractions,world", [("", 2), ("0.3", 2), ("0.05,0.15,0.3,0.55", 2), ("0.12,0.4", 3)])
+def test_library_side_exchange_two_ranks_on_one_gpu_host_staged(fractions, world):
+    """The library's data-parallel step with two (three) real ranks on the one GPU of the test box: fmhip_dp_epoch over
     fmhip_comm_create_external, every collective staged through the host and summed by gloo (RCCL refuses two ranks on
     one device).  Everything but the transport is the RCCL path: the plan broadcast from rank 0, the global row count,
     the interval schedule with 0 / 1 / 4 cuts, the rank that runs out of rows and contributes zeros, the step count
     agreed by a max-reduce.  Replicas bit-identical, same sequence of collectives on both ranks, oracle matched."""
     import tempfile
     port, out = str(_free_port()), os.path.join(tempfile.mkdtemp(), "dp")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_rccl_worker.py"), str(r), "2", port, out, "host", fractions])
-             for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_rccl_worker.py"), str(r), str(world), port, out, "host", fractions])
+             for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
-    r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
-    np.testing.assert_array_equal(r0["v"], r1["v"])
-    np.testing.assert_array_equal(r0["w"], r1["w"])
-    assert float(r0["w0"]) == float(r1["w0"])
-    np.testing.assert_array_equal(r0["calls"], r1["calls"])
-    np.testing.assert_array_equal(r0["cuts"], r1["cuts"])
+    r0 = np.load(out + ".0.npz")
+    for r in range(1, world):                    # world = 3: the third rank holds no rows at all and still keeps in step
+        r1 = np.load(out + ".%d.npz" % r)
+        np.testing.assert_array_equal(r0["v"], r1["v"])
+        np.testing.assert_array_equal(r0["w"], r1["w"])
+        assert float(r0["w0"]) == float(r1["w0"])
+        np.testing.assert_array_equal(r0["calls"], r1["calls"])
+        np.testing.assert_array_equal(r0["cuts"], r1["cuts"])
     n_cuts = len([x for x in fractions.split(",") if x])
     assert len(r0["cuts"]) == n_cuts and int(r0["steps"]) == 3 and int(r0["rows"]) == 1000      # last global batch: 1000 + 0 rows
     # per epoch: 1 step-count max-reduce; per step: the row count + (1 region, or 3 per interval); per plan: cuts + blocked flag
