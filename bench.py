@@ -338,6 +338,9 @@ def main():
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"],
                     help="rccl: the library's own communicator (fmhip_dp_step); torch: torch.distributed all-reduce "
                          "orchestrated from Python (sparkfm_amd.distributed.DataParallelSGD)")
+    ap.add_argument("--dp-exchange", default="auto", choices=["auto", "dense", "touched"],
+                    help="what a data-parallel step exchanges (fmhip_dp_exchange): the whole packed gradient in overlapped slices, or only "
+                         "the rows some rank touched; auto = touched for C5 (a 8.9 GB gradient), dense otherwise")
     ap.add_argument("--upper-fractions", default="auto",
                     help="cuts of the backward for the overlapped exchange: comma-separated ascending shares of the nonzeros at or "
                          "above each cut (e.g. 0.3 or 0.12,0.4), 'none' = one all-reduce after the whole backward, 'auto' = "
@@ -430,7 +433,8 @@ def main():
             comm = RcclComm(fm, rank, world)
             fixed = None if args.upper_fractions == "auto" else (() if args.upper_fractions == "none" else
                                                                  tuple(float(x) for x in args.upper_fractions.split(",")))
-            dp = HipDataParallelSGD(comm, eta=args.eta, reg0=regs[0], regw=regs[1], regv=regs[2],
+            dp_mode = args.dp_exchange if args.dp_exchange != "auto" else ("touched" if cfg.get("criteo") else "dense")
+            dp = HipDataParallelSGD(comm, eta=args.eta, reg0=regs[0], regw=regs[1], regv=regs[2], exchange=dp_mode,
                                     upper_fractions=fixed if fixed is not None else (0.05, 0.15, 0.3, 0.55))
             dp.plan(fm, ds)
             if args.emulate_allreduce:
@@ -480,7 +484,7 @@ def main():
     sync()
     barrier()
     tuning = None
-    if exchange == "rccl" and args.upper_fractions == "auto" and (world > 1 or args.emulate_allreduce):
+    if exchange == "rccl" and dp.exchange == "dense" and args.upper_fractions == "auto" and (world > 1 or args.emulate_allreduce):
         # measure, don't guess: the best cut depends on the all-reduce's real bandwidth on this node
         tuning = []
         for cand in ((0.3,), (0.2,), (0.12, 0.4), (0.08, 0.25, 0.5), (0.05, 0.15, 0.3, 0.55), (0.04, 0.1, 0.2, 0.35, 0.6), ()):
@@ -604,7 +608,7 @@ def main():
         nnz0, rows0 = bi["nnz"], bi["rows"]
         nnz0_sparse = int(round(nnz0 * lay["nnz_sparse"] / max(int(d["row_ptr"][-1]), 1)))   # batch 0's share of the sparse streams
         nnz0_sparse_b = int(round(nnz0 * lay["nnz_sparse_backward"] / max(int(d["row_ptr"][-1]), 1)))   # ... of the transposes
-        dense_apply = use_dp or n_cols * 2 > n1
+        dense_apply = (use_dp and not (exchange == "rccl" and dp.exchange == "touched")) or n_cols * 2 > n1
         req = requested_bytes(kp, rows0, nnz0, nnz0_sparse, n_cols, hot, n_cols, dense_apply, n1, packed, nnz0_sparse_b, lay["hot_pages"])
         table_bytes = {"forward": n1 * kp * 4, "backward": rows0 * kp * 4}
         kern = kernel_table(prof, k, kp, req, pmc, table_bytes)
@@ -631,7 +635,8 @@ def main():
                                            "share_of_nonzeros_left_to_the_forward": lay["nnz_sparse"] / max(int(d["row_ptr"][-1]), 1),
                                            "share_of_nonzeros_left_to_the_backward": lay["nnz_sparse_backward"] / max(int(d["row_ptr"][-1]), 1)},
                        "parallelism": "dp%d" % world, "exchange": exchange,
-                       "allreduce": ("inside the library (RCCL), overlapped with the feature-chunked backward, cuts at features %s" % dp.cuts
+                       "allreduce": ("inside the library (RCCL), touched rows only" if exchange == "rccl" and dp.exchange == "touched" else
+                                     "inside the library (RCCL), overlapped with the feature-chunked backward, cuts at features %s" % dp.cuts
                                      if exchange == "rccl" and dp.cuts else
                                      ("inside the library (RCCL), one all-reduce per step" if exchange == "rccl" else
                                       ("torch.distributed, orchestrated from Python" if exchange == "torch" else "none")))},
@@ -664,6 +669,14 @@ def main():
             _ffi.check(L.fmhip_grad_floats(hm, C.byref(gf)))
             payload = int(gf.value) * 4
             xc = {"nranks": world, "allreduce_bytes_per_step": payload, "backend": exchange}
+            if exchange == "rccl" and dp.exchange == "touched":
+                info = dp.exchange_info()
+                xc["mode"] = "touched rows (fmhip_dp_exchange): all-gather of ids, sorted union, packed all-reduce, rows-only update"
+                xc["dense_gradient_bytes"] = payload
+                xc["id_slots_per_rank"] = info["id_slots_per_rank"]
+                xc["mean_union_rows"] = info["mean_union_rows"]
+                xc["allreduce_bytes_per_step"] = int((32 + info["mean_union_rows"] * (kp + 2)) * 4)
+                xc["allgather_bytes_per_step"] = int(info["id_slots_per_rank"] * world * 4)
             if cprof and cprof["steps"]:
                 xc["exposed_comm_ms"] = cprof["exposed_ms"] / cprof["steps"]
                 xc["comm_busy_ms"] = cprof["comm_ms"] / cprof["steps"]

@@ -288,6 +288,7 @@ int fmhip_comm_info(fmhip_comm_t c, int *rank, int *world);
 #define FMHIP_COLL_SUM_F32 0
 #define FMHIP_COLL_MAX_I64 1
 #define FMHIP_COLL_BCAST0_I64 2
+#define FMHIP_COLL_ALLGATHER_I32 3 /* device_buf holds world x count int32, rank r's own at r * count: fill in the others' */
 typedef int (*fmhip_collective_fn)(void *ctx, void *device_buf, size_t count, int kind, void *hip_stream);
 int fmhip_comm_create_external(fmhip_model_t m, int rank, int world, fmhip_collective_fn fn, void *ctx, fmhip_comm_t *out);
 /* What a host-staged transport needs and cannot reach from the JVM / ctypes by itself: wait for a stream; copy
@@ -295,6 +296,19 @@ int fmhip_comm_create_external(fmhip_model_t m, int rank, int world, fmhip_colle
 int fmhip_stream_wait(void *hip_stream);
 int fmhip_device_read(void *host_dst, const void *device_src, size_t bytes, void *hip_stream);
 int fmhip_device_write(void *device_dst, const void *host_src, size_t bytes, void *hip_stream);
+/* What travels in a data-parallel step (set on every rank, before fmhip_dp_plan):
+ *   FMHIP_EXCHANGE_DENSE    (default) the whole packed gradient, 4(n+1)(k+1) bytes, in slices overlapped with the backward —
+ *                           north_star's dense all-reduce; right when a global batch touches most of the model (C4)
+ *   FMHIP_EXCHANGE_TOUCHED  only the gradient rows some rank's mini-batch touched: every rank's touched ids are gathered,
+ *                           their sorted union U (identical everywhere) is packed [scalars | G rows of U], summed, unpacked and
+ *                           applied with the rows-only update (weight decay rides in the tables' scale: 0.5 <= 1 - eta*reg <= 1
+ *                           required).  For models far wider than a global batch — C5's 2^25 x 64 table is 8.9 GB dense and
+ *                           ~0.1 of that here.  No overlap with the backward; one 4-byte read-back per step.
+ * fmhip_dp_exchange_info: the mode, the id slots per rank agreed by the plan, the mean |U| of the steps so far. */
+#define FMHIP_EXCHANGE_DENSE 0
+#define FMHIP_EXCHANGE_TOUCHED 1
+int fmhip_dp_exchange(fmhip_comm_t c, int mode);
+int fmhip_dp_exchange_info(fmhip_comm_t c, int *mode, int64_t *id_slots_per_rank, double *mean_union_rows);
 /* Chooses the feature ids that cut the backward into intervals and broadcasts them from rank 0 (collective).
  * upper_fractions[i], ascending: the share of rank 0's stored nonzeros that lies at or above cut i — e.g.
  * {0.25} = two intervals, the first (ids >= cut) a quarter of the work and nearly all of the gradient's

@@ -31,6 +31,7 @@ SYMBOLS = (
     "fmhip_dp_step", "fmhip_dp_epoch", "fmhip_comm_profile_begin", "fmhip_comm_profile_end", "fmhip_shard_rows", "fmhip_comm_emulate",
     "fmhip_feature_counts", "fmhip_rank_from_counts", "fmhip_relabel_columns", "fmhip_dataset_hot_pages",
     "fmhip_comm_create_external", "fmhip_stream_wait", "fmhip_device_read", "fmhip_device_write",
+    "fmhip_dp_exchange", "fmhip_dp_exchange_info",
 )
 UNIQUE_ID_BYTES = 128
 
@@ -58,7 +59,8 @@ class DatasetOpts(C.Structure):
 
 # int fn(void *ctx, void *device_buf, size_t count, int kind, void *hip_stream) — fmhip_comm_create_external
 CollectiveFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
-COLL_SUM_F32, COLL_MAX_I64, COLL_BCAST0_I64 = 0, 1, 2
+COLL_SUM_F32, COLL_MAX_I64, COLL_BCAST0_I64, COLL_ALLGATHER_I32 = 0, 1, 2, 3
+EXCHANGE_DENSE, EXCHANGE_TOUCHED = 0, 1
 
 
 class CommProfile(C.Structure):
@@ -153,6 +155,8 @@ def load():
     L.fmhip_comm_profile_end.argtypes = [vp, P(CommProfile)]
     L.fmhip_shard_rows.argtypes = [i64, vp, C.c_int, C.c_int, P(i64), P(i64)]
     L.fmhip_comm_create_external.argtypes = [vp, C.c_int, C.c_int, CollectiveFn, vp, P(vp)]
+    L.fmhip_dp_exchange.argtypes = [vp, C.c_int]
+    L.fmhip_dp_exchange_info.argtypes = [vp, P(C.c_int), P(i64), P(C.c_double)]
     L.fmhip_stream_wait.argtypes = [vp]
     L.fmhip_device_read.argtypes = [vp, vp, C.c_size_t, vp]
     L.fmhip_device_write.argtypes = [vp, vp, C.c_size_t, vp]

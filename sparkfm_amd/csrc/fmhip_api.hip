@@ -1083,6 +1083,57 @@ int step_apply_interval(fmhip_model_t m, double eta, double reg0, double regw, d
     return FMHIP_OK;
 }
 
+// can weight decay ride in the tables' scale for this (eta, reg)?  (no decay at all: trivially)
+bool lazy_decay_ok(double eta, double regw, double regv) {
+    const double dv = 1.0 - eta * regv, dw = 1.0 - eta * regw;
+    if (regw == 0.0 && regv == 0.0) return true;
+    return g_tune[kTuneLazy] && dv >= 0.5 && dw >= 0.5 && dv <= 1.0 && dw <= 1.0;
+}
+
+int step_apply_rows(fmhip_model_t m, double eta, double reg0, double regw, double regv, const int32_t *feat, int32_t n_feat,
+                    const float *rows) {
+    if (!lazy_decay_ok(eta, regw, regv))
+        return fail(FMHIP_ERR_UNSUPPORTED, "a rows-only update needs weight decay that fits the tables' scale (0.5 <= 1 - eta*reg <= 1)");
+    const double sv_out = m->sv * (1.0 - eta * regv), sw_out = m->sw * (1.0 - eta * regw);
+    ApplyArgs a{};
+    a.sv_in = (float)m->sv;
+    a.sw_in = (float)m->sw;
+    a.feat = feat;
+    a.n_feat = n_feat;
+    a.hot_ids = nullptr;
+    a.n_hot = 0;
+    a.eta_v = (float)(eta / sv_out);
+    a.eta_w = (float)(eta / sw_out);
+    a.V = m->V.p;
+    a.w = m->w.p;
+    a.w0 = m->w0.p;
+    a.GV = m->GV();
+    a.Gw = m->Gw();
+    a.Gb = m->Gb();
+    a.scal = m->scal();
+    a.rows = rows;
+    a.n1 = m->n1;
+    a.row_lo = 0;
+    a.row_hi = m->n1;
+    a.do_w0 = 1;
+    a.pack_k = m->pack_k();
+    a.eta = (float)eta;
+    a.reg0 = (float)reg0;
+    a.regw = (float)regw;
+    a.regv = (float)regv;
+    {
+        ProfScope ps(m, FMHIP_K_APPLY, m->last_nnz, m->last_rows);
+        HIP_TRY(launch_apply(m->Kp, a, m->stream));
+    }
+    m->sv = sv_out;
+    m->sw = sw_out;
+    if (m->sv < 0x1p-24 || m->sw < 0x1p-24) TRY(fold_scales(m));
+    m->grad_dirty = false;
+    m->host64_fresh = false;
+    ++m->prof_step;
+    return FMHIP_OK;
+}
+
 int read_scal(fmhip_model_t m, fmhip_stats *st) {
     float h[4];
     HIP_TRY(hipMemcpyAsync(h, m->scal(), sizeof h, hipMemcpyDeviceToHost, m->stream));

@@ -23,6 +23,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+
 #include <algorithm>
 #include <cstring>
 #include <mutex>
@@ -41,6 +44,7 @@ struct Rccl {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -69,6 +73,7 @@ Rccl &rccl() {
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
         r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
         r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
@@ -107,6 +112,48 @@ __global__ void k_comm_delay(uint64_t ticks) {
 // asynchronous copy, and the host runs steps ahead of the stream)
 __global__ void k_set_float(float *p, float v) { *p = v; }
 
+// ---- touched-rows exchange (fmhip_dp_exchange): the kernels around the collectives
+// this rank's segment of the id table: the batch's distinct features, the hot block's, then -1 up to `cap`
+__global__ __launch_bounds__(256) void k_fill_ids(int32_t *dst, const int32_t *feat, int32_t n_feat, const int32_t *hot, int32_t n_hot,
+                                                  int64_t cap) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= cap) return;
+    int32_t v = -1;
+    if (i < n_feat) v = feat[i];
+    else if (i < (int64_t)n_feat + n_hot) v = hot[i - n_feat];
+    dst[i] = v;
+}
+
+// message = [head (kGradHead floats) | per union row: G_V row (kp), G_w, G_b]; ids < 0 (the padding's one entry) travel as zeros
+__global__ __launch_bounds__(256) void k_pack_rows(const int32_t *u, int32_t n_u, int kp, const float *head, const float *GV, const float *Gw,
+                                                   const float *Gb, float *out) {
+    const int rf = kp + 2;
+    const int64_t total = (int64_t)kGradHead + (int64_t)n_u * rf;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        if (i < kGradHead) { out[i] = head[i]; continue; }
+        const int64_t j = (i - kGradHead) / rf;
+        const int c = (int)((i - kGradHead) % rf);
+        const int32_t id = u[j];
+        out[i] = id < 0 ? 0.f : (c < kp ? GV[(size_t)id * kp + c] : (c == kp ? Gw[id] : Gb[id]));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_unpack_rows(const int32_t *u, int32_t n_u, int kp, const float *in, float *head, float *GV, float *Gw,
+                                                     float *Gb) {
+    const int rf = kp + 2;
+    const int64_t total = (int64_t)kGradHead + (int64_t)n_u * rf;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        if (i < kGradHead) { head[i] = in[i]; continue; }
+        const int64_t j = (i - kGradHead) / rf;
+        const int c = (int)((i - kGradHead) % rf);
+        const int32_t id = u[j];
+        if (id < 0) continue;
+        if (c < kp) GV[(size_t)id * kp + c] = in[i];
+        else if (c == kp) Gw[id] = in[i];
+        else Gb[id] = in[i];
+    }
+}
+
 struct CommProf {
     hipEvent_t wait_a = nullptr, wait_b = nullptr;   // compute stream: around its wait for the last collective
     hipEvent_t c0[kMaxCuts + 1] = {}, c1[kMaxCuts + 1] = {};   // comm stream: around each collective
@@ -121,6 +168,15 @@ struct fmhip_comm {
     ncclComm_t comm = nullptr;                // RCCL communicator, or ...
     fmhip_collective_fn ext = nullptr;        // ... the caller's own transport (fmhip_comm_create_external)
     void *ext_ctx = nullptr;
+    // touched-rows exchange (fmhip_dp_exchange): per rank `cap` id slots; the union's rows travel instead of the whole gradient
+    int exchange = FMHIP_EXCHANGE_DENSE;
+    int64_t cap = 0;                          // agreed by fmhip_dp_plan: the largest per-batch id count of any rank
+    int32_t *ids = nullptr, *ids_sorted = nullptr, *uniq = nullptr, *n_uniq = nullptr;   // device: [world * cap] x 3, [1]
+    float *msg = nullptr;                     // device: [kGradHead + world * cap * (Kp + 2)]
+    void *tmp = nullptr;                      // rocPRIM temporary storage
+    size_t tmp_bytes = 0;
+    int msg_kp = 0;
+    int64_t touched_rows_sum = 0, touched_steps = 0;   // statistics: union sizes
     hipStream_t cs = nullptr;                 // the collectives' stream
     hipEvent_t ev_ready[kMaxCuts + 1] = {};   // compute stream: interval i of the gradient is final
     hipEvent_t ev_done[kMaxCuts + 1] = {};    // comm stream: interval i's slice has been exchanged
@@ -155,6 +211,9 @@ int collective(fmhip_comm_t c, void *buf, size_t count, int kind, hipStream_t s)
         case FMHIP_COLL_SUM_F32: NCCL_TRY(rccl().AllReduce(buf, buf, count, ncclFloat, ncclSum, c->comm, s)); break;
         case FMHIP_COLL_MAX_I64: NCCL_TRY(rccl().AllReduce(buf, buf, count, ncclInt64, ncclMax, c->comm, s)); break;
         case FMHIP_COLL_BCAST0_I64: NCCL_TRY(rccl().Broadcast(buf, buf, count, ncclInt64, 0, c->comm, s)); break;
+        case FMHIP_COLL_ALLGATHER_I32:     // in place: rank r's `count` elements already sit at buf + r * count
+            NCCL_TRY(rccl().AllGather(static_cast<int32_t *>(buf) + (size_t)c->rank * count, buf, count, ncclInt32, c->comm, s));
+            break;
         default: return fail(FMHIP_ERR_INVALID, "unknown collective kind %d", kind);
     }
     return FMHIP_OK;
@@ -203,7 +262,102 @@ int reduce_regions(fmhip_model_t m, fmhip_comm_t c, const Region *reg, int n_reg
     return FMHIP_OK;
 }
 
+void free_touched(fmhip_comm_t c) {
+    for (void *p : {(void *)c->ids, (void *)c->ids_sorted, (void *)c->uniq, (void *)c->n_uniq, (void *)c->msg, c->tmp})
+        if (p) (void)hipFree(p);
+    c->ids = c->ids_sorted = c->uniq = c->n_uniq = nullptr;
+    c->msg = nullptr;
+    c->tmp = nullptr;
+    c->tmp_bytes = 0;
+}
+
+// buffers of the touched-rows exchange for `cap` id slots per rank (collective sizes depend on it: every rank the same)
+int size_touched(fmhip_model_t m, fmhip_comm_t c, int64_t cap) {
+    free_touched(c);
+    c->cap = cap;
+    c->msg_kp = m->Kp;
+    const size_t n = (size_t)c->world * (size_t)cap;
+    if (n > (size_t)INT32_MAX) return fail(FMHIP_ERR_UNSUPPORTED, "%zu id slots exceed the touched-rows exchange's 2^31 limit", n);
+    size_t a = 0, b = 0;
+    int32_t *k = nullptr;
+    HIP_TRY(rocprim::radix_sort_keys(nullptr, a, k, k, n, 0, 32, m->stream));
+    HIP_TRY(rocprim::unique(nullptr, b, k, k, k, n, rocprim::equal_to<int32_t>(), m->stream));
+    c->tmp_bytes = std::max(a, b);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->ids), std::max<size_t>(n, 1) * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->ids_sorted), std::max<size_t>(n, 1) * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->uniq), std::max<size_t>(n, 1) * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->n_uniq), sizeof(int32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->msg), ((size_t)kGradHead + n * (size_t)(m->Kp + 2)) * sizeof(float)));
+    HIP_TRY(hipMalloc(&c->tmp, c->tmp_bytes + 16));
+    return FMHIP_OK;
+}
+
+// One data-parallel step that exchanges only the gradient rows some rank touched (models far wider than a global batch:
+// C5's 2^25 x 64 table moves 8.9 GB per dense all-reduce and ~0.1 of that here).  All on the compute stream:
+//   |B| -> forward -> backward (whole) -> all-gather of every rank's touched ids -> sort + unique = the union U (the same
+//   on every rank) -> pack [head | G rows of U] -> all-reduce -> unpack -> rows-only update of U with lazy weight decay.
+// One 4-byte read-back per step (|U| sizes the all-reduce).  Replicas stay bit-identical: same U, same sums, same update.
+int dp_step_touched(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0, double regw, double regv) {
+    const bool live = batch >= 0;
+    if (c->cap <= 0 || !c->ids || c->msg_kp != m->Kp)
+        return fail(FMHIP_ERR_INVALID, "the touched-rows exchange is not planned for this model: call fmhip_dp_plan (every rank)");
+    if (!lazy_decay_ok(eta, regw, regv))
+        return fail(FMHIP_ERR_UNSUPPORTED, "the touched-rows exchange needs weight decay that fits the tables' scale (0.5 <= 1 - eta*reg <= 1)");
+    int32_t n_feat = 0, n_hot = 0;
+    const int32_t *feat = nullptr, *hot = nullptr;
+    if (live) {
+        const auto &bm = d->batches[(size_t)batch];
+        n_feat = bm.n_cols;
+        feat = d->cfeat.p + bm.col_off;
+        n_hot = d->hot_pages * kHotT;
+        hot = d->d_hot_ids.p;
+        if ((int64_t)n_feat + n_hot > c->cap)
+            return fail(FMHIP_ERR_INVALID, "batch %lld touches %d rows, the plan allows %lld: call fmhip_dp_plan with this dataset (every rank)",
+                        (long long)batch, n_feat + n_hot, (long long)c->cap);
+    }
+    const float my_rows = live ? (float)d->batches[(size_t)batch].rows : 0.f;
+    hipLaunchKernelGGL(k_set_float, dim3(1), dim3(1), 0, m->stream, c->rows_dev, my_rows);
+    HIP_TRY(hipGetLastError());
+    TRY(collective(c, c->rows_dev, 1, FMHIP_COLL_SUM_F32, m->stream));
+    if (live) {
+        TRY(step_forward(m, d, batch));
+        TRY(step_backward(m, d, batch, 0, INT64_MAX, true, nullptr));
+    } else {
+        // out of rows: contribute zeros — the rows of G are clean after every update, the scalars in front of them keep the
+        // last step's (already exchanged) sums and must not travel again
+        if (m->grad_dirty) HIP_TRY(hipMemsetAsync(m->grad, 0, m->grad_floats() * sizeof(float), m->stream));
+        else HIP_TRY(hipMemsetAsync(m->grad, 0, (size_t)kGradHead * sizeof(float), m->stream));
+        m->grad_dirty = true;
+        m->last_nnz = m->last_rows = 0;
+    }
+    const size_t n = (size_t)c->world * (size_t)c->cap;
+    hipLaunchKernelGGL(k_fill_ids, dim3((unsigned)((c->cap + 255) / 256)), dim3(256), 0, m->stream, c->ids + (size_t)c->rank * c->cap, feat,
+                       n_feat, hot, n_hot, c->cap);
+    HIP_TRY(hipGetLastError());
+    TRY(collective(c, c->ids, (size_t)c->cap, FMHIP_COLL_ALLGATHER_I32, m->stream));
+    size_t tb = c->tmp_bytes;
+    HIP_TRY(rocprim::radix_sort_keys(c->tmp, tb, c->ids, c->ids_sorted, n, 0, 32, m->stream));
+    tb = c->tmp_bytes;
+    HIP_TRY(rocprim::unique(c->tmp, tb, c->ids_sorted, c->uniq, c->n_uniq, n, rocprim::equal_to<int32_t>(), m->stream));
+    int32_t n_u = 0;
+    HIP_TRY(hipMemcpyAsync(&n_u, c->n_uniq, sizeof n_u, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    const size_t floats = (size_t)kGradHead + (size_t)n_u * (size_t)(m->Kp + 2);
+    const unsigned blocks = (unsigned)std::min<size_t>((floats + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_pack_rows, dim3(blocks), dim3(256), 0, m->stream, c->uniq, n_u, m->Kp, m->scal(), m->GV(), m->Gw(), m->Gb(), c->msg);
+    HIP_TRY(hipGetLastError());
+    TRY(collective(c, c->msg, floats, FMHIP_COLL_SUM_F32, m->stream));
+    hipLaunchKernelGGL(k_unpack_rows, dim3(blocks), dim3(256), 0, m->stream, c->uniq, n_u, m->Kp, c->msg, m->scal(), m->GV(), m->Gw(), m->Gb());
+    HIP_TRY(hipGetLastError());
+    TRY(step_apply_rows(m, eta, reg0, regw, regv, c->uniq, n_u, c->rows_dev));
+    c->touched_rows_sum += n_u;
+    c->touched_steps += 1;
+    if (c->profiling) c->prof_bytes += (int64_t)(floats * sizeof(float) + (size_t)c->cap * c->world * sizeof(int32_t));
+    return FMHIP_OK;
+}
+
 int dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0, double regw, double regv) {
+    if (c->exchange == FMHIP_EXCHANGE_TOUCHED) return dp_step_touched(m, d, batch, c, eta, reg0, regw, regv);
     const bool live = batch >= 0;
     if (d->rb_rows != 0 && !c->cuts.empty())
         return fail(FMHIP_ERR_INVALID, "the communicator's plan cuts the backward, but this dataset's transposes are row-blocked: "
@@ -393,6 +547,7 @@ int fmhip_comm_destroy(fmhip_comm_t c) {
     (void)hipSetDevice(c->device);
     if (c->cs) (void)hipStreamSynchronize(c->cs);
     for (auto &p : c->prof) destroy_events(p);
+    free_touched(c);
     if (c->comm) (void)rccl().CommDestroy(c->comm);
     for (hipEvent_t e : c->ev_ready)
         if (e) (void)hipEventDestroy(e);
@@ -410,6 +565,21 @@ int fmhip_comm_emulate(fmhip_comm_t c, double payload_gb_per_s) {
     if (!c) return fail(FMHIP_ERR_INVALID, "communicator is NULL");
     if (payload_gb_per_s < 0.0) return fail(FMHIP_ERR_INVALID, "negative rate");
     c->emu_bytes_per_us = payload_gb_per_s * 1e3;      // GB/s = 1e3 bytes per microsecond
+    return FMHIP_OK;
+}
+
+int fmhip_dp_exchange(fmhip_comm_t c, int mode) {
+    if (!c) return fail(FMHIP_ERR_INVALID, "communicator is NULL");
+    if (mode != FMHIP_EXCHANGE_DENSE && mode != FMHIP_EXCHANGE_TOUCHED) return fail(FMHIP_ERR_INVALID, "unknown exchange mode %d", mode);
+    c->exchange = mode;
+    return FMHIP_OK;
+}
+
+int fmhip_dp_exchange_info(fmhip_comm_t c, int *mode, int64_t *id_slots_per_rank, double *mean_union_rows) {
+    if (!c) return fail(FMHIP_ERR_INVALID, "communicator is NULL");
+    if (mode) *mode = c->exchange;
+    if (id_slots_per_rank) *id_slots_per_rank = c->cap;
+    if (mean_union_rows) *mean_union_rows = c->touched_steps ? (double)c->touched_rows_sum / (double)c->touched_steps : 0.0;
     return FMHIP_OK;
 }
 
@@ -445,6 +615,13 @@ int fmhip_dp_plan(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, int n_frac
             while (f > 0 && (double)above < want) above += cnt[(size_t)f--];
             cuts[i] = f + 1 < m->n1 ? f + 1 : 0;
         }
+    }
+    if (c->exchange == FMHIP_EXCHANGE_TOUCHED) {
+        // the id table's width: the largest number of rows any batch of any rank touches
+        int64_t cap = 1;
+        for (const auto &bm : d->batches) cap = std::max<int64_t>(cap, (int64_t)bm.n_cols + d->hot_pages * kHotT);
+        TRY(control_i64(m, c, &cap, 1, false));
+        if (cap != c->cap || c->msg_kp != m->Kp || !c->ids) TRY(size_touched(m, c, cap));
     }
     TRY(control_i64(m, c, cuts, kMaxCuts + 1, true));
     // a rank whose transposes are row-blocked cannot cut its backward: then nobody does (same collectives everywhere)

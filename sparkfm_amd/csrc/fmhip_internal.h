@@ -202,6 +202,11 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
 int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double regv, fmhip_dataset_t d = nullptr, int64_t b = -1);
 int step_apply_interval(fmhip_model_t m, double eta, double reg0, double regw, double regv, int64_t lo, int64_t hi,
                         const float *rows, bool last);
+// the rows-only (lazy-decay) update of the feature rows listed on the device (ids < 0 are skipped), |B| from `rows`
+// (device float): the touched-rows exchange of the data-parallel step applies the union of all ranks' rows with it
+int step_apply_rows(fmhip_model_t m, double eta, double reg0, double regw, double regv, const int32_t *feat, int32_t n_feat,
+                    const float *rows);
+bool lazy_decay_ok(double eta, double regw, double regv);
 int read_scal(fmhip_model_t m, fmhip_stats *st);
 
 }  // namespace host

@@ -271,6 +271,14 @@ class HostStagedComm(RcclComm):
         def collective(_ctx, dev, count, kind, stream):
             try:
                 self.calls.append((kind, count))
+                if kind == _ffi.COLL_ALLGATHER_I32:     # world x count int32 on the device, this rank's own at rank * count
+                    host = np.empty(world * count, np.int32)
+                    _ffi.check(L.fmhip_device_read(_ffi.ptr(host), dev, host.nbytes, stream))
+                    parts = [torch.empty(count, dtype=torch.int32) for _ in range(world)]
+                    dist.all_gather(parts, torch.from_numpy(host[rank * count:(rank + 1) * count].copy()), group=group)
+                    host = np.concatenate([p.numpy() for p in parts])
+                    _ffi.check(L.fmhip_device_write(dev, _ffi.ptr(host), host.nbytes, stream))
+                    return 0
                 dt = np.float32 if kind == _ffi.COLL_SUM_F32 else np.int64
                 host = np.empty(count, dt)
                 _ffi.check(L.fmhip_device_read(_ffi.ptr(host), dev, host.nbytes, stream))
@@ -301,10 +309,14 @@ class HipDataParallelSGD(FMLearn):
     (the fastest of the candidates timed against an emulated 8-GPU all-reduce at C4's width);
     () = no overlap: whole backward, one all-reduce."""
 
-    def __init__(self, comm, eta=0.05, reg0=0.0, regw=0.0, regv=0.0, upper_fractions=(0.05, 0.15, 0.3, 0.55)):
+    def __init__(self, comm, eta=0.05, reg0=0.0, regw=0.0, regv=0.0, upper_fractions=(0.05, 0.15, 0.3, 0.55), exchange="dense"):
         self.comm = comm
         self.eta, self.reg0, self.regw, self.regv = float(eta), float(reg0), float(regw), float(regv)
         self.upper_fractions = tuple(float(f) for f in upper_fractions)
+        # "dense": the whole packed gradient in overlapped slices; "touched": only the rows some rank's batch touched
+        # (fmhip_dp_exchange) — for models far wider than a global batch
+        self.exchange = exchange
+        _ffi.check(_ffi.load().fmhip_dp_exchange(comm.handle, {"dense": _ffi.EXCHANGE_DENSE, "touched": _ffi.EXCHANGE_TOUCHED}[exchange]))
         self.cuts = None
         self._planned_for = None
         self.last_stats = None
@@ -318,6 +330,12 @@ class HipDataParallelSGD(FMLearn):
         self.cuts = [int(c) for c in cuts[:len(fr)] if c > 0]
         self._planned_for = id(dataset)
         return self.cuts
+
+    def exchange_info(self):
+        mode, cap, mean = C.c_int(), C.c_int64(), C.c_double()
+        _ffi.check(_ffi.load().fmhip_dp_exchange_info(self.comm.handle, C.byref(mode), C.byref(cap), C.byref(mean)))
+        return dict(mode="touched" if mode.value == _ffi.EXCHANGE_TOUCHED else "dense", id_slots_per_rank=int(cap.value),
+                    mean_union_rows=float(mean.value))
 
     def step(self, fm, dataset, batch):
         """One global step; batch < 0: this rank contributes zeros."""

@@ -15,6 +15,8 @@ def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     transport = sys.argv[5] if len(sys.argv) > 5 else "rccl"
     fractions = tuple(float(x) for x in sys.argv[6].split(",") if x) if len(sys.argv) > 6 else None
+    exchange = sys.argv[7] if len(sys.argv) > 7 else "dense"
+    n1 = int(sys.argv[8]) if len(sys.argv) > 8 else 800         # a model wider than the data exercises the rows-only update
     dev = 0 if transport == "host" else rank
     import torch.distributed as dist
     from sparkfm_amd import DataSet, FMModel, synth
@@ -26,18 +28,18 @@ def main():
     else:
         d = dict(row_ptr=np.zeros(1, np.int64), col=np.zeros(0, np.int32), val=np.zeros(0, np.float32), y=np.zeros(0, np.float32))
     ds = DataSet.from_arrays(d, batch_rows=1000, device=dev).cache()
-    w0, w, v = synth.init_params(5, 800, 32, stdev=0.05)
-    w = np.random.default_rng(9).normal(0, 0.05, 800)
-    fm = FMModel(799, 32, device=dev)
+    w0, w, v = synth.init_params(5, n1, 32, stdev=0.05)
+    w = np.random.default_rng(9).normal(0, 0.05, n1)
+    fm = FMModel(n1 - 1, 32, device=dev)
     fm.w0, fm.w, fm.v = w0, w, v
     comm = HostStagedComm(fm, rank, world) if transport == "host" else RcclComm(fm, rank, world)
     kw = {} if fractions is None else {"upper_fractions": fractions}
-    dp = HipDataParallelSGD(comm, eta=0.05, regw=1e-3, regv=1e-3, **kw)
+    dp = HipDataParallelSGD(comm, eta=0.05, regw=1e-3, regv=1e-3, exchange=exchange, **kw)
     for _ in range(2):
         dp.learn(fm, ds)
     calls = np.array(getattr(comm, "calls", []), np.int64).reshape(-1, 2)
     np.savez(out + ".%d.npz" % rank, w0=fm.w0, w=fm.w, v=fm.v, cuts=np.array(dp.cuts), calls=calls,
-             rows=dp.last_stats["rows"], steps=dp.last_stats["steps"])
+             rows=dp.last_stats["rows"], steps=dp.last_stats["steps"], mean_union=dp.exchange_info()["mean_union_rows"])
     dist.barrier()
     comm.close()
     dist.destroy_process_group()

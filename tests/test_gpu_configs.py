@@ -316,6 +316,44 @@ def test_library_side_exchange_one_rank(fmhip, upper):
     np.testing.assert_array_equal(out[0][2], out[1][2])
 
 
+def test_touched_rows_exchange_one_rank_over_rccl(fmhip):
+    """fmhip_dp_exchange(FMHIP_EXCHANGE_TOUCHED) with a world of one rank over real RCCL (ncclAllGather of the ids, the
+    packed all-reduce, both in place): on a model far wider than the data the result must be bit-identical to the plain
+    step, which takes the same rows-only update with lazy weight decay; the union is the batch's touched rows."""
+    from sparkfm_amd import synth
+    from sparkfm_amd.distributed import HipDataParallelSGD, RcclComm
+    n1 = 200_000
+    d = synth.make_zipf(93, 6000, 900, 4, 30, zipf_s=1.05)
+    w0, w, v = synth.init_params(6, n1, 32, stdev=0.05)
+    w = np.random.default_rng(1).normal(0, 0.05, n1)
+    out = []
+    for mode in ("touched", "plain"):
+        ds = fmhip.DataSet.from_arrays(d, batch_rows=1500).cache()
+        fm = fmhip.FMModel(n1 - 1, 32)
+        fm.w0, fm.w, fm.v = w0, w, v
+        if mode == "touched":
+            comm = RcclComm(fm, 0, 1)
+            dp = HipDataParallelSGD(comm, eta=0.05, regw=1e-2, regv=1e-2, exchange="touched")
+            for _ in range(3):
+                dp.learn(fm, ds)
+            info = dp.exchange_info()
+            touched = [ds.batch_info(b)["n_columns"] for b in range(ds.n_batches)]
+            assert info["mode"] == "touched" and info["id_slots_per_rank"] >= max(touched)
+            assert min(touched) <= info["mean_union_rows"] <= max(touched) + 64 + 1       # + unused hot slots' padding entry
+            assert dp.last_stats["rows"] == 1500 and dp.last_stats["steps"] == 4
+            comm.close()
+        else:
+            sgd = fmhip.HipSGD(eta=0.05, regw=1e-2, regv=1e-2)
+            for _ in range(3):
+                sgd.learn(fm, ds)
+        out.append((fm.w0, fm.w.copy(), fm.v.copy()))
+        ds.unpersist()
+        fm.close()
+    assert out[0][0] == out[1][0]
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+
+
 def test_library_side_exchange_two_ranks():
     """Two ranks, two GPUs, RCCL inside the library (fmhip_dp_epoch): bit-identical replicas that match the
     oracle over the equivalent global batches; uneven shards (rank 1 runs out of batches first).  Needs a
@@ -336,13 +374,13 @@ def test_library_side_exchange_two_ranks():
     assert rel(r0["v"], v) <= 1e-5 and rel(r0["w"], w) <= 1e-5 and float(r0["w0"]) == pytest.approx(w0, rel=1e-5, abs=1e-7)
 
 
-def _oracle_two_rank_epochs():
+def _oracle_two_rank_epochs(n1=800):
     """The oracle over the global batches of dist_rccl_worker's two uneven shards (2 epochs of 3 steps)."""
     from sparkfm_amd import synth
     shards = [synth.make_zipf(77, 3000, 800, 4, 24, zipf_s=1.05, row_begin=0),
               synth.make_zipf(77, 1700, 800, 4, 24, zipf_s=1.05, row_begin=3000)]
-    w0, w, v = synth.init_params(5, 800, 32, stdev=0.05)
-    w = np.random.default_rng(9).normal(0, 0.05, 800)
+    w0, w, v = synth.init_params(5, n1, 32, stdev=0.05)
+    w = np.random.default_rng(9).normal(0, 0.05, n1)
     for _ in range(2):
         for j in range(3):                       # rank 0: 3 batches of 1000; rank 1: 2 (1000 + 700), then zeros
             rp, cols, vals, ys = [0], [], [], []
@@ -387,6 +425,36 @@ def test_library_side_exchange_two_ranks_on_one_gpu_host_staged(fractions, world
     per_step = 1 + (1 if n_cuts == 0 else 3 * (n_cuts + 1))
     assert len(sums) == 2 * 3 * per_step
     w0, w, v = _oracle_two_rank_epochs()
+    assert rel(r0["v"], v) <= 1e-5 and rel(r0["w"], w) <= 1e-5 and float(r0["w0"]) == pytest.approx(w0, rel=1e-5, abs=1e-7)
+
+
+@pytest.mark.parametrize("world,n1", [(2, 800), (3, 50_000)])
+def test_touched_rows_exchange_on_one_gpu_host_staged(world, n1):
+    """fmhip_dp_exchange(FMHIP_EXCHANGE_TOUCHED): the data-parallel step that exchanges only the gradient rows some rank
+    touched (all-gather of ids -> sorted union -> packed all-reduce -> rows-only update with lazy weight decay), with two and
+    three real ranks on one GPU over the host-staged transport; uneven shards, a rank without rows, a model of 50,000
+    features of which the data touch 800 (the untouched rows must decay exactly as in the oracle's dense update).
+    Replicas bit-identical, same collectives everywhere, the oracle over the global batches matched."""
+    import tempfile
+    port, out = str(_free_port()), os.path.join(tempfile.mkdtemp(), "dp")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_rccl_worker.py"), str(r), str(world), port, out, "host", "",
+                               "touched", str(n1)]) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    r0 = np.load(out + ".0.npz")
+    for r in range(1, world):
+        r1 = np.load(out + ".%d.npz" % r)
+        np.testing.assert_array_equal(r0["v"], r1["v"])
+        np.testing.assert_array_equal(r0["w"], r1["w"])
+        assert float(r0["w0"]) == float(r1["w0"])
+        np.testing.assert_array_equal(r0["calls"], r1["calls"])
+    assert int(r0["steps"]) == 3 and int(r0["rows"]) == 1000
+    kinds = r0["calls"][:, 0]
+    assert (kinds == 3).sum() == 6 and (kinds == 0).sum() == 12          # per step: one id all-gather, the row count + the packed rows
+    assert 0 < float(r0["mean_union"]) <= 801                             # the union of the touched rows, not the model
+    packed = r0["calls"][(kinds == 0) & (r0["calls"][:, 1] > 1)][:, 1]
+    assert packed.max() <= 32 + 801 * 34 and (packed < 0.1 * n1 * 34).all() or n1 == 800
+    w0, w, v = _oracle_two_rank_epochs(n1)
     assert rel(r0["v"], v) <= 1e-5 and rel(r0["w"], w) <= 1e-5 and float(r0["w0"]) == pytest.approx(w0, rel=1e-5, abs=1e-7)
 
 
