@@ -25,6 +25,8 @@ class HipSGD protected (eta: Double, reg0: Double, regw: Double, regv: Double, b
   @transient private var cached: DataSet = null
   /** relabel feature ids by descending frequency before the upload (off: ids go to the GPU as the loader produced them) */
   var relabel: Boolean = false
+  /** exchange only the gradient rows some rank touched instead of the dense gradient (models far wider than a global batch) */
+  var touchedRowsExchange: Boolean = false
   @transient private var rank: Array[Int] = null
   @transient private var byRank: Array[Int] = null
 
@@ -56,6 +58,7 @@ class HipSGD protected (eta: Double, reg0: Double, regw: Double, regv: Double, b
       if (model == 0L) model = HipSGD.modelCreate(device, fm.num_attribute, fm.num_factor)
       if (world > 1 && comm == 0L) {
         comm = HipSGD.commCreate(model, uniqueId, rank, world)
+        if (touchedRowsExchange) HipSGD.dpExchange(comm, 1)
         HipSGD.dpPlan(model, data, comm, Array(0.05, 0.15, 0.3, 0.55))   // cuts of the backward for the overlapped all-reduce
       }
       cached = dataset
@@ -132,6 +135,8 @@ object HipSGD {
   @native def commDestroy(h: Long): Unit
   @native def dpPlan(model: Long, data: Long, comm: Long, upperFractions: Array[Double]): Unit
   @native def dpEpoch(model: Long, data: Long, comm: Long, eta: Double, reg0: Double, regw: Double, regv: Double): Unit
+  /** 0 = dense packed gradient (default), 1 = touched rows only (Criteo-width models); every rank, before dpPlan */
+  @native def dpExchange(comm: Long, mode: Int): Unit
   /** [lo, hi) of `rank`, balanced by stored nonzeros (fmhip_shard_rows). */
   @native def shardRows(rowPtr: Array[Long], world: Int, rank: Int): Array[Long]
   // feature relabelling by frequency (a pure renaming; ids that arrive hashed or in dictionary order cost ~20 % of the forward):

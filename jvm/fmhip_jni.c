@@ -160,6 +160,9 @@ JNIEXPORT void JNI_FN(dpEpoch)(JNIEnv *env, jobject o, jlong m, jlong d, jlong c
     raise(env, fmhip_dp_epoch(H_MODEL(m), H_DATA(d), H_COMM(c), eta, r0, rw, rv, NULL));
 }
 
+/* what a data-parallel step exchanges: 0 = the dense packed gradient, 1 = only the rows some rank touched */
+JNIEXPORT void JNI_FN(dpExchange)(JNIEnv *env, jobject o, jlong c, jint mode) { raise(env, fmhip_dp_exchange(H_COMM(c), mode)); }
+
 JNIEXPORT jlongArray JNI_FN(shardRows)(JNIEnv *env, jobject o, jlongArray rp, jint world, jint rank) {
     jsize n = (*env)->GetArrayLength(env, rp);
     jlong *p = (*env)->GetPrimitiveArrayCritical(env, rp, NULL);
