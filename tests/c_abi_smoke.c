@@ -62,6 +62,27 @@ int main(void) {
     CHECK(covered == 5);
     CHECK(fmhip_shard_rows(5, row_ptr, 3, 0, &lo, &hi) == FMHIP_OK && lo == 0 && hi == 4);   /* 103 of 400 nonzeros is nearest to a third */
     CHECK(fmhip_shard_rows(5, row_ptr, 0, 0, &lo, &hi) == FMHIP_ERR_INVALID);
+    /* feature relabelling by frequency: host arithmetic (descending count, ties by ascending id) */
+    {
+        const int32_t col[9] = {4, 1, 4, 2, 4, 1, 0, 2, 5};
+        int32_t out[9], rank[6], by_rank[6];
+        int64_t counts[6] = {0, 0, 0, 0, 0, 0};
+        const int32_t want_by_rank[6] = {4, 1, 2, 0, 5, 3};      /* counts 1,2,2,0,3,1 */
+        int i;
+        CHECK(fmhip_feature_counts(5, col, 6, counts) == FMHIP_OK);
+        CHECK(fmhip_feature_counts(4, col + 5, 6, counts) == FMHIP_OK);    /* a second partition accumulates */
+        CHECK(counts[4] == 3 && counts[1] == 2 && counts[3] == 0);
+        CHECK(fmhip_rank_from_counts(6, counts, rank, by_rank) == FMHIP_OK);
+        for (i = 0; i < 6; ++i) CHECK(by_rank[i] == want_by_rank[i] && rank[by_rank[i]] == i);
+        CHECK(fmhip_relabel_columns(9, col, 6, rank, out) == FMHIP_OK);
+        for (i = 0; i < 9; ++i) CHECK(by_rank[out[i]] == col[i]);
+        CHECK(fmhip_relabel_columns(9, col, 5, rank, out) == FMHIP_ERR_INVALID);   /* id 5 outside [0, 5) */
+    }
+    /* communicator-side argument checks */
+    CHECK(fmhip_comm_create_external(NULL, 0, 1, NULL, NULL, NULL) == FMHIP_ERR_INVALID);
+    CHECK(fmhip_dp_exchange(NULL, FMHIP_EXCHANGE_TOUCHED) == FMHIP_ERR_INVALID);
+    CHECK(fmhip_dataset_hot_pages(NULL, NULL, NULL, NULL, NULL) == FMHIP_ERR_INVALID);
+    CHECK(FMHIP_HOT_PAGES * 16 <= 64 && FMHIP_COLL_ALLGATHER_I32 == 3);
     printf("c_abi_smoke ok (fmhip %d)\n", fmhip_version());
     return 0;
 }
