@@ -28,8 +28,11 @@
  *    runs forward -> backward -> all-reduce of the packed gradient (overlapped with the
  *    backward) -> update entirely inside the library — the reduction the reference's
  *    learner does itself inside `learn` (S/fm/lib/ALS.scala:153 `error.reduce(_+_)`).
- *    The packed gradient is also exposed (fmhip_grad_*) for a host that brings its own
- *    collective (fmhip_step_compute -> host all-reduce -> fmhip_step_apply).
+ *    fmhip_dp_exchange switches the step to exchanging only the rows some rank touched
+ *    (models far wider than a batch); fmhip_comm_create_external runs the same step over
+ *    a collective of the caller's instead of RCCL.  The packed gradient is also exposed
+ *    (fmhip_grad_*) for a host that orchestrates the step itself
+ *    (fmhip_step_compute -> host all-reduce -> fmhip_step_apply).
  *  - a handle must not be used from two threads at once.
  */
 #ifndef FMHIP_H
