@@ -510,7 +510,7 @@ def main():
     if not os.environ.get("FMHIP_BENCH_NO_EVENTS"):
         # one kernel kind on every 4th step, rotating (a pair of event records costs ~8 us of stream time): with the
         # default 200 steps every kind is timed 12-13 times and the timed region is perturbed by < 1 %
-        _ffi.check(L.fmhip_profile_begin_sampled(hm, 4 if args.steps >= 64 else 1))
+        _ffi.check(L.fmhip_profile_begin_sampled(hm, 4 if args.steps >= 64 else (2 if args.steps >= 16 else 1)))
     sync()
     barrier()
     t0 = time.perf_counter()
