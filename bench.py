@@ -355,6 +355,8 @@ def main():
                     help="C5 only: keep the hashed ids as generated instead of relabelling them by frequency at load")
     ap.add_argument("--hot-pages", type=int, default=0,
                     help="A/B: pages of the dense hot block (fmhip_tune key 12; 1 = the two-sided page only, default = library's 3)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="A/B: fmhip_tune(KEY, VALUE) before anything is built (repeatable); see include/fmhip.h")
     ap.add_argument("--cpu-budget", type=float, default=30.0)
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -399,6 +401,9 @@ def main():
 
     if args.hot_pages:
         _ffi.check(_ffi.load().fmhip_tune(12, args.hot_pages))
+    for kv in args.tune:
+        key, value = kv.split("=")
+        _ffi.check(_ffi.load().fmhip_tune(int(key), int(value)))
     synth.set_threads(max(1, host_cores() // max(1, min(world, 8))) if world > 1 else host_cores())
     t0 = time.time()
     d = synth.make_config(config, rows=rows, row_begin=rank * rows)
