@@ -201,12 +201,15 @@ def test_row_blocked_transposes(fmhip, rb):
         L.fmhip_tune(3, 0)
 
 
-def hot_problem(seed, n_rows, n1, k, n_hot, dup_feature=None, zero_feature=None):
+def hot_problem(seed, n_rows, n1, k, n_hot, dup_feature=None, zero_feature=None, n_low=0):
     """Rows over n1 features of which the first n_hot (scattered over the id range) occur in 15-95 % of
-    the rows; optionally one hot feature occurs twice in some rows / is stored with explicit zeros."""
+    the rows (the last n_low of them in 6.5-9 % only: dense on the gradient side, never in page 0); optionally one hot
+    feature occurs twice in some rows / is stored with explicit zeros."""
     rng = np.random.default_rng(seed)
     hot_ids = np.sort(rng.choice(n1, size=n_hot, replace=False))
     freq = rng.uniform(0.15, 0.95, n_hot)
+    if n_low:
+        freq[n_hot - n_low:] = rng.uniform(0.065, 0.09, n_low)
     cold = np.setdiff1d(np.arange(n1), hot_ids)
     rows, vals = [], []
     for r in range(n_rows):
@@ -296,6 +299,49 @@ def test_dense_hot_block(fmhip, request, k, n_hot, dup, zero, pages, flat):
         assert sgd.last_stats["sse"] == pytest.approx(sse, rel=1e-5)
     assert np.linalg.norm(fm.v - v) <= 1e-4 * np.linalg.norm(v)
     assert np.linalg.norm(fm.w - w) <= 1e-4 * np.linalg.norm(w)
+    ds.unpersist()
+    fm.close()
+
+
+@pytest.mark.parametrize("k,n_hot,n_low", [(32, 30, 27), (64, 12, 10), (16, 40, 39)])
+def test_dense_hot_block_with_a_thin_first_page(fmhip, k, n_hot, n_low):
+    """Few features pass the 10 % mark of the two-sided page, many the 5 % mark of the gradient-side pages: page 0 is
+    partly (or, with a single 10 % feature, not at all: then there is no hot block) filled, the others follow behind its
+    unused slots.  Layout, predictions, every batch's gradient, bit-exact transposes, two epochs."""
+    a, hot_ids = hot_problem(300 + k, 4000, 600, k, n_hot, n_low=n_low)
+    a["val"] = a["val"].astype(np.float32).astype(np.float64)
+    n_rows, br = 4000, 900
+    ds, fm = make(fmhip, a, batch_rows=br)
+    lay = ds.layout()
+    if n_hot - n_low < 2:
+        assert lay["hot_pages"] == 0 and lay["hot_ids_all"] == [] and lay["nnz_sparse_backward"] == len(a["col"])
+    else:
+        assert sorted(lay["hot_ids"]) == sorted(int(x) for x in hot_ids[:n_hot - n_low])
+        assert sorted(lay["hot_ids_all"]) == sorted(int(x) for x in hot_ids) and lay["hot_pages"] == 1 + (n_low + 15) // 16
+    yh = fm.predict(ds)
+    oy = oracle.predict(a["w0"], a["w"], a["v"], a["row_ptr"], a["col"], a["val"])
+    assert (np.abs(yh - oy) <= TOL_Y * term_scale(a)).all()
+    for j in range(ds.n_batches):
+        lo, hi = j * br, min(n_rows, (j + 1) * br)
+        gv, gw, g0, st = fm.batchGradient(ds, j)
+        ogv, ogw, og0, osse, _ = oracle.batch_grad(a["w0"], a["w"], a["v"], lo, hi, a["row_ptr"], a["col"], a["val"], a["y"], threads=4)
+        check_grad(gv, gw, ogv, ogw, np.abs(a["v"]).max())
+        sub = a["row_ptr"][lo:hi + 1] - a["row_ptr"][lo]
+        sl = slice(a["row_ptr"][lo], a["row_ptr"][hi])
+        cp, rows, cv = oracle.transpose(a["n1"], sub, a["col"][sl], a["val"][sl])
+        feat, ptr, drows, dvals = ds.transposeInput(j)
+        present = np.nonzero(np.diff(cp))[0]
+        np.testing.assert_array_equal(feat, present.astype(np.int32))
+        np.testing.assert_array_equal(drows, rows)
+        np.testing.assert_array_equal(dvals.astype(np.float64), cv)
+    eta, regs = 0.02, (0.0, 1e-3, 1e-3)
+    sgd = fmhip.HipSGD(eta=eta, reg0=regs[0], regw=regs[1], regv=regs[2])
+    w0, w, v = a["w0"], a["w"], a["v"]
+    for _ in range(2):
+        fm = sgd.learn(fm, ds)
+        w0, w, v, sse = oracle.sgd_epoch(w0, w, v, br, a["row_ptr"], a["col"], a["val"], a["y"], eta, *regs)
+        assert sgd.last_stats["sse"] == pytest.approx(sse, rel=1e-5)
+    assert np.linalg.norm(fm.v - v) <= 1e-4 * np.linalg.norm(v) and np.linalg.norm(fm.w - w) <= 1e-4 * np.linalg.norm(w)
     ds.unpersist()
     fm.close()
 
