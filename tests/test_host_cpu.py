@@ -4,6 +4,7 @@ classes, the synthetic generator, and the build entry point."""
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -297,3 +298,29 @@ def test_feature_order_utilities_are_host_arithmetic():
     assert L.fmhip_relabel_columns(3, bad.ctypes.data, 5, np.arange(5, dtype=np.int32).ctypes.data, bad.ctypes.data) == -1
     ident = FeatureOrder.identity(6)
     assert np.array_equal(ident.relabel(np.array([5, 0, 2], np.int32)), [5, 0, 2])
+
+
+def test_bench_roofline_helpers():
+    """bench.py's byte accounting and ceilings (pure arithmetic): ceilings stay between the Infinity-Cache and the L2
+    gather rates, grow with the L2 hit rate, fall back to the HBM gather rate only when nothing is known about a table
+    beyond the Infinity Cache; the backward's requested bytes follow the entries left in the transposes; the committed
+    PMC entries of the HBM-resident leg are found for the C5 configuration."""
+    sys.path.insert(0, ROOT)
+    import bench
+    lo, hi = bench.CEIL["mall_gather"], bench.CEIL["l2_gather"]
+    prev = 0.0
+    for h in (0.0, 0.3, 0.74, 1.0):
+        name, c, got = bench.gather_ceiling(32 << 20, h)
+        assert lo - 1 <= c <= hi + 1 and c > prev and got == h
+        prev = c
+    assert bench.gather_ceiling(1 << 20)[1] == pytest.approx(hi)                     # fits one XCD's L2
+    assert bench.gather_ceiling(9 << 30)[:2] == ("hbm_gather", bench.CEIL["hbm_gather"])
+    name, c, _ = bench.gather_ceiling(9 << 30, 0.68)
+    assert "upper bound" in name and lo < c < hi
+    base = bench.requested_bytes(32, 250_000, 10_000_000, 8_000_000, 90_000, True, 90_000, True, 100_001, False)
+    paged = bench.requested_bytes(32, 250_000, 10_000_000, 8_000_000, 90_000, True, 90_000, True, 100_001, False, 6_600_000, 4)
+    assert paged["forward"] == base["forward"] and paged["apply"] == base["apply"]
+    assert base["backward"] - paged["backward"] == 1_400_000 * (8 + 128 + 4) - 3 * 64 * 250_000
+    pmc = bench.committed_pmc("C5", 64, 250_000)
+    assert {"k_forward", "k_backward", "step"} <= set(pmc) and 0 < pmc["k_forward"]["l2_hit"] < 1
+    assert bench.alg_bytes(32) == {"forward": 140, "backward": 132, "step": 272}
