@@ -599,6 +599,60 @@ def main():
                        "note": "rank 0 alone, same shard and batch, dense update, no all-reduce"}
     barrier()
 
+    # ---- the N = 1 line's own workload under the exchange: C3 on every GPU (weak scaling in the strict sense — the driver's
+    # per-N values compare C3 at N = 1 with C4 at N > 1, two different widths; this leg is the like-for-like number)
+    twin = None
+    if exchange == "rccl" and dp.exchange == "dense" and config != "C3" and not args.no_extra:
+        c3 = synth.CONFIGS["C3"]
+        d3 = synth.make_config("C3", rows=1_000_000, row_begin=rank * 1_000_000)
+        ds3 = DataSet.from_arrays(d3, name="C3", batch_rows=250_000, device=local_rank).cache()
+        fm3 = FMModel(c3["features"] - 1, c3["k"], seed=c3["seed"] + 1000, device=local_rank, init_on_device=True)
+        nb3 = ds3.n_batches
+        nnz3 = [ds3.batch_info(b)["nnz"] for b in range(nb3)]
+
+        def step3(j):
+            _ffi.check(L.fmhip_dp_step(fm3.handle, ds3.handle, j % nb3, comm.handle, args.eta, regs[0], regs[1], regs[2]))
+        keep = dp.upper_fractions
+        best3 = None
+        for cand in ((), (0.3,), (0.12, 0.4), (0.05, 0.15, 0.3, 0.55)):        # a 13.6 MB gradient wants fewer cuts than C4's 136 MB
+            dp.upper_fractions = cand
+            dp.plan(fm3, ds3)
+            for j in range(3):
+                step3(j)
+            _ffi.check(L.fmhip_synchronize(fm3.handle))
+            barrier()
+            t0 = time.perf_counter()
+            for j in range(8):
+                step3(j)
+            _ffi.check(L.fmhip_synchronize(fm3.handle))
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            if best3 is None or float(tt[0]) < best3[0]:
+                best3 = (float(tt[0]), cand)
+        dp.upper_fractions = best3[1]
+        dp.plan(fm3, ds3)
+        for j in range(4):
+            step3(j)
+        _ffi.check(L.fmhip_synchronize(fm3.handle))
+        barrier()
+        t0 = time.perf_counter()
+        for j in range(args.steps):
+            step3(j)
+        _ffi.check(L.fmhip_synchronize(fm3.handle))
+        barrier()
+        t3 = torch.tensor([time.perf_counter() - t0, float(sum(nnz3[j % nb3] for j in range(args.steps)))], dtype=torch.float64)
+        tm = t3.clone()
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t3, op=dist.ReduceOp.SUM)
+        twin = {"workload": "C3 on every GPU: 1000000 rows x 100000 features per GPU, k=32, batch 250000 rows per GPU — the N = 1 line's workload",
+                "value": float(t3[1]) / float(tm[0]), "unit": "nnz/s", "ms_per_step": float(tm[0]) / args.steps * 1e3,
+                "allreduce_bytes_per_step": 4 * (32 + (c3["features"] + 31) // 32 * 32 * 34), "cuts": list(dp.cuts)}
+        ds3.unpersist()
+        fm3.close()
+        dp.upper_fractions = keep
+        dp.plan(fm, ds)
+        barrier()
+
     if rank == 0:
         ab = alg_bytes(k)
         kp = 32
@@ -690,6 +744,8 @@ def main():
                 busy = max(cprof["comm_ms"] / cprof["steps"], 1e-9)
                 xc["alg_GBps"] = payload / busy / 1e6
                 xc["bus_GBps"] = payload * (2.0 * (world - 1) / max(world, 1)) / busy / 1e6
+            if twin:
+                xc["c3_on_every_gpu"] = twin
             if no_exchange:
                 xc["per_gpu_without_exchange"] = no_exchange
                 xc["efficiency_vs_no_exchange"] = value / (world * no_exchange["value"])
