@@ -279,7 +279,46 @@ def hbm_resident_leg(device, steps=24, rows=500_000, batch_rows=250_000):
                    "so an upper bound on HBM bytes).  frac_of_8TBps = fabric bytes / this run's step time / 8 TB/s.",
            "kernels": kern, "last_batch_mse": st.sse / max(st.rows, 1), "nonfinite": st.nonfinite}
     ds.unpersist()
-    fm.close()
+    fm.close(discard=True)
+    return out
+
+
+def c4_one_gpu_leg(device, eta, regs, rows=10_000_000, batch_rows=625_000, passes=3):
+    """BASELINE config 4 — ALL of its 10M rows x 1M features, k=32 — on ONE GPU with the data-parallel runs' batch of
+    625k rows and the plain step: the denominator the N > 1 lines (C4 sharded over N GPUs) are to be divided by, in the
+    driver-run N = 1 record."""
+    from sparkfm_amd import DataSet, FMModel, _ffi, synth
+    L = _ffi.load()
+    cfg = synth.CONFIGS["C4"]
+    t0 = time.time()
+    d = synth.make_config("C4", rows=rows)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    ds = DataSet.from_arrays(d, name="C4", batch_rows=batch_rows, device=device).cache()
+    t_load = time.time() - t0
+    fm = FMModel(cfg["features"] - 1, cfg["k"], seed=cfg["seed"] + 1000, device=device, init_on_device=True)
+    hm, hd, nb = fm.handle, ds.handle, ds.n_batches
+    nnz = int(d["row_ptr"][-1])
+    for j in range(nb):
+        _ffi.check(L.fmhip_sgd_step(hm, hd, j, eta, *regs, None))
+    _ffi.check(L.fmhip_synchronize(hm))
+    st0 = _ffi.Stats()
+    _ffi.check(L.fmhip_step_stats(hm, C.byref(st0)))
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        for j in range(nb):
+            _ffi.check(L.fmhip_sgd_step(hm, hd, j, eta, *regs, None))
+    _ffi.check(L.fmhip_synchronize(hm))
+    dt = time.perf_counter() - t0
+    st = _ffi.Stats()
+    _ffi.check(L.fmhip_step_stats(hm, C.byref(st)))
+    out = {"workload": "C4 on one GPU: %d rows x %d features, k=%d, batch %d rows (%d batches), the plain step (fmhip_sgd_step), %d passes" %
+                       (rows, cfg["features"], cfg["k"], batch_rows, nb, passes),
+           "value": nnz * passes / dt, "unit": "nnz/s", "ms_per_step": dt / (passes * nb) * 1e3, "steps": passes * nb, "nnz": nnz,
+           "last_batch_mse_after_first_pass": st0.sse / max(st0.rows, 1), "last_batch_mse": st.sse / max(st.rows, 1),
+           "nonfinite": st.nonfinite, "setup_s": {"generate": t_gen, "load_transpose_h2d": t_load}}
+    ds.unpersist()
+    fm.close(discard=True)
     return out
 
 
@@ -338,9 +377,15 @@ def main():
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"],
                     help="rccl: the library's own communicator (fmhip_dp_step); torch: torch.distributed all-reduce "
                          "orchestrated from Python (sparkfm_amd.distributed.DataParallelSGD)")
-    ap.add_argument("--dp-exchange", default="auto", choices=["auto", "dense", "touched"],
-                    help="what a data-parallel step exchanges (fmhip_dp_exchange): the whole packed gradient in overlapped slices, or only "
-                         "the rows some rank touched; auto = touched for C5 (a 8.9 GB gradient), dense otherwise")
+    ap.add_argument("--dp-exchange", default="auto", choices=["auto", "dense", "sharded", "touched"],
+                    help="what a data-parallel step exchanges (fmhip_dp_exchange): dense = the whole packed gradient all-reduced in "
+                         "overlapped slices, every rank updates every row; sharded = the slices reduce-scattered, every rank updates its "
+                         "1/N share, the updated rows all-gathered; touched = only the rows some rank touched; auto = touched for C5 "
+                         "(an 8.9 GB gradient), otherwise dense and sharded are both timed during warm-up and the faster is kept")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
+                    help="rccl: one rank per GPU, the library's RCCL communicator; host: ALL ranks on GPU 0, the library's step over "
+                         "fmhip_comm_create_external with every collective staged through the host and summed by gloo — the same "
+                         "schedule, plan and update, for boxes with fewer GPUs than ranks (a rehearsal, not a measurement)")
     ap.add_argument("--upper-fractions", default="auto",
                     help="cuts of the backward for the overlapped exchange: comma-separated ascending shares of the nonzeros at or "
                          "above each cut (e.g. 0.3 or 0.12,0.4), 'none' = one all-reduce after the whole backward, 'auto' = "
@@ -375,6 +420,8 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if args.transport == "host":
+        local_rank = 0                      # every rank shares the one GPU; the collectives are staged through the host
     torch.cuda.set_device(local_rank)
     use_dp = world > 1 or args.force_dp
     exchange = args.exchange if use_dp else "none"
@@ -390,7 +437,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from sparkfm_amd import DataSet, FMModel, _ffi, synth
-    from sparkfm_amd.distributed import DataParallelSGD, HipDataParallelSGD, RcclComm, torch_stream_handle
+    from sparkfm_amd.distributed import DataParallelSGD, HipDataParallelSGD, HostStagedComm, RcclComm, torch_stream_handle
 
     config = args.config or ("C4" if world > 1 else "C3")
     cfg = synth.CONFIGS[config]
@@ -435,10 +482,10 @@ def main():
     comm_note = None
     if exchange == "rccl":
         try:
-            comm = RcclComm(fm, rank, world)
+            comm = HostStagedComm(fm, rank, world) if args.transport == "host" else RcclComm(fm, rank, world)
             fixed = None if args.upper_fractions == "auto" else (() if args.upper_fractions == "none" else
                                                                  tuple(float(x) for x in args.upper_fractions.split(",")))
-            dp_mode = args.dp_exchange if args.dp_exchange != "auto" else ("touched" if cfg.get("criteo") else "dense")
+            dp_mode = args.dp_exchange if args.dp_exchange != "auto" else ("touched" if cfg.get("criteo") else "sharded")
             dp = HipDataParallelSGD(comm, eta=args.eta, reg0=regs[0], regw=regs[1], regv=regs[2], exchange=dp_mode,
                                     upper_fractions=fixed if fixed is not None else (0.05, 0.15, 0.3, 0.55))
             dp.plan(fm, ds)
@@ -447,8 +494,10 @@ def main():
                     raise SystemExit("--emulate-allreduce is for one-rank runs")
                 emu_ranks, emu_busbw = args.emulate_allreduce.split(":")
                 emu_ranks, emu_busbw = int(emu_ranks), float(emu_busbw)
-                # ring all-reduce: 2(N-1)/N of the payload crosses each rank's links -> payload rate = busbw * N / (2(N-1))
+                # ring all-reduce: 2(N-1)/N of the payload crosses each rank's links -> payload rate = busbw * N / (2(N-1));
+                # the sharded update's reduce-scatter and all-gather are half of that each, and this rank plays rank 0 of N
                 _ffi.check(L.fmhip_comm_emulate(comm.handle, emu_busbw * emu_ranks / (2.0 * (emu_ranks - 1))))
+                _ffi.check(L.fmhip_comm_emulate_ranks(comm.handle, emu_ranks))
         except Exception as ex:   # noqa: BLE001 — reported in the JSON line, never silent
             # every rank fails or succeeds together (communicator creation is collective); fall back to the
             # Python-orchestrated exchange over torch.distributed
@@ -489,24 +538,32 @@ def main():
     sync()
     barrier()
     tuning = None
-    if exchange == "rccl" and dp.exchange == "dense" and args.upper_fractions == "auto" and (world > 1 or args.emulate_allreduce):
-        # measure, don't guess: the best cut depends on the all-reduce's real bandwidth on this node
+    if exchange == "rccl" and dp.exchange != "touched" and args.upper_fractions == "auto" and (world > 1 or args.emulate_allreduce):
+        # measure, don't guess: the best cut — and whether the sharded update pays — depends on the collectives' real
+        # bandwidth on this node.  Candidates are timed for 4 steps each; the ranks agree through a max-reduce.
         tuning = []
-        for cand in ((0.3,), (0.2,), (0.12, 0.4), (0.08, 0.25, 0.5), (0.05, 0.15, 0.3, 0.55), (0.04, 0.1, 0.2, 0.35, 0.6), ()):
-            dp.upper_fractions = cand
-            dp.plan(fm, ds)
-            step(0)
-            sync()
-            barrier()
-            t0 = time.perf_counter()
-            for j in range(4):
-                step(j)
-            sync()
-            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-            if use_dp:
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            tuning.append({"upper_fractions": list(cand), "cuts": list(dp.cuts), "ms_per_step": float(tt[0]) / 4 * 1e3})
+        modes = ("sharded", "dense") if args.dp_exchange == "auto" else (dp.exchange,)
+        cands = ((0.3,), (0.2,), (0.12, 0.4), (0.08, 0.25, 0.5), (0.05, 0.15, 0.3, 0.55), (0.04, 0.1, 0.2, 0.35, 0.6), ())
+        if args.transport == "host":
+            cands = ((0.12, 0.4), ())        # a rehearsal of the flow: every step moves the whole gradient through the host
+        for mode in modes:
+            dp.set_exchange(mode)
+            for cand in cands:
+                dp.upper_fractions = cand
+                dp.plan(fm, ds)
+                step(0)
+                sync()
+                barrier()
+                t0 = time.perf_counter()
+                for j in range(4):
+                    step(j)
+                sync()
+                tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+                if use_dp:
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                tuning.append({"exchange": mode, "upper_fractions": list(cand), "cuts": list(dp.cuts), "ms_per_step": float(tt[0]) / 4 * 1e3})
         best = min(tuning, key=lambda x: x["ms_per_step"])
+        dp.set_exchange(best["exchange"])
         dp.upper_fractions = tuple(best["upper_fractions"])
         dp.plan(fm, ds)
         step(0)
@@ -582,7 +639,7 @@ def main():
         sustained = {"seconds": dt, "steps": n_done, "value": s_nnz / dt, "unit": "nnz/s", "ms_per_step": dt / n_done * 1e3}
 
     # ---- the same shard and batch WITHOUT the exchange (what one GPU of the job does alone)
-    no_exchange = None
+    no_exchange = one_gpu_plain = None
     if use_dp and rank == 0 and not args.no_extra:
         sync()
         for j in range(4):
@@ -597,12 +654,24 @@ def main():
         dt = time.perf_counter() - t0
         no_exchange = {"value": sum(bnnz[j % nb] for j in range(args.steps)) / dt, "unit": "nnz/s", "ms_per_step": dt / args.steps * 1e3,
                        "note": "rank 0 alone, same shard and batch, dense update, no all-reduce"}
+        # ... and the plain one-GPU step (fmhip_sgd_step: the update merged into the fixup launch or rows-only, as N = 1 runs
+        # it) on the same shard and batch: the denominator for this line's scaling, measured in the same process
+        for j in range(4):
+            _ffi.check(L.fmhip_sgd_step(hm, hd, j % nb, args.eta, *regs, None))
+        sync()
+        t0 = time.perf_counter()
+        for j in range(args.steps):
+            _ffi.check(L.fmhip_sgd_step(hm, hd, j % nb, args.eta, *regs, None))
+        sync()
+        dt = time.perf_counter() - t0
+        one_gpu_plain = {"value": sum(bnnz[j % nb] for j in range(args.steps)) / dt, "unit": "nnz/s", "ms_per_step": dt / args.steps * 1e3,
+                         "note": "rank 0 alone, same shard and batch, the plain one-GPU step (fmhip_sgd_step), while the other ranks wait"}
     barrier()
 
     # ---- the N = 1 line's own workload under the exchange: C3 on every GPU (weak scaling in the strict sense — the driver's
     # per-N values compare C3 at N = 1 with C4 at N > 1, two different widths; this leg is the like-for-like number)
     twin = None
-    if exchange == "rccl" and dp.exchange == "dense" and config != "C3" and not args.no_extra:
+    if exchange == "rccl" and dp.exchange != "touched" and config != "C3" and not args.no_extra:
         c3 = synth.CONFIGS["C3"]
         d3 = synth.make_config("C3", rows=1_000_000, row_begin=rank * 1_000_000)
         ds3 = DataSet.from_arrays(d3, name="C3", batch_rows=250_000, device=local_rank).cache()
@@ -612,23 +681,26 @@ def main():
 
         def step3(j):
             _ffi.check(L.fmhip_dp_step(fm3.handle, ds3.handle, j % nb3, comm.handle, args.eta, regs[0], regs[1], regs[2]))
-        keep = dp.upper_fractions
+        keep, keep_mode = dp.upper_fractions, dp.exchange
         best3 = None
-        for cand in ((), (0.3,), (0.12, 0.4), (0.05, 0.15, 0.3, 0.55)):        # a 13.6 MB gradient wants fewer cuts than C4's 136 MB
-            dp.upper_fractions = cand
-            dp.plan(fm3, ds3)
-            for j in range(3):
-                step3(j)
-            _ffi.check(L.fmhip_synchronize(fm3.handle))
-            barrier()
-            t0 = time.perf_counter()
-            for j in range(8):
-                step3(j)
-            _ffi.check(L.fmhip_synchronize(fm3.handle))
-            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            if best3 is None or float(tt[0]) < best3[0]:
-                best3 = (float(tt[0]), cand)
+        for mode3 in (("sharded", "dense") if args.dp_exchange == "auto" else (dp.exchange,)):
+            dp.set_exchange(mode3)
+            for cand in ((), (0.3,), (0.12, 0.4), (0.05, 0.15, 0.3, 0.55)):        # a 13.6 MB gradient wants fewer cuts than C4's 136 MB
+                dp.upper_fractions = cand
+                dp.plan(fm3, ds3)
+                for j in range(3):
+                    step3(j)
+                _ffi.check(L.fmhip_synchronize(fm3.handle))
+                barrier()
+                t0 = time.perf_counter()
+                for j in range(8):
+                    step3(j)
+                _ffi.check(L.fmhip_synchronize(fm3.handle))
+                tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                if best3 is None or float(tt[0]) < best3[0]:
+                    best3 = (float(tt[0]), cand, mode3)
+        dp.set_exchange(best3[2])
         dp.upper_fractions = best3[1]
         dp.plan(fm3, ds3)
         for j in range(4):
@@ -646,9 +718,10 @@ def main():
         dist.all_reduce(t3, op=dist.ReduceOp.SUM)
         twin = {"workload": "C3 on every GPU: 1000000 rows x 100000 features per GPU, k=32, batch 250000 rows per GPU — the N = 1 line's workload",
                 "value": float(t3[1]) / float(tm[0]), "unit": "nnz/s", "ms_per_step": float(tm[0]) / args.steps * 1e3,
-                "allreduce_bytes_per_step": 4 * (32 + (c3["features"] + 31) // 32 * 32 * 34), "cuts": list(dp.cuts)}
+                "allreduce_bytes_per_step": 4 * (32 + (c3["features"] + 31) // 32 * 32 * 34), "cuts": list(dp.cuts), "exchange": dp.exchange}
         ds3.unpersist()
-        fm3.close()
+        fm3.close(discard=True)
+        dp.set_exchange(keep_mode)
         dp.upper_fractions = keep
         dp.plan(fm, ds)
         barrier()
@@ -695,10 +768,13 @@ def main():
                                            "share_of_nonzeros_left_to_the_forward": lay["nnz_sparse"] / max(int(d["row_ptr"][-1]), 1),
                                            "share_of_nonzeros_left_to_the_backward": lay["nnz_sparse_backward"] / max(int(d["row_ptr"][-1]), 1)},
                        "parallelism": "dp%d" % world, "exchange": exchange,
-                       "allreduce": ("inside the library (RCCL), touched rows only" if exchange == "rccl" and dp.exchange == "touched" else
-                                     "inside the library (RCCL), overlapped with the feature-chunked backward, cuts at features %s" % dp.cuts
+                       "transport": ("host-staged gloo over fmhip_comm_create_external, all ranks on GPU 0 (a rehearsal of the N-rank flow, "
+                                     "not a measurement)" if args.transport == "host" and use_dp else ("RCCL" if use_dp else "none")),
+                       "allreduce": ("inside the library, touched rows only" if exchange == "rccl" and dp.exchange == "touched" else
+                                     ("inside the library, %s, overlapped with the feature-chunked backward, cuts at features %s" %
+                                      ("reduce-scatter -> sharded update -> all-gather" if dp.exchange == "sharded" else "all-reduce, every rank updates every row", dp.cuts))
                                      if exchange == "rccl" and dp.cuts else
-                                     ("inside the library (RCCL), one all-reduce per step" if exchange == "rccl" else
+                                     ("inside the library, one %s per step" % ("reduce-scatter + all-gather" if dp.exchange == "sharded" else "all-reduce") if exchange == "rccl" else
                                       ("torch.distributed, orchestrated from Python" if exchange == "torch" else "none")))},
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
@@ -728,10 +804,11 @@ def main():
             gf = C.c_int64()
             _ffi.check(L.fmhip_grad_floats(hm, C.byref(gf)))
             payload = int(gf.value) * 4
-            xc = {"nranks": world, "allreduce_bytes_per_step": payload, "backend": exchange}
+            xc = {"nranks": world, "allreduce_bytes_per_step": payload, "backend": exchange, "transport": args.transport,
+                  "mode": dp.exchange if exchange == "rccl" else "dense"}
             if exchange == "rccl" and dp.exchange == "touched":
                 info = dp.exchange_info()
-                xc["mode"] = "touched rows (fmhip_dp_exchange): all-gather of ids, sorted union, packed all-reduce, rows-only update"
+                xc["mode_note"] = "touched rows (fmhip_dp_exchange): all-gather of ids, sorted union, packed all-reduce, rows-only update"
                 xc["dense_gradient_bytes"] = payload
                 xc["id_slots_per_rank"] = info["id_slots_per_rank"]
                 xc["mean_union_rows"] = info["mean_union_rows"]
@@ -749,6 +826,11 @@ def main():
             if no_exchange:
                 xc["per_gpu_without_exchange"] = no_exchange
                 xc["efficiency_vs_no_exchange"] = value / (world * no_exchange["value"])
+            if one_gpu_plain:
+                # the like-for-like scaling of THIS line: the job's throughput over what one GPU does alone on the same workload
+                # (C4's shard and batch, the plain step) — the driver's N = 1 line is C3, another width
+                xc["c4_one_gpu"] = one_gpu_plain
+                xc["scaling_vs_c4_one_gpu"] = value / one_gpu_plain["value"]
             if comm_note:
                 xc["note"] = comm_note
             if tuning:
@@ -761,12 +843,17 @@ def main():
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
         if world == 1 and not args.no_extra and not use_dp:
             ds.unpersist()
-            fm.close()
+            fm.close(discard=True)
+            del d
             extra = {}
             try:
                 extra["hbm_resident"] = hbm_resident_leg(local_rank)
             except Exception as ex:   # noqa: BLE001
                 extra["hbm_resident"] = {"error": repr(ex)}
+            try:
+                extra["c4_one_gpu"] = c4_one_gpu_leg(local_rank, args.eta, regs)
+            except Exception as ex:   # noqa: BLE001
+                extra["c4_one_gpu"] = {"error": repr(ex)}
             extra["als_c1"] = als_c1(local_rank)
             out["extra"] = extra
         os.write(json_fd, (json.dumps(out) + "\n").encode())

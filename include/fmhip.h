@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define FMHIP_VERSION 200 /* 0.2.0 */
+#define FMHIP_VERSION 300 /* 0.3.0 */
 
 enum {
     FMHIP_OK = 0,
@@ -292,6 +292,9 @@ int fmhip_comm_info(fmhip_comm_t c, int *rank, int *world);
 #define FMHIP_COLL_MAX_I64 1
 #define FMHIP_COLL_BCAST0_I64 2
 #define FMHIP_COLL_ALLGATHER_I32 3 /* device_buf holds world x count int32, rank r's own at r * count: fill in the others' */
+/* the sharded update (FMHIP_EXCHANGE_SHARDED): device_buf holds world x count floats, segment r at r * count */
+#define FMHIP_COLL_REDUCE_SCATTER_F32 4 /* on return rank r's segment holds the sum over all ranks of that segment (the other segments: unspecified) */
+#define FMHIP_COLL_ALLGATHER_F32 5      /* rank r's own segment is in place: fill in the others' */
 typedef int (*fmhip_collective_fn)(void *ctx, void *device_buf, size_t count, int kind, void *hip_stream);
 int fmhip_comm_create_external(fmhip_model_t m, int rank, int world, fmhip_collective_fn fn, void *ctx, fmhip_comm_t *out);
 /* What a host-staged transport needs and cannot reach from the JVM / ctypes by itself: wait for a stream; copy
@@ -307,9 +310,18 @@ int fmhip_device_write(void *device_dst, const void *host_src, size_t bytes, voi
  *                           applied with the rows-only update (weight decay rides in the tables' scale: 0.5 <= 1 - eta*reg <= 1
  *                           required).  For models far wider than a global batch — C5's 2^25 x 64 table is 8.9 GB dense and
  *                           ~0.1 of that here.  No overlap with the backward; one 4-byte read-back per step.
+ *   FMHIP_EXCHANGE_SHARDED  the dense exchange with the UPDATE sharded too: each interval's G_V slice is reduce-scattered (rank r
+ *                           receives the summed rows of its 1/world share of the interval), rank r updates just those rows of V and
+ *                           zeroes them, the updated rows are all-gathered in place into every replica's V.  Same bytes on the wire as
+ *                           the all-reduce (it IS a ring all-reduce cut in two), but the update and the zeroing of the gradient — 4 x
+ *                           the model's bytes, paid by EVERY rank in the dense mode — shrink world-fold, and the replicas are identical
+ *                           by construction (one writer per row).  G_w / G_b (1/32 of the bytes) are still all-reduced and every rank
+ *                           steps all of w.  Interval edges are rounded to multiples of `world`; needs the library's own gradient
+ *                           buffer (fmhip_grad_bind: only if n+1 is a multiple of world) and world <= 64.
  * fmhip_dp_exchange_info: the mode, the id slots per rank agreed by the plan, the mean |U| of the steps so far. */
 #define FMHIP_EXCHANGE_DENSE 0
 #define FMHIP_EXCHANGE_TOUCHED 1
+#define FMHIP_EXCHANGE_SHARDED 2
 int fmhip_dp_exchange(fmhip_comm_t c, int mode);
 int fmhip_dp_exchange_info(fmhip_comm_t c, int *mode, int64_t *id_slots_per_rank, double *mean_union_rows);
 /* Chooses the feature ids that cut the backward into intervals and broadcasts them from rank 0 (collective).
@@ -339,6 +351,10 @@ typedef struct fmhip_comm_profile {
  * that payload would take at that rate — so the overlap schedule can be timed with one rank.  0 = off.
  * (Optimistic: a real collective also takes CUs and memory bandwidth from the backward beside it.) */
 int fmhip_comm_emulate(fmhip_comm_t c, double payload_gb_per_s);
+/* ... and for the sharded update: pretend to be rank 0 of `ranks` (one real rank only): intervals are cut into `ranks` shares,
+ * this rank updates and zeroes only the first, the reduce-scatter / all-gather delays are those of `ranks` GPUs (half an
+ * all-reduce each).  The rows of the other shares are NOT updated — a timing aid, not a training mode.  0 = off. */
+int fmhip_comm_emulate_ranks(fmhip_comm_t c, int ranks);
 int fmhip_comm_profile_begin(fmhip_comm_t c);
 int fmhip_comm_profile_end(fmhip_comm_t c, fmhip_comm_profile *p);
 /* Contiguous row shard [lo, hi) of `rank`, balanced by stored nonzeros (not by row count): the

@@ -2,9 +2,17 @@
  * fmhip_jni.c — JNI shim between jvm/HipSGD.scala and libfmhip.so (include/fmhip.h).
  *
  * SOURCE ONLY: the build image has no JDK (no jni.h), so this file has never been compiled here.  It is
- * deliberately nothing but marshalling: every function pins the Java arrays, calls ONE entry point of the
- * C ABI with plain pointers and sizes, unpins, and turns a non-zero status into a RuntimeException that
- * carries fmhip_last_error().  Build on a machine with a JDK:
+ * deliberately nothing but marshalling: every function obtains the Java arrays, calls ONE entry point of the
+ * C ABI with plain pointers and sizes, releases them, and turns a non-zero status into a RuntimeException that
+ * carries fmhip_last_error().
+ *
+ * Array access.  Calls that run long or block — the dataset build (a multi-second host pass, hipMalloc, stream syncs),
+ * parameter transfers, scoring, the O(nnz) relabelling helpers — take the arrays with Get<Type>ArrayElements (the VM
+ * may copy; the garbage collector keeps running).  GetPrimitiveArrayCritical is used only around the one short,
+ * non-blocking call (shardRows: a binary search): a critical region locks out the collector for every thread of an
+ * executor.
+ *
+ * Build on a machine with a JDK:
  *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude jvm/fmhip_jni.c \
  *       -Lsparkfm_amd/lib -lfmhip -Wl,-rpath,'$ORIGIN' -o libfmhip_jni.so
  * Scala `object HipSGD` natives are static methods of class io.edstud.spark.fm.lib.HipSGD$ ("_00024" = '$').
@@ -25,21 +33,24 @@ static void raise(JNIEnv *env, int rc) {
         (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/RuntimeException"), fmhip_last_error());
 }
 
-/* pinned views of the CSR arrays of one call (jlong == int64_t, jint == int32_t, jdouble == double) */
+/* views of the CSR arrays of one call (jlong == int64_t, jint == int32_t, jdouble == double); the calls that use them
+ * are long ones: Get<Type>ArrayElements, not critical regions.  y_mode: how `y` is released (JNI_ABORT = an input,
+ * 0 = an output to copy back) */
 typedef struct { jlong *rp; jint *col; jdouble *val; jdouble *y; } csr_pins;
 
-static void pin(JNIEnv *env, csr_pins *p, jlongArray rp, jintArray col, jdoubleArray val, jdoubleArray y) {
-    p->rp = (*env)->GetPrimitiveArrayCritical(env, rp, NULL);
-    p->col = col ? (*env)->GetPrimitiveArrayCritical(env, col, NULL) : NULL;
-    p->val = val ? (*env)->GetPrimitiveArrayCritical(env, val, NULL) : NULL;
-    p->y = y ? (*env)->GetPrimitiveArrayCritical(env, y, NULL) : NULL;
+static int pin(JNIEnv *env, csr_pins *p, jlongArray rp, jintArray col, jdoubleArray val, jdoubleArray y) {
+    p->rp = (*env)->GetLongArrayElements(env, rp, NULL);
+    p->col = col ? (*env)->GetIntArrayElements(env, col, NULL) : NULL;
+    p->val = val ? (*env)->GetDoubleArrayElements(env, val, NULL) : NULL;
+    p->y = y ? (*env)->GetDoubleArrayElements(env, y, NULL) : NULL;
+    return p->rp && (!col || p->col) && (!val || p->val) && (!y || p->y);     /* 0: OutOfMemoryError is pending */
 }
 
-static void unpin(JNIEnv *env, csr_pins *p, jlongArray rp, jintArray col, jdoubleArray val, jdoubleArray y) {
-    if (p->y) (*env)->ReleasePrimitiveArrayCritical(env, y, p->y, JNI_ABORT);
-    if (p->val) (*env)->ReleasePrimitiveArrayCritical(env, val, p->val, JNI_ABORT);
-    if (p->col) (*env)->ReleasePrimitiveArrayCritical(env, col, p->col, JNI_ABORT);
-    (*env)->ReleasePrimitiveArrayCritical(env, rp, p->rp, JNI_ABORT);
+static void unpin(JNIEnv *env, csr_pins *p, jlongArray rp, jintArray col, jdoubleArray val, jdoubleArray y, jint y_mode) {
+    if (p->y) (*env)->ReleaseDoubleArrayElements(env, y, p->y, y_mode);
+    if (p->val) (*env)->ReleaseDoubleArrayElements(env, val, p->val, JNI_ABORT);
+    if (p->col) (*env)->ReleaseIntArrayElements(env, col, p->col, JNI_ABORT);
+    if (p->rp) (*env)->ReleaseLongArrayElements(env, rp, p->rp, JNI_ABORT);
 }
 
 JNIEXPORT jlong JNI_FN(modelCreate)(JNIEnv *env, jobject o, jint dev, jlong n, jint k) {
@@ -51,33 +62,38 @@ JNIEXPORT jlong JNI_FN(modelCreate)(JNIEnv *env, jobject o, jint dev, jlong n, j
 JNIEXPORT void JNI_FN(modelDestroy)(JNIEnv *env, jobject o, jlong h) { raise(env, fmhip_model_destroy(H_MODEL(h))); }
 
 JNIEXPORT void JNI_FN(setParams)(JNIEnv *env, jobject o, jlong h, jdouble w0, jdoubleArray w, jdoubleArray v) {
-    jdouble *pw = (*env)->GetPrimitiveArrayCritical(env, w, NULL);
-    jdouble *pv = (*env)->GetPrimitiveArrayCritical(env, v, NULL);
-    int rc = fmhip_model_set_params(H_MODEL(h), w0, pw, pv);
-    (*env)->ReleasePrimitiveArrayCritical(env, v, pv, JNI_ABORT);
-    (*env)->ReleasePrimitiveArrayCritical(env, w, pw, JNI_ABORT);
-    raise(env, rc);
+    jdouble *pw = (*env)->GetDoubleArrayElements(env, w, NULL);
+    jdouble *pv = (*env)->GetDoubleArrayElements(env, v, NULL);
+    int rc = FMHIP_ERR_NOMEM;
+    if (pw && pv) rc = fmhip_model_set_params(H_MODEL(h), w0, pw, pv);
+    if (pv) (*env)->ReleaseDoubleArrayElements(env, v, pv, JNI_ABORT);
+    if (pw) (*env)->ReleaseDoubleArrayElements(env, w, pw, JNI_ABORT);
+    if (pw && pv) raise(env, rc);
 }
 
 JNIEXPORT void JNI_FN(getParams)(JNIEnv *env, jobject o, jlong h, jdoubleArray w0, jdoubleArray w, jdoubleArray v) {
-    jdouble *p0 = (*env)->GetPrimitiveArrayCritical(env, w0, NULL);
-    jdouble *pw = (*env)->GetPrimitiveArrayCritical(env, w, NULL);
-    jdouble *pv = (*env)->GetPrimitiveArrayCritical(env, v, NULL);
-    int rc = fmhip_model_get_params(H_MODEL(h), p0, pw, pv);
-    (*env)->ReleasePrimitiveArrayCritical(env, v, pv, 0);        /* 0: copy back */
-    (*env)->ReleasePrimitiveArrayCritical(env, w, pw, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, w0, p0, 0);
-    raise(env, rc);
+    jdouble p0 = 0.0;
+    jdouble *pw = (*env)->GetDoubleArrayElements(env, w, NULL);
+    jdouble *pv = (*env)->GetDoubleArrayElements(env, v, NULL);
+    int rc = FMHIP_ERR_NOMEM;
+    if (pw && pv) rc = fmhip_model_get_params(H_MODEL(h), &p0, pw, pv);
+    if (pv) (*env)->ReleaseDoubleArrayElements(env, v, pv, 0);        /* 0: copy back */
+    if (pw) (*env)->ReleaseDoubleArrayElements(env, w, pw, 0);
+    if (pw && pv) {
+        (*env)->SetDoubleArrayRegion(env, w0, 0, 1, &p0);
+        raise(env, rc);
+    }
 }
 
 JNIEXPORT jlong JNI_FN(datasetCreate)(JNIEnv *env, jobject o, jint dev, jlong n_rows, jlongArray rp, jintArray col,
                                       jdoubleArray val, jdoubleArray y, jlong batch_rows) {
     csr_pins p;
     fmhip_dataset_t d = NULL;
-    pin(env, &p, rp, col, val, y);
-    int rc = fmhip_dataset_create(dev, n_rows, (const int64_t *)p.rp, (const int32_t *)p.col, p.val, p.y, batch_rows, &d);
-    unpin(env, &p, rp, col, val, y);
-    raise(env, rc);
+    const int ok = pin(env, &p, rp, col, val, y);
+    int rc = FMHIP_ERR_NOMEM;
+    if (ok) rc = fmhip_dataset_create(dev, n_rows, (const int64_t *)p.rp, (const int32_t *)p.col, p.val, p.y, batch_rows, &d);
+    unpin(env, &p, rp, col, val, y, JNI_ABORT);
+    if (ok) raise(env, rc);
     return (jlong)(intptr_t)d;
 }
 
@@ -85,10 +101,11 @@ JNIEXPORT jlong JNI_FN(rowsCreate)(JNIEnv *env, jobject o, jint dev, jlong n_row
                                    jdoubleArray val, jdoubleArray y) {
     csr_pins p;
     fmhip_dataset_t d = NULL;
-    pin(env, &p, rp, col, val, y);
-    int rc = fmhip_rows_create(dev, n_rows, (const int64_t *)p.rp, (const int32_t *)p.col, p.val, p.y, &d);
-    unpin(env, &p, rp, col, val, y);
-    raise(env, rc);
+    const int ok = pin(env, &p, rp, col, val, y);
+    int rc = FMHIP_ERR_NOMEM;
+    if (ok) rc = fmhip_rows_create(dev, n_rows, (const int64_t *)p.rp, (const int32_t *)p.col, p.val, p.y, &d);
+    unpin(env, &p, rp, col, val, y, JNI_ABORT);
+    if (ok) raise(env, rc);
     return (jlong)(intptr_t)d;
 }
 
@@ -105,22 +122,27 @@ JNIEXPORT jdouble JNI_FN(rmse)(JNIEnv *env, jobject o, jlong m, jlong d) {
 }
 
 JNIEXPORT void JNI_FN(predict)(JNIEnv *env, jobject o, jlong m, jlong d, jdoubleArray yhat) {
-    jdouble *py = (*env)->GetPrimitiveArrayCritical(env, yhat, NULL);
+    jdouble *py = (*env)->GetDoubleArrayElements(env, yhat, NULL);
+    if (!py) return;                                             /* OutOfMemoryError is pending */
     int rc = fmhip_predict(H_MODEL(m), H_DATA(d), py);
-    (*env)->ReleasePrimitiveArrayCritical(env, yhat, py, 0);
+    (*env)->ReleaseDoubleArrayElements(env, yhat, py, 0);
     raise(env, rc);
 }
 
 JNIEXPORT void JNI_FN(predictRows)(JNIEnv *env, jobject o, jlong m, jlong n_rows, jlongArray rp, jintArray col,
                                    jdoubleArray val, jdoubleArray yhat) {
     csr_pins p;
-    pin(env, &p, rp, col, val, yhat);
-    int rc = fmhip_predict_rows(H_MODEL(m), n_rows, (const int64_t *)p.rp, (const int32_t *)p.col, p.val, p.y);
-    /* yhat is an output: copy back (mode 0), the inputs are released without a copy */
-    (*env)->ReleasePrimitiveArrayCritical(env, yhat, p.y, 0);
-    p.y = NULL;
-    unpin(env, &p, rp, col, val, NULL);
-    raise(env, rc);
+    const int ok = pin(env, &p, rp, col, val, yhat);
+    int rc = FMHIP_ERR_NOMEM;
+    if (ok) rc = fmhip_predict_rows(H_MODEL(m), n_rows, (const int64_t *)p.rp, (const int32_t *)p.col, p.val, p.y);
+    unpin(env, &p, rp, col, val, yhat, 0);     /* yhat is an output: copied back (mode 0); the inputs are released without a copy */
+    if (ok) raise(env, rc);
+}
+
+JNIEXPORT jint JNI_FN(deviceCount)(JNIEnv *env, jobject o) {
+    int n = 0;
+    raise(env, fmhip_device_count(&n));
+    return n;
 }
 
 JNIEXPORT jbyteArray JNI_FN(commUniqueId)(JNIEnv *env, jobject o) {
@@ -160,7 +182,7 @@ JNIEXPORT void JNI_FN(dpEpoch)(JNIEnv *env, jobject o, jlong m, jlong d, jlong c
     raise(env, fmhip_dp_epoch(H_MODEL(m), H_DATA(d), H_COMM(c), eta, r0, rw, rv, NULL));
 }
 
-/* what a data-parallel step exchanges: 0 = the dense packed gradient, 1 = only the rows some rank touched */
+/* what a data-parallel step exchanges: FMHIP_EXCHANGE_DENSE 0, _TOUCHED 1, _SHARDED 2 */
 JNIEXPORT void JNI_FN(dpExchange)(JNIEnv *env, jobject o, jlong c, jint mode) { raise(env, fmhip_dp_exchange(H_COMM(c), mode)); }
 
 JNIEXPORT jlongArray JNI_FN(shardRows)(JNIEnv *env, jobject o, jlongArray rp, jint world, jint rank) {
@@ -182,32 +204,35 @@ JNIEXPORT jlongArray JNI_FN(shardRows)(JNIEnv *env, jobject o, jlongArray rp, ji
  * byRank; relabelColumns rewrites `col` in place */
 JNIEXPORT void JNI_FN(featureCounts)(JNIEnv *env, jobject o, jintArray col, jlong n1, jlongArray counts) {
     jsize nnz = (*env)->GetArrayLength(env, col);
-    jint *c = (*env)->GetPrimitiveArrayCritical(env, col, NULL);
-    jlong *k = (*env)->GetPrimitiveArrayCritical(env, counts, NULL);
-    int rc = fmhip_feature_counts((int64_t)nnz, (const int32_t *)c, (int64_t)n1, (int64_t *)k);
-    (*env)->ReleasePrimitiveArrayCritical(env, counts, k, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, col, c, JNI_ABORT);
-    raise(env, rc);
+    jint *c = (*env)->GetIntArrayElements(env, col, NULL);
+    jlong *k = (*env)->GetLongArrayElements(env, counts, NULL);
+    int rc = FMHIP_ERR_NOMEM;
+    if (c && k) rc = fmhip_feature_counts((int64_t)nnz, (const int32_t *)c, (int64_t)n1, (int64_t *)k);
+    if (k) (*env)->ReleaseLongArrayElements(env, counts, k, 0);
+    if (c) (*env)->ReleaseIntArrayElements(env, col, c, JNI_ABORT);
+    if (c && k) raise(env, rc);
 }
 
 JNIEXPORT void JNI_FN(rankFromCounts)(JNIEnv *env, jobject o, jlongArray counts, jintArray rank, jintArray byRank) {
     jsize n1 = (*env)->GetArrayLength(env, counts);
-    jlong *k = (*env)->GetPrimitiveArrayCritical(env, counts, NULL);
-    jint *r = (*env)->GetPrimitiveArrayCritical(env, rank, NULL);
-    jint *b = (*env)->GetPrimitiveArrayCritical(env, byRank, NULL);
-    int rc = fmhip_rank_from_counts((int64_t)n1, (const int64_t *)k, (int32_t *)r, (int32_t *)b);
-    (*env)->ReleasePrimitiveArrayCritical(env, byRank, b, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, rank, r, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, counts, k, JNI_ABORT);
-    raise(env, rc);
+    jlong *k = (*env)->GetLongArrayElements(env, counts, NULL);
+    jint *r = (*env)->GetIntArrayElements(env, rank, NULL);
+    jint *b = (*env)->GetIntArrayElements(env, byRank, NULL);
+    int rc = FMHIP_ERR_NOMEM;
+    if (k && r && b) rc = fmhip_rank_from_counts((int64_t)n1, (const int64_t *)k, (int32_t *)r, (int32_t *)b);
+    if (b) (*env)->ReleaseIntArrayElements(env, byRank, b, 0);
+    if (r) (*env)->ReleaseIntArrayElements(env, rank, r, 0);
+    if (k) (*env)->ReleaseLongArrayElements(env, counts, k, JNI_ABORT);
+    if (k && r && b) raise(env, rc);
 }
 
 JNIEXPORT void JNI_FN(relabelColumns)(JNIEnv *env, jobject o, jintArray col, jintArray rank) {
     jsize nnz = (*env)->GetArrayLength(env, col), n1 = (*env)->GetArrayLength(env, rank);
-    jint *c = (*env)->GetPrimitiveArrayCritical(env, col, NULL);
-    jint *r = (*env)->GetPrimitiveArrayCritical(env, rank, NULL);
-    int rc = fmhip_relabel_columns((int64_t)nnz, (const int32_t *)c, (int64_t)n1, (const int32_t *)r, (int32_t *)c);
-    (*env)->ReleasePrimitiveArrayCritical(env, rank, r, JNI_ABORT);
-    (*env)->ReleasePrimitiveArrayCritical(env, col, c, 0);
-    raise(env, rc);
+    jint *c = (*env)->GetIntArrayElements(env, col, NULL);
+    jint *r = (*env)->GetIntArrayElements(env, rank, NULL);
+    int rc = FMHIP_ERR_NOMEM;
+    if (c && r) rc = fmhip_relabel_columns((int64_t)nnz, (const int32_t *)c, (int64_t)n1, (const int32_t *)r, (int32_t *)c);
+    if (r) (*env)->ReleaseIntArrayElements(env, rank, r, JNI_ABORT);
+    if (c) (*env)->ReleaseIntArrayElements(env, col, c, 0);
+    if (c && r) raise(env, rc);
 }

@@ -31,7 +31,7 @@ SYMBOLS = (
     "fmhip_dp_step", "fmhip_dp_epoch", "fmhip_comm_profile_begin", "fmhip_comm_profile_end", "fmhip_shard_rows", "fmhip_comm_emulate",
     "fmhip_feature_counts", "fmhip_rank_from_counts", "fmhip_relabel_columns", "fmhip_dataset_hot_pages",
     "fmhip_comm_create_external", "fmhip_stream_wait", "fmhip_device_read", "fmhip_device_write",
-    "fmhip_dp_exchange", "fmhip_dp_exchange_info",
+    "fmhip_dp_exchange", "fmhip_dp_exchange_info", "fmhip_comm_emulate_ranks",
 )
 UNIQUE_ID_BYTES = 128
 
@@ -59,8 +59,9 @@ class DatasetOpts(C.Structure):
 
 # int fn(void *ctx, void *device_buf, size_t count, int kind, void *hip_stream) — fmhip_comm_create_external
 CollectiveFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
-COLL_SUM_F32, COLL_MAX_I64, COLL_BCAST0_I64, COLL_ALLGATHER_I32 = 0, 1, 2, 3
-EXCHANGE_DENSE, EXCHANGE_TOUCHED = 0, 1
+COLL_SUM_F32, COLL_MAX_I64, COLL_BCAST0_I64, COLL_ALLGATHER_I32, COLL_REDUCE_SCATTER_F32, COLL_ALLGATHER_F32 = 0, 1, 2, 3, 4, 5
+EXCHANGE_DENSE, EXCHANGE_TOUCHED, EXCHANGE_SHARDED = 0, 1, 2
+EXCHANGE_MODES = {"dense": EXCHANGE_DENSE, "touched": EXCHANGE_TOUCHED, "sharded": EXCHANGE_SHARDED}
 
 
 class CommProfile(C.Structure):
@@ -151,6 +152,7 @@ def load():
     L.fmhip_dp_step.argtypes = [vp, vp, i64, vp, dbl, dbl, dbl, dbl]
     L.fmhip_dp_epoch.argtypes = [vp, vp, vp, dbl, dbl, dbl, dbl, P(Stats)]
     L.fmhip_comm_emulate.argtypes = [vp, dbl]
+    L.fmhip_comm_emulate_ranks.argtypes = [vp, C.c_int]
     L.fmhip_comm_profile_begin.argtypes = [vp]
     L.fmhip_comm_profile_end.argtypes = [vp, P(CommProfile)]
     L.fmhip_shard_rows.argtypes = [i64, vp, C.c_int, C.c_int, P(i64), P(i64)]

@@ -34,6 +34,22 @@ __global__ __launch_bounds__(kBlock) void k_apply_rows(ApplyArgs a) {
     if (a.do_w0) apply_w0(a, invb);
 }
 
+// Sharded update (fmhip_comm.hip): the V rows of a feature interval are updated by their owning rank only and come
+// back through the all-gather, but w (4 bytes per feature against 4*Kp) is stepped by every rank from the all-reduced
+// G_w: the rows [w_lo, w_hi) that k_apply does not visit on this rank ([row_lo, row_hi) is its own share) — the same
+// operations as apply_piece<KP, false>'s linear-weight branch, so every replica holds the same bits.
+__global__ __launch_bounds__(kBlock) void k_apply_w(ApplyArgs a) {
+    const float invb = apply_invb(a);
+    for (int64_t i = a.w_lo + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.w_hi; i += (int64_t)gridDim.x * kBlock) {
+        if (i >= a.row_lo && i < a.row_hi) continue;
+        const float us = a.w[i], gi = a.Gw[i] * invb;
+        const float wi = us * a.sw_in;
+        a.w[i] = wi - a.eta * fmaf(a.regw, wi, gi);
+        a.Gw[i] = 0.f;
+        a.Gb[i] = 0.f;
+    }
+}
+
 
 // ------------------------------------------------------------------ init
 // `new FMModel(n, k)` on the device (S/fm/FMModel.scala:17-22): v ~ N(mean, stdev), w = 0, w0 = 0.
@@ -91,6 +107,14 @@ hipError_t launch_init_normal(int Kp, float *V, float *w, float *w0, int64_t n1,
     if (blocks > 16384) blocks = 16384;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_init_normal, dim3((unsigned)blocks), dim3(kBlock), 0, s, V, w, w0, n1, n1p, k, Kp, seed, mean, stdev);
+    return hipGetLastError();
+}
+
+hipError_t launch_apply_w(const ApplyArgs &a, hipStream_t s) {
+    if (a.w_hi <= a.w_lo) return hipSuccess;
+    int64_t blocks = (a.w_hi - a.w_lo + kBlock - 1) / kBlock;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_apply_w, dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 

@@ -1083,6 +1083,42 @@ int step_apply_interval(fmhip_model_t m, double eta, double reg0, double regw, d
     return FMHIP_OK;
 }
 
+int step_apply_shard(fmhip_model_t m, double eta, double reg0, double regw, double regv, int64_t lo, int64_t hi, int64_t vlo,
+                     int64_t vhi, const float *rows, bool last, hipStream_t s) {
+    ApplyArgs a{};
+    a.sv_in = (float)m->sv;
+    a.sw_in = (float)m->sw;
+    a.eta_v = a.eta_w = (float)eta;
+    a.V = m->V.p;
+    a.w = m->w.p;
+    a.w0 = m->w0.p;
+    a.GV = m->GV();
+    a.Gw = m->Gw();
+    a.Gb = m->Gb();
+    a.scal = m->scal();
+    a.rows = rows;
+    a.n1 = m->n1;
+    hi = std::min(hi, m->n1);
+    a.row_lo = std::min(std::max(vlo, lo), hi);
+    a.row_hi = std::min(std::max(vhi, a.row_lo), hi);
+    a.w_lo = lo;
+    a.w_hi = hi;
+    a.do_w0 = last ? 1 : 0;
+    a.pack_k = m->pack_k();
+    a.eta = (float)eta;
+    a.reg0 = (float)reg0;
+    a.regw = (float)regw;
+    a.regv = (float)regv;
+    if (a.row_hi > a.row_lo || last) HIP_TRY(launch_apply(m->Kp, a, s));
+    HIP_TRY(launch_apply_w(a, s));
+    if (last) {
+        m->sv = m->sw = 1.0;      // every share folded the pending scale; the all-gather spreads the folded rows
+        m->host64_fresh = false;
+        ++m->prof_step;
+    }
+    return FMHIP_OK;
+}
+
 // can weight decay ride in the tables' scale for this (eta, reg)?  (no decay at all: trivially)
 bool lazy_decay_ok(double eta, double regw, double regv) {
     const double dv = 1.0 - eta * regv, dw = 1.0 - eta * regw;
@@ -1259,8 +1295,9 @@ int fmhip_model_create(int device, int64_t num_attribute, int32_t num_factor, vo
         m->own_stream = true;
     }
     int rc;
-    if ((rc = m->V.alloc((size_t)m->n1p * m->Kp)) || (rc = m->w.alloc((size_t)m->n1p)) || (rc = m->w0.alloc(1)) ||
-        (rc = m->grad_own.alloc(m->grad_floats())) || (rc = m->acc.alloc(4))) {
+    const size_t slack = (size_t)fmhip_model::kSlackRows * m->Kp;       // zero rows behind the tables (sharded exchange)
+    if ((rc = m->V.alloc((size_t)m->n1p * m->Kp + slack)) || (rc = m->w.alloc((size_t)m->n1p)) || (rc = m->w0.alloc(1)) ||
+        (rc = m->grad_own.alloc(m->grad_floats() + slack)) || (rc = m->acc.alloc(4))) {
         fmhip_model_destroy(m);
         return rc;
     }
@@ -1269,7 +1306,7 @@ int fmhip_model_create(int device, int64_t num_attribute, int32_t num_factor, vo
     if (e == hipSuccess) e = hipMemsetAsync(m->V.p, 0, m->V.n * sizeof(float), m->stream);
     if (e == hipSuccess) e = hipMemsetAsync(m->w.p, 0, m->w.n * sizeof(float), m->stream);
     if (e == hipSuccess) e = hipMemsetAsync(m->w0.p, 0, sizeof(float), m->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(m->grad, 0, m->grad_floats() * sizeof(float), m->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(m->grad, 0, m->grad_own.n * sizeof(float), m->stream);
     if (e == hipSuccess) e = hipMemsetAsync(m->acc.p, 0, 4 * sizeof(double), m->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
     if (e != hipSuccess) {

@@ -18,6 +18,17 @@
 // The CSC stream is sorted by feature id, so the backward can deliver the gradient rows of an interval of
 // ids at a time; the cold interval is nearly all of the gradient's volume and under half of the work.
 // More cuts give a deeper pipeline (the collective of interval i runs beside the backward of interval i+1).
+//
+// FMHIP_EXCHANGE_SHARDED — the same exchange with the update sharded as well (three streams):
+//   compute stream  forward | backward(int n-1) | backward(int n-2) | ... | backward(int 0) + statistics | wait(last all-gather, zeroing)
+//   comm stream     rows    |                   | RS(n-1)           | RS(n-2) AG(n-1) | RS(n-3) AG(n-2) ...| RS(0) AG(1) AG(0)
+//   apply stream                                        | upd(n-1) zero     | upd(n-2) zero ...                  | upd(0) zero
+// RS(i) = reduce-scatter of interval i's G_V rows (+ all-reduce of its G_w / G_b entries, 1/Kp of the bytes, one grouped
+// call); upd(i) = this rank's 1/world share of the interval's V rows (and all of its w), zero = the other shares' gradient
+// rows; AG(i) = all-gather of the updated V rows into every replica.  RS + AG moves the bytes of the all-reduce it
+// replaces; the update and the zeroing — 4x the model's bytes on EVERY rank in the dense mode — shrink world-fold.
+// AG(i) is queued behind RS(i-1): the comm stream never idles waiting for an update (queued right behind RS(i) it cost
+// the emulated 8 x 300 GB/s step 0.18 ms of bubbles, profiles/r03_experiments.md).
 #include "fmhip_internal.h"
 
 #include <dlfcn.h>
@@ -45,6 +56,7 @@ struct Rccl {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclReduceScatter) ReduceScatter = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -74,6 +86,7 @@ Rccl &rccl() {
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
         r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+        r.ReduceScatter = reinterpret_cast<decltype(r.ReduceScatter)>(sym("ncclReduceScatter"));
         r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
@@ -154,11 +167,17 @@ __global__ __launch_bounds__(256) void k_unpack_rows(const int32_t *u, int32_t n
     }
 }
 
+// The event set of ONE profiled step.  Sets are created in fmhip_comm_profile_begin (a pool), never inside a step: an
+// event creation costs the host tens of microseconds, and the pass that uses them is the one that measures what the
+// exchange leaves exposed.
+constexpr int kProfColl = 2 * (kMaxCuts + 1) + 2;     // sharded mode: a reduce-scatter and an all-gather per interval
+constexpr int kProfSteps = 32;                        // steps a profiling pass can record (later ones go unrecorded)
 struct CommProf {
     hipEvent_t wait_a = nullptr, wait_b = nullptr;   // compute stream: around its wait for the last collective
-    hipEvent_t c0[kMaxCuts + 1] = {}, c1[kMaxCuts + 1] = {};   // comm stream: around each collective
+    hipEvent_t c0[kProfColl] = {}, c1[kProfColl] = {};         // comm stream: around each collective
     hipEvent_t a0[kMaxCuts + 1] = {}, a1[kMaxCuts + 1] = {};   // compute stream: around each interval's update
     int n_coll = 0, n_apply = 0;
+    bool used = false;
 };
 
 }  // namespace
@@ -186,8 +205,17 @@ struct fmhip_comm {
     int64_t *scratch = nullptr;               // device int64[kMaxCuts + 1] for the small control collectives
     double emu_bytes_per_us = 0.0;            // > 0: every collective is followed by a delay of bytes / this (fmhip_comm_emulate)
     bool profiling = false;
-    std::vector<CommProf> prof;
+    std::vector<CommProf> prof;               // the pool of event sets (fmhip_comm_profile_begin)
+    size_t prof_next = 0;                     // sets handed out since _begin
     int64_t prof_bytes = 0;
+    // sharded update (FMHIP_EXCHANGE_SHARDED)
+    hipStream_t as = nullptr;                 // the updates' (and the gradient zeroing's) stream
+    hipEvent_t ev_applied[kMaxCuts + 1] = {}; // apply stream: this rank's share of interval i is updated (its all-gather may start)
+    hipEvent_t ev_gathered = nullptr;         // comm stream: behind the last all-gather enqueued
+    int emu_ranks = 0;                        // > 0: one real rank plays rank 0 of this many (fmhip_comm_emulate_ranks)
+    // agreed by fmhip_dp_plan over all ranks: the largest mini-batch of any rank (rows), so that every size check of a
+    // step passes or fails on every rank alike
+    int64_t plan_max_rows = -1;
 };
 
 namespace {
@@ -195,9 +223,37 @@ namespace {
 void destroy_events(CommProf &p) {
     for (hipEvent_t e : {p.wait_a, p.wait_b})
         if (e) (void)hipEventDestroy(e);
-    for (int i = 0; i <= kMaxCuts; ++i)
-        for (hipEvent_t e : {p.c0[i], p.c1[i], p.a0[i], p.a1[i]})
+    for (int i = 0; i < kProfColl; ++i)
+        for (hipEvent_t e : {p.c0[i], p.c1[i]})
             if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i <= kMaxCuts; ++i)
+        for (hipEvent_t e : {p.a0[i], p.a1[i]})
+            if (e) (void)hipEventDestroy(e);
+    p = CommProf();
+}
+
+int create_events(CommProf &p) {
+    hipError_t e = hipEventCreate(&p.wait_a);
+    if (e == hipSuccess) e = hipEventCreate(&p.wait_b);
+    for (int i = 0; i < kProfColl && e == hipSuccess; ++i) {
+        e = hipEventCreate(&p.c0[i]);
+        if (e == hipSuccess) e = hipEventCreate(&p.c1[i]);
+    }
+    for (int i = 0; i <= kMaxCuts && e == hipSuccess; ++i) {
+        e = hipEventCreate(&p.a0[i]);
+        if (e == hipSuccess) e = hipEventCreate(&p.a1[i]);
+    }
+    if (e != hipSuccess) return fail(FMHIP_ERR_HIP, "profiling events: %s", hipGetErrorString(e));
+    return FMHIP_OK;
+}
+
+// the event set of the step being enqueued (NULL: not profiling, or the pool is used up)
+CommProf *next_prof(fmhip_comm_t c) {
+    if (!c->profiling || c->prof_next >= c->prof.size()) return nullptr;
+    CommProf *p = &c->prof[c->prof_next++];
+    p->used = true;
+    p->n_coll = p->n_apply = 0;
+    return p;
 }
 
 // one collective on `s`: through RCCL, or handed to the caller's transport
@@ -214,8 +270,22 @@ int collective(fmhip_comm_t c, void *buf, size_t count, int kind, hipStream_t s)
         case FMHIP_COLL_ALLGATHER_I32:     // in place: rank r's `count` elements already sit at buf + r * count
             NCCL_TRY(rccl().AllGather(static_cast<int32_t *>(buf) + (size_t)c->rank * count, buf, count, ncclInt32, c->comm, s));
             break;
+        case FMHIP_COLL_REDUCE_SCATTER_F32:  // in place: rank r receives the sum of segment r where it already lies
+            NCCL_TRY(rccl().ReduceScatter(buf, static_cast<float *>(buf) + (size_t)c->rank * count, count, ncclFloat, ncclSum, c->comm, s));
+            break;
+        case FMHIP_COLL_ALLGATHER_F32:
+            NCCL_TRY(rccl().AllGather(static_cast<float *>(buf) + (size_t)c->rank * count, buf, count, ncclFloat, c->comm, s));
+            break;
         default: return fail(FMHIP_ERR_INVALID, "unknown collective kind %d", kind);
     }
+    return FMHIP_OK;
+}
+
+// holds stream `s` for the time `bytes` would take at the emulated payload rate (fmhip_comm_emulate)
+int emu_delay(fmhip_comm_t c, double bytes, hipStream_t s) {
+    if (c->emu_bytes_per_us <= 0.0 || bytes <= 0.0) return FMHIP_OK;
+    hipLaunchKernelGGL(k_comm_delay, dim3(1), dim3(64), 0, s, (uint64_t)(bytes / c->emu_bytes_per_us * 100.0));
+    HIP_TRY(hipGetLastError());
     return FMHIP_OK;
 }
 
@@ -236,10 +306,8 @@ int reduce_regions(fmhip_model_t m, fmhip_comm_t c, const Region *reg, int n_reg
     HIP_TRY(hipEventRecord(after, m->stream));
     HIP_TRY(hipStreamWaitEvent(c->cs, after, 0));
     int pi = -1;
-    if (pr) {
+    if (pr && pr->n_coll < kProfColl) {
         pi = pr->n_coll++;
-        HIP_TRY(hipEventCreate(&pr->c0[pi]));
-        HIP_TRY(hipEventCreate(&pr->c1[pi]));
         HIP_TRY(hipEventRecord(pr->c0[pi], c->cs));
     }
     size_t bytes = 0;
@@ -251,12 +319,8 @@ int reduce_regions(fmhip_model_t m, fmhip_comm_t c, const Region *reg, int n_reg
         bytes += reg[i].n * sizeof(float);
     }
     if (group) NCCL_TRY(rccl().GroupEnd());
-    if (c->emu_bytes_per_us > 0.0) {
-        const double us = (double)bytes / c->emu_bytes_per_us;
-        hipLaunchKernelGGL(k_comm_delay, dim3(1), dim3(64), 0, c->cs, (uint64_t)(us * 100.0));
-        HIP_TRY(hipGetLastError());
-    }
-    if (pr) HIP_TRY(hipEventRecord(pr->c1[pi], c->cs));
+    TRY(emu_delay(c, (double)bytes, c->cs));
+    if (pi >= 0) HIP_TRY(hipEventRecord(pr->c1[pi], c->cs));
     HIP_TRY(hipEventRecord(done, c->cs));
     c->prof_bytes += c->profiling ? (int64_t)bytes : 0;
     return FMHIP_OK;
@@ -311,9 +375,6 @@ int dp_step_touched(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_com
         feat = d->cfeat.p + bm.col_off;
         n_hot = d->hot_pages * kHotT;
         hot = d->d_hot_ids.p;
-        if ((int64_t)n_feat + n_hot > c->cap)
-            return fail(FMHIP_ERR_INVALID, "batch %lld touches %d rows, the plan allows %lld: call fmhip_dp_plan with this dataset (every rank)",
-                        (long long)batch, n_feat + n_hot, (long long)c->cap);
     }
     const float my_rows = live ? (float)d->batches[(size_t)batch].rows : 0.f;
     hipLaunchKernelGGL(k_set_float, dim3(1), dim3(1), 0, m->stream, c->rows_dev, my_rows);
@@ -356,16 +417,8 @@ int dp_step_touched(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_com
     return FMHIP_OK;
 }
 
-int dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0, double regw, double regv) {
-    if (c->exchange == FMHIP_EXCHANGE_TOUCHED) return dp_step_touched(m, d, batch, c, eta, reg0, regw, regv);
+int dp_step_dense(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0, double regw, double regv) {
     const bool live = batch >= 0;
-    if (d->rb_rows != 0 && !c->cuts.empty())
-        return fail(FMHIP_ERR_INVALID, "the communicator's plan cuts the backward, but this dataset's transposes are row-blocked: "
-                                       "call fmhip_dp_plan with this dataset (every rank)");
-    // the global row count travels as one fp32 sum: exact below 2^24 rows per global batch
-    if (live && (double)d->batches[(size_t)batch].rows * c->world >= 16777216.0)
-        return fail(FMHIP_ERR_INVALID, "a global batch of %lld x %d rows exceeds 2^24: use smaller batches",
-                    (long long)d->batches[(size_t)batch].rows, c->world);
     // |B| first: every interval's update divides by the GLOBAL row count, so it is exchanged on its own (4 bytes,
     // hidden under the forward) instead of waiting for the head in the last message
     const float my_rows = live ? (float)d->batches[(size_t)batch].rows : 0.f;
@@ -382,11 +435,7 @@ int dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, d
         m->grad_dirty = true;
         m->last_nnz = m->last_rows = 0;
     }
-    CommProf *pr = nullptr;
-    if (c->profiling) {
-        c->prof.emplace_back();
-        pr = &c->prof.back();
-    }
+    CommProf *pr = next_prof(c);
     // intervals [edge[i], edge[i+1]) from the top down; the lowest one carries the statistics scalars
     std::vector<int64_t> edge{0};
     for (int64_t x : c->cuts)
@@ -409,11 +458,7 @@ int dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, d
         }
     }
     m->bw_next_hi = -1;
-    if (pr) {
-        HIP_TRY(hipEventCreate(&pr->wait_a));
-        HIP_TRY(hipEventCreate(&pr->wait_b));
-        HIP_TRY(hipEventRecord(pr->wait_a, m->stream));
-    }
+    if (pr) HIP_TRY(hipEventRecord(pr->wait_a, m->stream));
     // update every interval as its slice arrives (identical on all ranks: replicas stay bit-identical); intervals of
     // less than an eighth of the rows wait for the next one and share its launch (a launch costs more than they do)
     int64_t pend_hi = -1;
@@ -423,18 +468,165 @@ int dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, d
         const bool last = i == 0;
         HIP_TRY(hipStreamWaitEvent(m->stream, c->ev_done[i], 0));
         if (!last && (pend_hi - lo) * 8 < m->n1) continue;
-        if (pr) {
-            const int ai = pr->n_apply++;
-            HIP_TRY(hipEventCreate(&pr->a0[ai]));
-            HIP_TRY(hipEventCreate(&pr->a1[ai]));
-            HIP_TRY(hipEventRecord(pr->a0[ai], m->stream));
-        }
+        if (pr) HIP_TRY(hipEventRecord(pr->a0[pr->n_apply++], m->stream));
         TRY(step_apply_interval(m, eta, reg0, regw, regv, lo, pend_hi, c->rows_dev, last));
         if (pr) HIP_TRY(hipEventRecord(pr->a1[pr->n_apply - 1], m->stream));
         pend_hi = -1;
     }
     if (pr) HIP_TRY(hipEventRecord(pr->wait_b, m->stream));
     return FMHIP_OK;
+}
+
+// rounds the shares of [0, n+1) for `world` ranks: every interval edge is a multiple of world, the top one rounded UP
+// (into the zero rows kept behind the tables, fmhip_model::kSlackRows)
+inline int64_t shard_top(fmhip_model_t m, int W) { return (m->n1 + W - 1) / W * W; }
+
+// One data-parallel step with the update sharded over the ranks (FMHIP_EXCHANGE_SHARDED; the schedule is drawn at the
+// top of this file).  Per feature interval, from the cold ids down: backward -> reduce-scatter of its G_V rows (rank r
+// receives the summed rows of share r) grouped with the all-reduce of its G_w / G_b entries -> rank r updates ITS
+// rows of V and all of the interval's w, zeroes the other shares' gradient rows -> all-gather of the updated rows in
+// place into V.  One writer per V row: the replicas are identical whatever order the transport sums in.
+int dp_step_sharded(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0, double regw, double regv) {
+    const bool live = batch >= 0;
+    const int W = c->emu_ranks > 0 ? c->emu_ranks : c->world;        // shares per interval
+    const int R = c->emu_ranks > 0 ? 0 : c->rank;                    // ... and which one is this rank's
+    const int64_t top = shard_top(m, W);
+    if (top > m->n1p + (m->grad == m->grad_own.p ? (int64_t)fmhip_model::kSlackRows : 0))
+        return fail(FMHIP_ERR_UNSUPPORTED, "the sharded exchange needs %lld rows for %d equal shares of %lld: more ranks than the tables' "
+                                           "slack allows (%d), or a caller-owned gradient buffer (fmhip_grad_bind) with n+1 not a multiple of world",
+                    (long long)top, W, (long long)m->n1, fmhip_model::kSlackRows);
+    const float my_rows = live ? (float)d->batches[(size_t)batch].rows : 0.f;
+    hipLaunchKernelGGL(k_set_float, dim3(1), dim3(1), 0, m->stream, c->rows_dev, my_rows);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_rows, m->stream));
+    HIP_TRY(hipStreamWaitEvent(c->cs, c->ev_rows, 0));
+    TRY(collective(c, c->rows_dev, 1, FMHIP_COLL_SUM_F32, c->cs));
+    if (live) {
+        TRY(step_forward(m, d, batch));
+    } else {
+        // out of rows: contribute zeros.  After a sharded step every row of G is clean (own share: the update; the other
+        // shares: the zeroing); only the statistics scalars in front keep the last step's sums
+        if (m->grad_dirty) HIP_TRY(hipMemsetAsync(m->grad, 0, m->grad_floats() * sizeof(float), m->stream));
+        else HIP_TRY(hipMemsetAsync(m->grad, 0, (size_t)kGradHead * sizeof(float), m->stream));
+        m->grad_dirty = true;
+        m->last_nnz = m->last_rows = 0;
+    }
+    CommProf *pr = next_prof(c);
+    std::vector<int64_t> edge{0};
+    for (int64_t x : c->cuts) {
+        const int64_t xr = x / W * W;                                // the plan rounds already; a plan made for another world may not have
+        if (xr > edge.back() && xr < m->n1) edge.push_back(xr);
+    }
+    edge.push_back(m->n1);
+    const int n_int = (int)edge.size() - 1;
+    const size_t kp = (size_t)m->Kp;
+    const double ar_scale = 1.0, half = 0.5;                          // emulated durations: a reduce-scatter or an all-gather is half an all-reduce
+    // the all-gather of interval i's updated V rows (in place: every rank's share already lies where it belongs)
+    auto gather = [&](int i) -> int {
+        const int64_t lo = edge[(size_t)i], hi_r = i == n_int - 1 ? top : edge[(size_t)i + 1];
+        const int64_t chunk = (hi_r - lo) / W;
+        const int64_t vlo = lo + (int64_t)R * chunk;
+        HIP_TRY(hipStreamWaitEvent(c->cs, c->ev_applied[i], 0));
+        int pi = -1;
+        if (pr && pr->n_coll < kProfColl) {
+            pi = pr->n_coll++;
+            HIP_TRY(hipEventRecord(pr->c0[pi], c->cs));
+        }
+        // one real rank playing `emu_ranks`: the collective runs on its own share (in place), the delay is the interval's
+        TRY(collective(c, m->V.p + (size_t)(c->emu_ranks > 0 ? vlo : lo) * kp, (size_t)chunk * kp, FMHIP_COLL_ALLGATHER_F32, c->cs));
+        TRY(emu_delay(c, half * (double)(hi_r - lo) * kp * sizeof(float), c->cs));
+        if (pi >= 0) HIP_TRY(hipEventRecord(pr->c1[pi], c->cs));
+        HIP_TRY(hipEventRecord(c->ev_gathered, c->cs));
+        return FMHIP_OK;
+    };
+    for (int i = n_int - 1; i >= 0; --i) {
+        const int64_t lo = edge[(size_t)i], hi = edge[(size_t)i + 1];
+        const bool last = i == 0;
+        if (live) TRY(step_backward(m, d, batch, lo, n_int == 1 ? INT64_MAX : hi, last, nullptr));
+        const int64_t hi_r = i == n_int - 1 ? top : hi;              // the top interval reaches into the slack rows
+        const int64_t chunk = (hi_r - lo) / W;
+        const int64_t vlo = lo + (int64_t)R * chunk, vhi = vlo + chunk;
+        // ---- exchange of the interval's gradient
+        HIP_TRY(hipEventRecord(c->ev_ready[i], m->stream));
+        HIP_TRY(hipStreamWaitEvent(c->cs, c->ev_ready[i], 0));
+        int pi = -1;
+        if (pr && pr->n_coll < kProfColl) {
+            pi = pr->n_coll++;
+            HIP_TRY(hipEventRecord(pr->c0[pi], c->cs));
+        }
+        float *gw = last ? m->grad : m->Gw() + lo;
+        const size_t n_gw = (size_t)(hi - lo) + (last ? (size_t)kGradHead : 0), n_gb = (size_t)(hi - lo);
+        // one real rank playing `emu_ranks`: the collective runs on its own share (in place), the delay is the interval's
+        const size_t rs_count = (size_t)chunk * kp;
+        float *rs_buf = m->GV() + (size_t)(c->emu_ranks > 0 ? vlo : lo) * kp;
+        if (!c->ext) NCCL_TRY(rccl().GroupStart());
+        TRY(collective(c, rs_buf, rs_count, FMHIP_COLL_REDUCE_SCATTER_F32, c->cs));
+        TRY(collective(c, gw, n_gw, FMHIP_COLL_SUM_F32, c->cs));
+        TRY(collective(c, m->Gb() + lo, n_gb, FMHIP_COLL_SUM_F32, c->cs));
+        if (!c->ext) NCCL_TRY(rccl().GroupEnd());
+        const double gv_bytes = (double)(hi_r - lo) * kp * sizeof(float), head_bytes = (double)(n_gw + n_gb) * sizeof(float);
+        TRY(emu_delay(c, half * gv_bytes + ar_scale * head_bytes, c->cs));
+        if (pi >= 0) HIP_TRY(hipEventRecord(pr->c1[pi], c->cs));
+        HIP_TRY(hipEventRecord(c->ev_done[i], c->cs));
+        // ---- this rank's share of the update, the other shares' rows zeroed (apply stream)
+        HIP_TRY(hipStreamWaitEvent(c->as, c->ev_done[i], 0));
+        TRY(step_apply_shard(m, eta, reg0, regw, regv, lo, hi, vlo, vhi, c->rows_dev, last, c->as));
+        if (vlo > lo) HIP_TRY(hipMemsetAsync(m->GV() + (size_t)lo * kp, 0, (size_t)(vlo - lo) * kp * sizeof(float), c->as));
+        if (hi_r > vhi) HIP_TRY(hipMemsetAsync(m->GV() + (size_t)vhi * kp, 0, (size_t)(hi_r - vhi) * kp * sizeof(float), c->as));
+        HIP_TRY(hipEventRecord(c->ev_applied[i], c->as));
+        // ---- the updated rows travel to every replica — one interval LATER on the comm stream (behind the next interval's
+        // reduce-scatter), so that the collectives never wait for an update: by then this interval's share is long written
+        if (i < n_int - 1) TRY(gather(i + 1));
+        if (c->profiling) c->prof_bytes += (int64_t)(gv_bytes + head_bytes);
+    }
+    TRY(gather(0));
+    m->bw_next_hi = -1;
+    // the next forward reads V (every all-gather must have landed) and the next backward writes G (every zeroing done)
+    if (pr) HIP_TRY(hipEventRecord(pr->wait_a, m->stream));
+    HIP_TRY(hipStreamWaitEvent(m->stream, c->ev_gathered, 0));
+    HIP_TRY(hipStreamWaitEvent(m->stream, c->ev_applied[0], 0));
+    if (pr) HIP_TRY(hipEventRecord(pr->wait_b, m->stream));
+    m->grad_dirty = false;
+    return FMHIP_OK;
+}
+
+// A step's size checks that depend on THIS rank's batch only.  A failure here must not leave the peers waiting in a
+// collective: the caller runs the step with a zero contribution (as a rank that has run out of rows does) and
+// reports the error afterwards.
+int local_checks(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c) {
+    (void)m;
+    if (batch < 0) return FMHIP_OK;
+    const auto &bm = d->batches[(size_t)batch];
+    if (c->exchange != FMHIP_EXCHANGE_TOUCHED && d->rb_rows != 0 && !c->cuts.empty())
+        return fail(FMHIP_ERR_INVALID, "the communicator's plan cuts the backward, but this dataset's transposes are row-blocked: "
+                                       "call fmhip_dp_plan with this dataset (every rank)");
+    // the global row count travels as one fp32 sum: exact below 2^24 rows per global batch.  fmhip_dp_plan agreed on the
+    // largest batch of any rank; a batch beyond it belongs to a dataset the plan has not seen
+    if (c->plan_max_rows >= 0 ? bm.rows > c->plan_max_rows : (double)bm.rows * c->world >= 16777216.0)
+        return fail(FMHIP_ERR_INVALID, "batch %lld has %lld rows, the plan covers batches of up to %lld (a global batch must stay below 2^24 "
+                                       "rows): call fmhip_dp_plan with this dataset (every rank)",
+                    (long long)batch, (long long)bm.rows, (long long)c->plan_max_rows);
+    if (c->exchange == FMHIP_EXCHANGE_TOUCHED && (int64_t)bm.n_cols + d->hot_pages * kHotT > c->cap)
+        return fail(FMHIP_ERR_INVALID, "batch %lld touches %d rows, the plan allows %lld: call fmhip_dp_plan with this dataset (every rank)",
+                    (long long)batch, bm.n_cols + d->hot_pages * kHotT, (long long)c->cap);
+    return FMHIP_OK;
+}
+
+int dp_step_mode(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0, double regw, double regv) {
+    switch (c->exchange) {
+        case FMHIP_EXCHANGE_TOUCHED: return dp_step_touched(m, d, batch, c, eta, reg0, regw, regv);
+        case FMHIP_EXCHANGE_SHARDED: return dp_step_sharded(m, d, batch, c, eta, reg0, regw, regv);
+        default: return dp_step_dense(m, d, batch, c, eta, reg0, regw, regv);
+    }
+}
+
+int dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0, double regw, double regv) {
+    const int pre = local_checks(m, d, batch, c);
+    if (pre == FMHIP_OK) return dp_step_mode(m, d, batch, c, eta, reg0, regw, regv);
+    const std::string why = fmhip_last_error();
+    const int rc = dp_step_mode(m, d, -1, c, eta, reg0, regw, regv);     // keep in step with the peers: contribute zeros
+    if (rc != FMHIP_OK) return rc;
+    return fail(pre, "%s (this rank contributed zeros to the step)", why.c_str());
 }
 
 // small control collectives (a count, a cut) through a device scratch word
@@ -464,6 +656,9 @@ static int comm_resources(fmhip_comm *c) {
     for (int i = 0; i <= kMaxCuts && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_ready[i], hipEventDisableTiming);
     for (int i = 0; i <= kMaxCuts && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->as, hipStreamNonBlocking);
+    for (int i = 0; i <= kMaxCuts && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_applied[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->scratch), (kMaxCuts + 1) * sizeof(int64_t));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->rows_dev), 32 * sizeof(float));
     if (e != hipSuccess) return fail(FMHIP_ERR_HIP, "communicator resources: %s", hipGetErrorString(e));
@@ -546,7 +741,12 @@ int fmhip_comm_destroy(fmhip_comm_t c) {
     if (!c) return FMHIP_OK;
     (void)hipSetDevice(c->device);
     if (c->cs) (void)hipStreamSynchronize(c->cs);
+    if (c->as) (void)hipStreamSynchronize(c->as);
     for (auto &p : c->prof) destroy_events(p);
+    for (hipEvent_t e : c->ev_applied)
+        if (e) (void)hipEventDestroy(e);
+    if (c->ev_gathered) (void)hipEventDestroy(c->ev_gathered);
+    if (c->as) (void)hipStreamDestroy(c->as);
     free_touched(c);
     if (c->comm) (void)rccl().CommDestroy(c->comm);
     for (hipEvent_t e : c->ev_ready)
@@ -568,9 +768,20 @@ int fmhip_comm_emulate(fmhip_comm_t c, double payload_gb_per_s) {
     return FMHIP_OK;
 }
 
+int fmhip_comm_emulate_ranks(fmhip_comm_t c, int ranks) {
+    if (!c) return fail(FMHIP_ERR_INVALID, "communicator is NULL");
+    if (ranks < 0 || ranks > fmhip_model::kSlackRows) return fail(FMHIP_ERR_INVALID, "ranks must be 0..%d", fmhip_model::kSlackRows);
+    if (ranks > 0 && c->world != 1) return fail(FMHIP_ERR_INVALID, "emulated ranks are for one-rank communicators (this one has %d)", c->world);
+    c->emu_ranks = ranks;
+    return FMHIP_OK;
+}
+
 int fmhip_dp_exchange(fmhip_comm_t c, int mode) {
     if (!c) return fail(FMHIP_ERR_INVALID, "communicator is NULL");
-    if (mode != FMHIP_EXCHANGE_DENSE && mode != FMHIP_EXCHANGE_TOUCHED) return fail(FMHIP_ERR_INVALID, "unknown exchange mode %d", mode);
+    if (mode != FMHIP_EXCHANGE_DENSE && mode != FMHIP_EXCHANGE_TOUCHED && mode != FMHIP_EXCHANGE_SHARDED)
+        return fail(FMHIP_ERR_INVALID, "unknown exchange mode %d", mode);
+    if (mode == FMHIP_EXCHANGE_SHARDED && c->world > fmhip_model::kSlackRows)
+        return fail(FMHIP_ERR_UNSUPPORTED, "the sharded exchange supports up to %d ranks", fmhip_model::kSlackRows);
     c->exchange = mode;
     return FMHIP_OK;
 }
@@ -616,20 +827,38 @@ int fmhip_dp_plan(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, int n_frac
             cuts[i] = f + 1 < m->n1 ? f + 1 : 0;
         }
     }
+    // What every rank must agree on before a step can be sized (one max-reduce): the largest mini-batch of any rank —
+    // its global row count travels as one fp32 sum, exact below 2^24 —, whether some rank's transposes are row-blocked
+    // (it cannot cut its backward: then nobody does, same collectives everywhere), the touched-rows table's width, and
+    // whether some rank cannot hold the sharded exchange's equal shares.  All ranks pass or fail together.
+    int64_t agree[4] = {0, d->rb_rows != 0, 1, 0};
+    for (const auto &bm : d->batches) {
+        agree[0] = std::max<int64_t>(agree[0], bm.rows);
+        agree[2] = std::max<int64_t>(agree[2], (int64_t)bm.n_cols + d->hot_pages * kHotT);
+    }
+    const int W = c->emu_ranks > 0 ? c->emu_ranks : c->world;
+    if (c->exchange == FMHIP_EXCHANGE_SHARDED)
+        agree[3] = shard_top(m, W) > m->n1p + (m->grad == m->grad_own.p ? (int64_t)fmhip_model::kSlackRows : 0);
+    TRY(control_i64(m, c, agree, 4, false));
+    if ((double)agree[0] * c->world >= 16777216.0)
+        return fail(FMHIP_ERR_INVALID, "a global batch of %lld x %d rows exceeds 2^24 (the summed row count travels as one fp32 word): "
+                                       "use smaller batches", (long long)agree[0], c->world);
+    if (agree[3])
+        return fail(FMHIP_ERR_UNSUPPORTED, "the sharded exchange cannot cut %lld rows into %d equal shares on some rank (a caller-owned "
+                                           "gradient buffer, fmhip_grad_bind, needs n+1 to be a multiple of world)", (long long)m->n1, W);
+    c->plan_max_rows = agree[0];
+    const int64_t blocked = agree[1];
     if (c->exchange == FMHIP_EXCHANGE_TOUCHED) {
         // the id table's width: the largest number of rows any batch of any rank touches
-        int64_t cap = 1;
-        for (const auto &bm : d->batches) cap = std::max<int64_t>(cap, (int64_t)bm.n_cols + d->hot_pages * kHotT);
-        TRY(control_i64(m, c, &cap, 1, false));
+        const int64_t cap = agree[2];
         if (cap != c->cap || c->msg_kp != m->Kp || !c->ids) TRY(size_touched(m, c, cap));
     }
     TRY(control_i64(m, c, cuts, kMaxCuts + 1, true));
-    // a rank whose transposes are row-blocked cannot cut its backward: then nobody does (same collectives everywhere)
-    int64_t blocked = d->rb_rows != 0;
-    TRY(control_i64(m, c, &blocked, 1, false));
     c->cuts.clear();
-    for (int i = 0; i < n_fractions && !blocked; ++i)
+    for (int i = 0; i < n_fractions && !blocked; ++i) {
+        if (c->exchange == FMHIP_EXCHANGE_SHARDED) cuts[i] = cuts[i] / W * W;      // equal shares: edges at multiples of world
         if (cuts[i] > 0 && cuts[i] < m->n1) c->cuts.push_back(cuts[i]);
+    }
     std::sort(c->cuts.begin(), c->cuts.end());
     c->cuts.erase(std::unique(c->cuts.begin(), c->cuts.end()), c->cuts.end());
     if (cuts_out)
@@ -650,8 +879,16 @@ int fmhip_dp_epoch(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double et
     TRY(check_comm(m, c));
     TRY(check_train(m, d));
     const int64_t nb = (int64_t)d->batches.size();
-    int64_t steps = nb;     // every rank takes the same number of steps: the largest local batch count
-    TRY(control_i64(m, c, &steps, 1, false));
+    // every rank takes the same number of steps — the largest local batch count — and every rank learns whether SOME
+    // rank's dataset does not fit the plan (then all of them stop here, none inside a collective)
+    int64_t agree[2] = {nb, 0};
+    for (int64_t j = 0; j < nb && !agree[1]; ++j) agree[1] = local_checks(m, d, j, c) != FMHIP_OK;
+    const std::string why = agree[1] ? fmhip_last_error() : "";
+    TRY(control_i64(m, c, agree, 2, false));
+    if (agree[1])
+        return fail(FMHIP_ERR_INVALID, "%s", why.empty() ? "another rank's dataset does not fit the communicator's plan: call fmhip_dp_plan "
+                                                           "with the datasets of this epoch (every rank)" : why.c_str());
+    const int64_t steps = agree[0];
     for (int64_t j = 0; j < steps; ++j) TRY(dp_step(m, d, j < nb ? j : -1, c, eta, reg0, regw, regv));
     if (stats) {
         memset(stats, 0, sizeof *stats);
@@ -664,8 +901,20 @@ int fmhip_dp_epoch(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double et
 
 int fmhip_comm_profile_begin(fmhip_comm_t c) {
     if (!c) return fail(FMHIP_ERR_INVALID, "communicator is NULL");
-    for (auto &p : c->prof) destroy_events(p);
-    c->prof.clear();
+    TRY(set_device(c->device));
+    if (c->prof.empty()) {
+        c->prof.resize(kProfSteps);
+        for (auto &p : c->prof) {
+            const int rc = create_events(p);
+            if (rc != FMHIP_OK) {
+                for (auto &q : c->prof) destroy_events(q);
+                c->prof.clear();
+                return rc;
+            }
+        }
+    }
+    for (auto &p : c->prof) p.used = false;
+    c->prof_next = 0;
     c->prof_bytes = 0;
     c->profiling = true;
     return FMHIP_OK;
@@ -678,18 +927,20 @@ int fmhip_comm_profile_end(fmhip_comm_t c, fmhip_comm_profile *p) {
     memset(p, 0, sizeof *p);
     HIP_TRY(hipDeviceSynchronize());
     for (auto &r : c->prof) {
+        if (!r.used) continue;
         float ms = 0.f;
         // what the compute stream spent between its last backward and the end of the step, minus the updates themselves
-        if (r.wait_a && r.wait_b && hipEventElapsedTime(&ms, r.wait_a, r.wait_b) == hipSuccess) p->exposed_ms += ms;
+        // (dense mode; the sharded mode's updates run on a stream of their own and what is left of them counts as exposed)
+        if (hipEventElapsedTime(&ms, r.wait_a, r.wait_b) == hipSuccess) p->exposed_ms += ms;
         for (int i = 0; i < r.n_apply; ++i)
             if (hipEventElapsedTime(&ms, r.a0[i], r.a1[i]) == hipSuccess) p->exposed_ms -= ms;
         for (int i = 0; i < r.n_coll; ++i)
             if (hipEventElapsedTime(&ms, r.c0[i], r.c1[i]) == hipSuccess) p->comm_ms += ms;
         p->steps += 1;
-        destroy_events(r);
+        r.used = false;
     }
     p->bytes = c->prof_bytes;
-    c->prof.clear();
+    c->prof_next = 0;
     return FMHIP_OK;
 }
 

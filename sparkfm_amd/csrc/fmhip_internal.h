@@ -135,6 +135,9 @@ struct fmhip_model {
     template <typename T> using DevBuf = fmhip::host::DevBuf<T>;
     using ProfRec = fmhip::host::ProfRec;
     static constexpr int kGradHead = fmhip::kGradHead;
+    // rows allocated (and kept zero) behind row n1p of V and of the library's own packed gradient: the sharded exchange
+    // (fmhip_comm.hip) cuts [0, n+1) into `world` equal shares, so its last share may reach up to world - 1 rows past n1p
+    static constexpr int kSlackRows = 64;
     int device = 0;
     int64_t n = 0, n1 = 0, n1p = 0;
     int32_t k = 0, Kp = 0;
@@ -202,6 +205,10 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
 int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double regv, fmhip_dataset_t d = nullptr, int64_t b = -1);
 int step_apply_interval(fmhip_model_t m, double eta, double reg0, double regw, double regv, int64_t lo, int64_t hi,
                         const float *rows, bool last);
+// The sharded update of the feature interval [lo, hi) on stream `s`: V rows [vlo, vhi) (this rank's share; their w too) by
+// the dense pass, the linear weights of the rest of the interval by k_apply_w.  `last`: also steps w0 and closes the step.
+int step_apply_shard(fmhip_model_t m, double eta, double reg0, double regw, double regv, int64_t lo, int64_t hi, int64_t vlo,
+                     int64_t vhi, const float *rows, bool last, hipStream_t s);
 // the rows-only (lazy-decay) update of the feature rows listed on the device (ids < 0 are skipped), |B| from `rows`
 // (device float): the touched-rows exchange of the data-parallel step applies the union of all ranks' rows with it
 int step_apply_rows(fmhip_model_t m, double eta, double reg0, double regw, double regv, const int32_t *feat, int32_t n_feat,

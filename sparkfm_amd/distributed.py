@@ -271,13 +271,24 @@ class HostStagedComm(RcclComm):
         def collective(_ctx, dev, count, kind, stream):
             try:
                 self.calls.append((kind, count))
-                if kind == _ffi.COLL_ALLGATHER_I32:     # world x count int32 on the device, this rank's own at rank * count
-                    host = np.empty(world * count, np.int32)
+                if kind in (_ffi.COLL_ALLGATHER_I32, _ffi.COLL_ALLGATHER_F32):
+                    # world x count elements on the device, this rank's own at rank * count
+                    dt, tdt = (np.int32, torch.int32) if kind == _ffi.COLL_ALLGATHER_I32 else (np.float32, torch.float32)
+                    host = np.empty(world * count, dt)
                     _ffi.check(L.fmhip_device_read(_ffi.ptr(host), dev, host.nbytes, stream))
-                    parts = [torch.empty(count, dtype=torch.int32) for _ in range(world)]
+                    parts = [torch.empty(count, dtype=tdt) for _ in range(world)]
                     dist.all_gather(parts, torch.from_numpy(host[rank * count:(rank + 1) * count].copy()), group=group)
                     host = np.concatenate([p.numpy() for p in parts])
                     _ffi.check(L.fmhip_device_write(dev, _ffi.ptr(host), host.nbytes, stream))
+                    return 0
+                if kind == _ffi.COLL_REDUCE_SCATTER_F32:
+                    # world x count floats; this rank keeps the sum of ITS segment, the others' are left as they were
+                    host = np.empty(world * count, np.float32)
+                    _ffi.check(L.fmhip_device_read(_ffi.ptr(host), dev, host.nbytes, stream))
+                    t = torch.from_numpy(host)
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                    mine = np.ascontiguousarray(host[rank * count:(rank + 1) * count])
+                    _ffi.check(L.fmhip_device_write(C.c_void_p(dev + rank * count * 4), _ffi.ptr(mine), mine.nbytes, stream))
                     return 0
                 dt = np.float32 if kind == _ffi.COLL_SUM_F32 else np.int64
                 host = np.empty(count, dt)
@@ -313,13 +324,20 @@ class HipDataParallelSGD(FMLearn):
         self.comm = comm
         self.eta, self.reg0, self.regw, self.regv = float(eta), float(reg0), float(regw), float(regv)
         self.upper_fractions = tuple(float(f) for f in upper_fractions)
-        # "dense": the whole packed gradient in overlapped slices; "touched": only the rows some rank's batch touched
-        # (fmhip_dp_exchange) — for models far wider than a global batch
+        # "dense": the whole packed gradient all-reduced in overlapped slices, every rank updates every row; "sharded": the
+        # slices reduce-scattered, every rank updates its 1/world share, the updated rows all-gathered; "touched": only the
+        # rows some rank's batch touched (fmhip_dp_exchange) — for models far wider than a global batch
         self.exchange = exchange
-        _ffi.check(_ffi.load().fmhip_dp_exchange(comm.handle, {"dense": _ffi.EXCHANGE_DENSE, "touched": _ffi.EXCHANGE_TOUCHED}[exchange]))
+        _ffi.check(_ffi.load().fmhip_dp_exchange(comm.handle, _ffi.EXCHANGE_MODES[exchange]))
         self.cuts = None
         self._planned_for = None
         self.last_stats = None
+
+    def set_exchange(self, exchange):
+        """Switches what a step exchanges (every rank alike, then `plan` again)."""
+        _ffi.check(_ffi.load().fmhip_dp_exchange(self.comm.handle, _ffi.EXCHANGE_MODES[exchange]))
+        self.exchange = exchange
+        self._planned_for = None
 
     def plan(self, fm, dataset):
         """Collective: rank 0's data pick the cuts, every rank receives them."""
@@ -334,7 +352,7 @@ class HipDataParallelSGD(FMLearn):
     def exchange_info(self):
         mode, cap, mean = C.c_int(), C.c_int64(), C.c_double()
         _ffi.check(_ffi.load().fmhip_dp_exchange_info(self.comm.handle, C.byref(mode), C.byref(cap), C.byref(mean)))
-        return dict(mode="touched" if mode.value == _ffi.EXCHANGE_TOUCHED else "dense", id_slots_per_rank=int(cap.value),
+        return dict(mode={v: k for k, v in _ffi.EXCHANGE_MODES.items()}[mode.value], id_slots_per_rank=int(cap.value),
                     mean_union_rows=float(mean.value))
 
     def step(self, fm, dataset, batch):

@@ -151,9 +151,15 @@ class FMModel(Model):
         self._host_fresh = False
         self._dev_fresh = True
 
-    def close(self):
+    def close(self, discard=False):
+        """Frees the device model.  The parameters are copied back to the host first so that `fm.w` / `fm.v` keep
+        working — except with `discard=True`, or for a model drawn on the device (`init_on_device=True`: it exists so
+        that no host copy is made until one is asked for; at 2^25 x 64 the copy is 8.6 GB of fp32 staging plus a 17 GB
+        fp64 array) whose parameters nobody has read yet.  After such a close `fm.w` / `fm.v` are gone: pull them
+        first (`fm.v`, `fm.rows(ids)`) if they are wanted."""
         if self._h is not None:
-            self._pull()
+            if not discard and not (self._init_on_device and self._v is None):
+                self._pull()
             _ffi.load().fmhip_model_destroy(self._h)
             self._h = None
             self._dev_fresh = False

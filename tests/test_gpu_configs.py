@@ -24,6 +24,7 @@ from test_gpu_parity import TOL_Y, check_grad, term_scale
 pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 
 
 @pytest.fixture(scope="module")
@@ -273,11 +274,13 @@ def _free_port():
     return p
 
 
+@pytest.mark.parametrize("exchange", ["dense", "sharded"])
 @pytest.mark.parametrize("upper", [(0.45,), (), (0.1, 0.3, 0.6)])
-def test_library_side_exchange_one_rank(fmhip, upper):
+def test_library_side_exchange_one_rank(fmhip, upper, exchange):
     """fmhip_comm_create / fmhip_dp_plan / fmhip_dp_epoch with a world of ONE rank: RCCL is loaded, the
-    communicator is built, both collectives of the overlapped schedule really run (in place, on the second
-    stream) — and the result must be bit-identical to the plain dense step."""
+    communicator is built, the collectives of the overlapped schedule really run (in place, on the second
+    stream: all-reduces, or the sharded update's reduce-scatter + all-gather) — and the result must be
+    bit-identical to the plain dense step."""
     from sparkfm_amd import synth
     from sparkfm_amd.distributed import HipDataParallelSGD, RcclComm
     d = synth.make_zipf(91, 5000, 900, 4, 30, zipf_s=1.05)
@@ -294,7 +297,7 @@ def test_library_side_exchange_one_rank(fmhip, upper):
                 # hold the comm stream for every collective as a 40 GB/s all-reduce would: the schedule must not care
                 from sparkfm_amd import _ffi as ffi
                 ffi.check(ffi.load().fmhip_comm_emulate(comm.handle, 40.0))
-            dp = HipDataParallelSGD(comm, eta=0.05, regw=1e-3, regv=1e-3, upper_fractions=upper)
+            dp = HipDataParallelSGD(comm, eta=0.05, regw=1e-3, regv=1e-3, upper_fractions=upper, exchange=exchange)
             for _ in range(2):
                 dp.learn(fm, ds)
             assert len(dp.cuts) == len(upper) and dp.cuts == sorted(dp.cuts, reverse=True)
@@ -397,8 +400,9 @@ def _oracle_two_rank_epochs(n1=800):
     return w0, w, v
 
 
+@pytest.mark.parametrize("exchange", ["dense", "sharded"])
 @pytest.mark.parametrize("fractions,world", [("", 2), ("0.3", 2), ("0.05,0.15,0.3,0.55", 2), ("0.12,0.4", 3)])
-def test_library_side_exchange_two_ranks_on_one_gpu_host_staged(fractions, world):
+def test_library_side_exchange_two_ranks_on_one_gpu_host_staged(fractions, world, exchange):
     """The library's data-parallel step with two (three) real ranks on the one GPU of the test box: fmhip_dp_epoch over
     fmhip_comm_create_external, every collective staged through the host and summed by gloo (RCCL refuses two ranks on
     one device).  Everything but the transport is the RCCL path: the plan broadcast from rank 0, the global row count,
@@ -406,8 +410,8 @@ def test_library_side_exchange_two_ranks_on_one_gpu_host_staged(fractions, world
     agreed by a max-reduce.  Replicas bit-identical, same sequence of collectives on both ranks, oracle matched."""
     import tempfile
     port, out = str(_free_port()), os.path.join(tempfile.mkdtemp(), "dp")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_rccl_worker.py"), str(r), str(world), port, out, "host", fractions])
-             for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_rccl_worker.py"), str(r), str(world), port, out, "host", fractions,
+                               exchange]) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
     r0 = np.load(out + ".0.npz")
@@ -420,12 +424,48 @@ def test_library_side_exchange_two_ranks_on_one_gpu_host_staged(fractions, world
         np.testing.assert_array_equal(r0["cuts"], r1["cuts"])
     n_cuts = len([x for x in fractions.split(",") if x])
     assert len(r0["cuts"]) == n_cuts and int(r0["steps"]) == 3 and int(r0["rows"]) == 1000      # last global batch: 1000 + 0 rows
-    # per epoch: 1 step-count max-reduce; per step: the row count + (1 region, or 3 per interval); per plan: cuts + blocked flag
+    # per epoch: 1 max-reduce (step count + validation); per step: the row count + (1 region, or 3 per interval); per plan: 1 max-reduce + cuts
     sums = r0["calls"][r0["calls"][:, 0] == 0]
-    per_step = 1 + (1 if n_cuts == 0 else 3 * (n_cuts + 1))
+    if exchange == "dense":
+        per_step = 1 + (1 if n_cuts == 0 else 3 * (n_cuts + 1))
+    else:
+        # sharded: per interval a reduce-scatter of G_V (kind 4), two all-reduces (G_w with or without the scalars, G_b), an all-gather of V (kind 5)
+        per_step = 1 + 2 * (n_cuts + 1)
+        for kind in (4, 5):
+            seg = r0["calls"][r0["calls"][:, 0] == kind][:, 1]
+            assert len(seg) == 2 * 3 * (n_cuts + 1)
+            # equal shares per rank: the intervals' shares add up to ceil(800 / world) rows of 32 floats
+            assert seg.reshape(6, -1).sum(axis=1).tolist() == [-(-800 // world) * 32] * 6
     assert len(sums) == 2 * 3 * per_step
     w0, w, v = _oracle_two_rank_epochs()
     assert rel(r0["v"], v) <= 1e-5 and rel(r0["w"], w) <= 1e-5 and float(r0["w0"]) == pytest.approx(w0, rel=1e-5, abs=1e-7)
+
+
+def test_bench_with_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2 --transport host`: the bench's whole N > 1 flow — self-launch of the ranks (before the
+    parent touches the GPU), gloo control plane, the library's communicator, the cut / exchange-mode tuning, the timed
+    region with its barriers and max over ranks, the exchange's own profile pass, the legs without exchange, the C3 twin,
+    the JSON assembly — with both ranks on the one GPU of the test box and every collective staged through the host
+    (RCCL refuses two ranks on one device).  Timings mean nothing here; the flow and the line's keys are what is tested."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "host", "--steps", "4", "--warmup", "2",
+           "--rows", "200000", "--batch-rows", "100000"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 4 and out["warmup"] == 2
+    assert out["metric"] == "nnz_per_sec_fm_sgd_training" and out["value"] > 0 and out["ms_per_step"] > 0
+    assert out["config"]["workload"].startswith("C4") and out["config"]["rows_per_gpu"] == 200000
+    x = out["exchange"]
+    assert x["nranks"] == 2 and x["transport"] == "host" and x["mode"] in ("dense", "sharded")
+    assert {t["exchange"] for t in x["cut_tuning"]} == {"dense", "sharded"} and all(t["ms_per_step"] > 0 for t in x["cut_tuning"])
+    assert x["exposed_comm_ms"] >= 0 and x["comm_busy_ms"] > 0
+    assert x["c3_on_every_gpu"]["value"] > 0 and x["c3_on_every_gpu"]["exchange"] in ("dense", "sharded")
+    assert x["per_gpu_without_exchange"]["value"] > 0 and x["c4_one_gpu"]["value"] > 0 and x["scaling_vs_c4_one_gpu"] > 0
+    assert out["train"]["nonfinite"] == 0 and out["sustained"]["steps"] > 0
 
 
 @pytest.mark.parametrize("world,n1", [(2, 800), (3, 50_000)])

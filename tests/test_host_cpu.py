@@ -20,7 +20,8 @@ def test_library_exports_every_declared_symbol():
     L = _ffi.load()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.fmhip_version() == 200
+    m = re.search(r"#define FMHIP_VERSION (\d+)", hdr)
+    assert L.fmhip_version() == int(m.group(1)) == 300
     m = re.search(r"#define FMHIP_RANGE_LEN (\d+)", hdr)
     assert int(m.group(1)) == _ffi.RANGE_LEN
 
@@ -324,3 +325,89 @@ def test_bench_roofline_helpers():
     pmc = bench.committed_pmc("C5", 64, 250_000)
     assert {"k_forward", "k_backward", "step"} <= set(pmc) and 0 < pmc["k_forward"]["l2_hit"] < 1
     assert bench.alg_bytes(32) == {"forward": 140, "backward": 132, "step": 272}
+
+
+# ---- the JVM side (jvm/HipSGD.scala + jvm/fmhip_jni.c): no JDK / scalac in this image, so the sources are checked
+# ---- against each other and against the header instead of being compiled
+
+_JNI_TYPES = {"Int": "jint", "Long": "jlong", "Double": "jdouble", "Array[Double]": "jdoubleArray", "Array[Long]": "jlongArray",
+              "Array[Int]": "jintArray", "Array[Byte]": "jbyteArray", "Unit": "void"}
+
+
+def _scala_natives(src):
+    out = {}
+    for m in re.finditer(r"@native\s+def\s+(\w+)\s*\(([^)]*)\)\s*:\s*([\w\[\]]+)", src):
+        args = [a.split(":")[1].strip() for a in m.group(2).split(",") if a.strip()]
+        out[m.group(1)] = (args, m.group(3))
+    return out
+
+
+def _jni_functions(src):
+    out = {}
+    for m in re.finditer(r"JNIEXPORT\s+(\w+)\s+JNI_FN\((\w+)\)\s*\(([^)]*)\)", src):
+        args = [" ".join(a.split()[:-1]) for a in m.group(3).split(",")]      # "JNIEnv *env" -> "JNIEnv", "jint dev" -> "jint"
+        assert args[:2] == ["JNIEnv", "jobject"], (m.group(2), args)
+        out[m.group(2)] = (args[2:], m.group(1))
+    return out
+
+
+def test_jvm_natives_match_the_jni_shim_and_the_header():
+    scala = open(os.path.join(ROOT, "jvm", "HipSGD.scala")).read()
+    shim = open(os.path.join(ROOT, "jvm", "fmhip_jni.c")).read()
+    hdr = open(os.path.join(ROOT, "include", "fmhip.h")).read()
+    natives, jni = _scala_natives(scala), _jni_functions(shim)
+    assert len(natives) >= 20
+    assert set(natives) == set(jni), (set(natives) ^ set(jni))
+    for name, (args, ret) in natives.items():
+        assert [_JNI_TYPES[a] for a in args] == jni[name][0], name
+        assert _JNI_TYPES[ret] == jni[name][1], name
+    # every C-ABI symbol the shim calls is declared by the header
+    declared = set(re.findall(r"\b(fmhip_[a-z0-9_]+)\s*\(", hdr)) | set(re.findall(r"\b(fmhip_[a-z0-9_]+_t)\b", hdr))
+    used = set(re.findall(r"\b(fmhip_[a-z0-9_]+)\b", re.sub(r"/\*.*?\*/", "", shim, flags=re.S))) - {"fmhip_jni"}
+    assert used <= declared, used - declared
+    # every HipSGD.<name>( call in the Scala source has a definition in the companion object, with that many arguments
+    defs = {m.group(1): len([a for a in m.group(2).split(",") if a.strip()])
+            for m in re.finditer(r"\bdef\s+(\w+)\s*\(([^)]*)\)", scala[scala.index("object HipSGD"):])}
+    for m in re.finditer(r"HipSGD\.(\w+)\(", scala):
+        assert m.group(1) in defs, m.group(1)
+    for name, (args, _) in natives.items():
+        for call in re.finditer(r"HipSGD\.%s\(([^()]*(?:\([^()]*\)[^()]*)*)\)" % name, scala):
+            depth, n = 0, 1
+            for ch in call.group(1):
+                depth += ch in "([" 
+                depth -= ch in ")]"
+                n += ch == "," and depth == 0
+            assert n == len(args) or (not call.group(1).strip() and not args), (name, call.group(0))
+    # INTEGRATION.md states the count
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "%d natives" % len(natives) in integ
+
+
+def test_jvm_class_has_no_duplicate_members():
+    """The round-2 source declared `rank` twice (a constructor parameter and a var): scalac refuses that."""
+    scala = open(os.path.join(ROOT, "jvm", "HipSGD.scala")).read()
+    cls = scala[scala.index("class HipSGD"):scala.index("object HipSGD")]
+    params = re.search(r"class HipSGD protected \(([^)]*)\)", cls, re.S).group(1)
+    names = [p.split(":")[0].strip() for p in params.split(",")]
+    body = cls[cls.index("extends FMLearn"):]
+    depth, members = 0, []
+    for line in body.splitlines():
+        if depth == 1:
+            m = re.match(r"\s*(?:@transient\s+)?(?:override\s+)?(?:private\s+|protected\s+)?(?:var|val|def)\s+(\w+)", line)
+            if m:
+                members.append(m.group(1))
+        depth += line.count("{") - line.count("}")
+    assert len(members) >= 8
+    every = names + members
+    assert len(every) == len(set(every)), sorted(n for n in every if every.count(n) > 1)
+    assert scala.count("{") == scala.count("}") and scala.count("(") == scala.count(")")
+
+
+def test_jni_shim_type_checks_against_a_stub_header():
+    """No JDK here: `gcc -fsyntax-only` against tests/jni_stub/jni.h (a test stub of the names the shim uses) at least
+    type-checks every call the shim makes into include/fmhip.h."""
+    import subprocess
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Werror", "-fsyntax-only",
+                        "-I" + os.path.join(ROOT, "tests", "jni_stub"), "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "jvm", "fmhip_jni.c")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
