@@ -400,7 +400,8 @@ def test_jvm_class_has_no_duplicate_members():
     assert len(members) >= 8
     every = names + members
     assert len(every) == len(set(every)), sorted(n for n in every if every.count(n) > 1)
-    assert scala.count("{") == scala.count("}") and scala.count("(") == scala.count(")")
+    code = re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", scala, flags=re.S))      # comments may hold "[lo, hi)"
+    assert code.count("{") == code.count("}") and code.count("(") == code.count(")") and code.count("[") == code.count("]")
 
 
 def test_jni_shim_type_checks_against_a_stub_header():
