@@ -578,6 +578,7 @@ def main():
     t0 = time.perf_counter()
     for j in range(args.warmup, args.warmup + args.steps):
         step(j)
+    enqueue_s = time.perf_counter() - t0          # what the HOST needed to queue the steps (it must stay ahead of the GPU)
     sync()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -797,6 +798,7 @@ def main():
             "kernels": kern,
             "train": {"last_batch_mse": st.sse / max(st.rows, 1), "nonfinite": st.nonfinite},
             "setup_s": {"generate": t_gen, "load_transpose_h2d": t_load},
+            "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
         }
         if sustained:
             out["sustained"] = sustained

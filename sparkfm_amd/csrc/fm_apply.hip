@@ -29,25 +29,40 @@ __global__ __launch_bounds__(kBlock) void k_apply_rows(ApplyArgs a) {
     for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kBlock) {
         const int64_t j = idx / LPR;
         const int32_t i = j < a.n_feat ? a.feat[j] : a.hot_ids[j - a.n_feat];
-        if (i >= 0) apply_piece<KP, true>(a, i, (int)(idx % LPR), invb);
+        if (i >= 0) apply_piece<KP, true>(a, i, (int)(idx % LPR), invb, a.g_compact ? j : (int64_t)i);
     }
     if (a.do_w0) apply_w0(a, invb);
 }
 
-// Sharded update (fmhip_comm.hip): the V rows of a feature interval are updated by their owning rank only and come
-// back through the all-gather, but w (4 bytes per feature against 4*Kp) is stepped by every rank from the all-reduced
-// G_w: the rows [w_lo, w_hi) that k_apply does not visit on this rank ([row_lo, row_hi) is its own share) — the same
-// operations as apply_piece<KP, false>'s linear-weight branch, so every replica holds the same bits.
-__global__ __launch_bounds__(kBlock) void k_apply_w(ApplyArgs a) {
+// Sharded update (fmhip_comm.hip, FMHIP_EXCHANGE_SHARDED): one launch per feature interval [w_lo, z_hi), queued on the
+// collectives' stream between the interval's reduce-scatter and its all-gather.
+//   * the V rows of THIS rank's share [row_lo, row_hi) get the dense update (apply_piece<KP, false>: the same operations
+//     as the unsharded pass) and come back to every replica through the all-gather — one writer per row;
+//   * the other shares' rows of G_V hold this rank's local (unsummed) gradient: zeroed for the next step;
+//   * w (4 bytes per feature against 4*KP) is stepped by EVERY rank from the all-reduced G_w over [w_lo, w_hi) — the
+//     operations of apply_piece's linear-weight branch, so every replica holds the same bits.
+template <int KP>
+__global__ __launch_bounds__(kBlock) void k_apply_shard(ApplyArgs a) {
+    constexpr int LPR = KP / 4;
     const float invb = apply_invb(a);
-    for (int64_t i = a.w_lo + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.w_hi; i += (int64_t)gridDim.x * kBlock) {
-        if (i >= a.row_lo && i < a.row_hi) continue;
-        const float us = a.w[i], gi = a.Gw[i] * invb;
-        const float wi = us * a.sw_in;
-        a.w[i] = wi - a.eta * fmaf(a.regw, wi, gi);
-        a.Gw[i] = 0.f;
-        a.Gb[i] = 0.f;
+    const int64_t total = (a.z_hi - a.w_lo) * LPR;
+    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = a.w_lo + idx / LPR;
+        const int c = (int)(idx % LPR);
+        if (i >= a.row_lo && i < a.row_hi) {
+            apply_piece<KP, false>(a, i, c, invb);
+            continue;
+        }
+        reinterpret_cast<float4 *>(a.GV)[i * LPR + c] = f4zero();
+        if (c == 0 && i < a.w_hi) {
+            const float us = a.w[i], gi = a.Gw[i] * invb;
+            const float wi = us * a.sw_in;
+            a.w[i] = wi - a.eta * fmaf(a.regw, wi, gi);
+            a.Gw[i] = 0.f;
+            a.Gb[i] = 0.f;
+        }
     }
+    if (a.do_w0) apply_w0(a, invb);
 }
 
 
@@ -110,11 +125,18 @@ hipError_t launch_init_normal(int Kp, float *V, float *w, float *w0, int64_t n1,
     return hipGetLastError();
 }
 
-hipError_t launch_apply_w(const ApplyArgs &a, hipStream_t s) {
-    if (a.w_hi <= a.w_lo) return hipSuccess;
-    int64_t blocks = (a.w_hi - a.w_lo + kBlock - 1) / kBlock;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_apply_w, dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
+hipError_t launch_apply_shard(int Kp, const ApplyArgs &a, hipStream_t s) {
+    int64_t blocks = ((a.z_hi - a.w_lo) * (Kp / 4) + kBlock - 1) / kBlock;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    dim3 g((unsigned)blocks), b(kBlock);
+    switch (Kp) {
+        case 32: hipLaunchKernelGGL((k_apply_shard<32>), g, b, 0, s, a); break;
+        case 64: hipLaunchKernelGGL((k_apply_shard<64>), g, b, 0, s, a); break;
+        case 128: hipLaunchKernelGGL((k_apply_shard<128>), g, b, 0, s, a); break;
+        case 256: hipLaunchKernelGGL((k_apply_shard<256>), g, b, 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -146,12 +146,14 @@ __device__ __forceinline__ uint32_t slot_bcast(uint32_t v, int src) { return (ui
 // perform the same operations on the same values (bit-identical; tested).
 //
 // one float4 of one feature row; ROWS = the rows-only (lazy) form
+// gr: the row of the gradient arrays that belongs to parameter row i (the packed gradient: gr == i; the compact
+// gradient of the touched-rows exchange: the position of feature i in the step's union)
 template <int KP, bool ROWS>
-__device__ __forceinline__ void apply_piece(const ApplyArgs &a, int64_t i, int c, float invb) {
+__device__ __forceinline__ void apply_piece(const ApplyArgs &a, int64_t i, int c, float invb, int64_t gr) {
     constexpr int LPR = KP / 4;
     float4 *V4 = reinterpret_cast<float4 *>(a.V) + i * LPR + c;
-    float4 *G4 = reinterpret_cast<float4 *>(a.GV) + i * LPR + c;
-    const float b = a.Gb[i];
+    float4 *G4 = reinterpret_cast<float4 *>(a.GV) + gr * LPR + c;
+    const float b = a.Gb[gr];
     float4 g = *G4, u = *V4;
     float4 v = f4mul(u, a.sv_in);                      // the parameter values (x 1 is exact)
     float wslot = 0.f;
@@ -176,12 +178,16 @@ __device__ __forceinline__ void apply_piece(const ApplyArgs &a, int64_t i, int c
     *V4 = u;
     *G4 = f4zero();
     if (c == 0) {
-        const float us = a.w[i], gi = a.Gw[i] * invb;
+        const float us = a.w[i], gi = a.Gw[gr] * invb;
         const float wi = us * a.sw_in;
         a.w[i] = ROWS ? us - a.eta_w * gi : wi - a.eta * fmaf(a.regw, wi, gi);
-        a.Gw[i] = 0.f;
-        a.Gb[i] = 0.f;  // same wave already holds its copy of b (all lanes of a row share a wave)
+        a.Gw[gr] = 0.f;
+        a.Gb[gr] = 0.f;  // same wave already holds its copy of b (all lanes of a row share a wave)
     }
+}
+template <int KP, bool ROWS>
+__device__ __forceinline__ void apply_piece(const ApplyArgs &a, int64_t i, int c, float invb) {
+    apply_piece<KP, ROWS>(a, i, c, invb, i);
 }
 
 // 1/|B|: from the step's row count on the device, or given by the host

@@ -107,9 +107,10 @@ struct ApplyArgs {
     int32_t n_feat;
     const int32_t *hot_ids;  // [n_hot], -1 = unused
     int32_t n_hot;
-    // k_apply_w (sharded update): the linear weights of the rows [w_lo, w_hi) OUTSIDE [row_lo, row_hi) — whose owner is
-    // another rank, so k_apply does not visit them here — are stepped and their G_w / G_b entries zeroed
-    int64_t w_lo, w_hi;
+    int32_t g_compact;       // rows-only variant: GV / Gw / Gb are COMPACT arrays indexed by the position in `feat`, not by feature id
+    // k_apply_shard (sharded update of one feature interval): V rows [row_lo, row_hi) = this rank's share are updated,
+    // the linear weights of [w_lo, w_hi) = the whole interval are stepped, the G_V rows of [w_lo, z_hi) outside the share zeroed
+    int64_t w_lo, w_hi, z_hi;
 };
 
 struct BwdArgs {
@@ -177,7 +178,7 @@ hipError_t launch_backward(int Kp, const BwdArgs &a, hipStream_t s);
 hipError_t launch_fixup(int Kp, const BwdArgs &a, hipStream_t s);
 hipError_t launch_fixup2(int Kp, const BwdArgs &a, hipStream_t s);   // sums the pieces of multi-piece features
 hipError_t launch_apply(int Kp, const ApplyArgs &a, hipStream_t s);
-hipError_t launch_apply_w(const ApplyArgs &a, hipStream_t s);        // see ApplyArgs::w_lo
+hipError_t launch_apply_shard(int Kp, const ApplyArgs &a, hipStream_t s);        // see ApplyArgs::w_lo
 // scal[0..3] = {sum e, sum e^2, n_rows, nonfinite} (optional); acc (optional, 4 doubles) += the same
 hipError_t launch_reduce_blocks(const double *bsum, int32_t nblocks, int32_t n_rows, float *scal, double *acc,
                                 hipStream_t s);

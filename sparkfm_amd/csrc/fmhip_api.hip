@@ -770,6 +770,12 @@ BwdArgs bwd_args(fmhip_model_t m, fmhip_dataset_t d, int64_t b) {
     a.GV = m->GV();
     a.Gw = m->Gw();
     a.Gb = m->Gb();
+    if (m->view) {     // the rows go to a compact buffer (touched-rows exchange): column s -> row view->cdst[s]
+        a.GV = m->view->GV;
+        a.Gw = m->view->Gw;
+        a.Gb = m->view->Gb;
+        a.cdst = m->view->cdst;
+    }
     a.part = m->part.p;
     return a;
 }
@@ -805,11 +811,11 @@ void hot_attach(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm, BwdArgs
     h.xhot = d->xhot.p + (size_t)bm.row0 * kHotT;
     h.page_stride = std::max<int64_t>(d->n_rows, 1) * kHotT;
     h.pages = d->hot_pages;
-    h.hot_ids = d->d_hot_ids.p;
+    h.hot_ids = m->view ? m->view->hot_pos : d->d_hot_ids.p;
     h.part = m->hot_part.p;
-    h.GV = m->GV();
-    h.Gw = m->Gw();
-    h.Gb = m->Gb();
+    h.GV = ba.GV;
+    h.Gw = ba.Gw;
+    h.Gb = ba.Gb;
     h.n_rows = (int32_t)bm.rows;
     h.pack_k = m->pack_k();
     h.nblk = hot_blocks(m->Kp, bm.rows);
@@ -844,7 +850,7 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
             ba.red_bsum = m->bsum.p;
             ba.red_nblocks = m->fwd_parts;
             ba.red_rows = (int32_t)bm.rows;
-            ba.red_scal = m->scal();
+            ba.red_scal = m->view ? m->view->scal : m->scal();
             ba.red_acc = acc;
         }
         {
@@ -911,7 +917,7 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
         ba.red_bsum = m->bsum.p;
         ba.red_nblocks = m->fwd_parts;
         ba.red_rows = (int32_t)bm.rows;
-        ba.red_scal = m->scal();
+        ba.red_scal = m->view ? m->view->scal : m->scal();
         ba.red_acc = acc;
     }
     const int64_t nnz_part = (int64_t)e_hi - e_lo;
@@ -1083,8 +1089,8 @@ int step_apply_interval(fmhip_model_t m, double eta, double reg0, double regw, d
     return FMHIP_OK;
 }
 
-int step_apply_shard(fmhip_model_t m, double eta, double reg0, double regw, double regv, int64_t lo, int64_t hi, int64_t vlo,
-                     int64_t vhi, const float *rows, bool last, hipStream_t s) {
+int step_apply_shard(fmhip_model_t m, double eta, double reg0, double regw, double regv, int64_t lo, int64_t hi, int64_t hi_r,
+                     int64_t vlo, int64_t vhi, const float *rows, bool last, hipStream_t s) {
     ApplyArgs a{};
     a.sv_in = (float)m->sv;
     a.sw_in = (float)m->sw;
@@ -1103,14 +1109,14 @@ int step_apply_shard(fmhip_model_t m, double eta, double reg0, double regw, doub
     a.row_hi = std::min(std::max(vhi, a.row_lo), hi);
     a.w_lo = lo;
     a.w_hi = hi;
+    a.z_hi = std::max(hi_r, hi);
     a.do_w0 = last ? 1 : 0;
     a.pack_k = m->pack_k();
     a.eta = (float)eta;
     a.reg0 = (float)reg0;
     a.regw = (float)regw;
     a.regv = (float)regv;
-    if (a.row_hi > a.row_lo || last) HIP_TRY(launch_apply(m->Kp, a, s));
-    HIP_TRY(launch_apply_w(a, s));
+    HIP_TRY(launch_apply_shard(m->Kp, a, s));
     if (last) {
         m->sv = m->sw = 1.0;      // every share folded the pending scale; the all-gather spreads the folded rows
         m->host64_fresh = false;
@@ -1127,7 +1133,7 @@ bool lazy_decay_ok(double eta, double regw, double regv) {
 }
 
 int step_apply_rows(fmhip_model_t m, double eta, double reg0, double regw, double regv, const int32_t *feat, int32_t n_feat,
-                    const float *rows) {
+                    const float *rows, const GradView *view) {
     if (!lazy_decay_ok(eta, regw, regv))
         return fail(FMHIP_ERR_UNSUPPORTED, "a rows-only update needs weight decay that fits the tables' scale (0.5 <= 1 - eta*reg <= 1)");
     const double sv_out = m->sv * (1.0 - eta * regv), sw_out = m->sw * (1.0 - eta * regw);
@@ -1143,10 +1149,11 @@ int step_apply_rows(fmhip_model_t m, double eta, double reg0, double regw, doubl
     a.V = m->V.p;
     a.w = m->w.p;
     a.w0 = m->w0.p;
-    a.GV = m->GV();
-    a.Gw = m->Gw();
-    a.Gb = m->Gb();
-    a.scal = m->scal();
+    a.GV = view ? view->GV : m->GV();
+    a.Gw = view ? view->Gw : m->Gw();
+    a.Gb = view ? view->Gb : m->Gb();
+    a.scal = view ? view->scal : m->scal();
+    a.g_compact = view ? 1 : 0;
     a.rows = rows;
     a.n1 = m->n1;
     a.row_lo = 0;

@@ -19,16 +19,16 @@
 // ids at a time; the cold interval is nearly all of the gradient's volume and under half of the work.
 // More cuts give a deeper pipeline (the collective of interval i runs beside the backward of interval i+1).
 //
-// FMHIP_EXCHANGE_SHARDED — the same exchange with the update sharded as well (three streams):
-//   compute stream  forward | backward(int n-1) | backward(int n-2) | ... | backward(int 0) + statistics | wait(last all-gather, zeroing)
-//   comm stream     rows    |                   | RS(n-1)           | RS(n-2) AG(n-1) | RS(n-3) AG(n-2) ...| RS(0) AG(1) AG(0)
-//   apply stream                                        | upd(n-1) zero     | upd(n-2) zero ...                  | upd(0) zero
+// FMHIP_EXCHANGE_SHARDED — the same exchange with the update sharded as well:
+//   compute stream  forward | backward(int n-1) | backward(int n-2) | ... | backward(int 0) + statistics | wait(comm stream)
+//   comm stream     rows    |                   | RS(n-1) upd(n-1) AG(n-1) | RS(n-2) upd(n-2) AG(n-2) ... | RS(0) upd(0) AG(0)
 // RS(i) = reduce-scatter of interval i's G_V rows (+ all-reduce of its G_w / G_b entries, 1/Kp of the bytes, one grouped
-// call); upd(i) = this rank's 1/world share of the interval's V rows (and all of its w), zero = the other shares' gradient
-// rows; AG(i) = all-gather of the updated V rows into every replica.  RS + AG moves the bytes of the all-reduce it
-// replaces; the update and the zeroing — 4x the model's bytes on EVERY rank in the dense mode — shrink world-fold.
-// AG(i) is queued behind RS(i-1): the comm stream never idles waiting for an update (queued right behind RS(i) it cost
-// the emulated 8 x 300 GB/s step 0.18 ms of bubbles, profiles/r03_experiments.md).
+// call); upd(i) = ONE launch: this rank's 1/world share of the interval's V rows updated, all of its w stepped, the other
+// shares' gradient rows zeroed; AG(i) = all-gather of the updated V rows into every replica.  RS + AG moves the bytes of
+// the all-reduce it replaces; the update and the zeroing — 4x the model's bytes on EVERY rank in the dense mode — shrink
+// to 1/world + 1x.  All three pieces of an interval sit on the comm stream, in order: no event hops between them (on
+// streams of their own they cost the host ~20 API calls per interval and the host, not the GPU, paced the step —
+// profiles/r03_experiments.md).
 #include "fmhip_internal.h"
 
 #include <dlfcn.h>
@@ -137,34 +137,20 @@ __global__ __launch_bounds__(256) void k_fill_ids(int32_t *dst, const int32_t *f
     dst[i] = v;
 }
 
-// message = [head (kGradHead floats) | per union row: G_V row (kp), G_w, G_b]; ids < 0 (the padding's one entry) travel as zeros
-__global__ __launch_bounds__(256) void k_pack_rows(const int32_t *u, int32_t n_u, int kp, const float *head, const float *GV, const float *Gw,
-                                                   const float *Gb, float *out) {
-    const int rf = kp + 2;
-    const int64_t total = (int64_t)kGradHead + (int64_t)n_u * rf;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        if (i < kGradHead) { out[i] = head[i]; continue; }
-        const int64_t j = (i - kGradHead) / rf;
-        const int c = (int)((i - kGradHead) % rf);
-        const int32_t id = u[j];
-        out[i] = id < 0 ? 0.f : (c < kp ? GV[(size_t)id * kp + c] : (c == kp ? Gw[id] : Gb[id]));
+// pos[i] = the position of ids[i] in the sorted, duplicate-free table u[0..n_u) (ids < 0: -1).  Every id is in the table by
+// construction (the table is the union of every rank's ids, this rank's among them).
+__global__ __launch_bounds__(256) void k_positions(const int32_t *ids, int32_t n, const int32_t *u, int32_t n_u, int32_t *pos) {
+    const int32_t i = (int32_t)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= n) return;
+    const int32_t id = ids[i];
+    if (id < 0) { pos[i] = -1; return; }
+    int32_t lo = 0, hi = n_u;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (u[mid] < id) lo = mid + 1;
+        else hi = mid;
     }
-}
-
-__global__ __launch_bounds__(256) void k_unpack_rows(const int32_t *u, int32_t n_u, int kp, const float *in, float *head, float *GV, float *Gw,
-                                                     float *Gb) {
-    const int rf = kp + 2;
-    const int64_t total = (int64_t)kGradHead + (int64_t)n_u * rf;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        if (i < kGradHead) { head[i] = in[i]; continue; }
-        const int64_t j = (i - kGradHead) / rf;
-        const int c = (int)((i - kGradHead) % rf);
-        const int32_t id = u[j];
-        if (id < 0) continue;
-        if (c < kp) GV[(size_t)id * kp + c] = in[i];
-        else if (c == kp) Gw[id] = in[i];
-        else Gb[id] = in[i];
-    }
+    pos[i] = lo;
 }
 
 // The event set of ONE profiled step.  Sets are created in fmhip_comm_profile_begin (a pool), never inside a step: an
@@ -187,15 +173,26 @@ struct fmhip_comm {
     ncclComm_t comm = nullptr;                // RCCL communicator, or ...
     fmhip_collective_fn ext = nullptr;        // ... the caller's own transport (fmhip_comm_create_external)
     void *ext_ctx = nullptr;
-    // touched-rows exchange (fmhip_dp_exchange): per rank `cap` id slots; the union's rows travel instead of the whole gradient
     int exchange = FMHIP_EXCHANGE_DENSE;
-    int64_t cap = 0;                          // agreed by fmhip_dp_plan: the largest per-batch id count of any rank
-    int32_t *ids = nullptr, *ids_sorted = nullptr, *uniq = nullptr, *n_uniq = nullptr;   // device: [world * cap] x 3, [1]
-    float *msg = nullptr;                     // device: [kGradHead + world * cap * (Kp + 2)]
-    void *tmp = nullptr;                      // rocPRIM temporary storage
-    size_t tmp_bytes = 0;
-    int msg_kp = 0;
-    int64_t touched_rows_sum = 0, touched_steps = 0;   // statistics: union sizes
+    // touched-rows exchange (fmhip_dp_exchange).  The mini-batches of a dataset are fixed, so the rows a lock-step step
+    // touches on ANY rank — the union of every rank's batch t — are known when the plan is made: fmhip_dp_plan forms every
+    // step's union once (all-gather of the ids, sort, unique) together with the position of each of this rank's columns in
+    // it, and a step's gradient is written straight into a COMPACT buffer with one row per union feature (GradView).  A
+    // step then has no id exchange, no sort, no pack / unpack and no host read-back: backward -> all-reduce of the compact
+    // buffer (its size is known on the host) -> rows-only update.
+    struct TStep {
+        int32_t *uni = nullptr;               // device: the union's feature ids, ascending (a leading -1 = padding)
+        int32_t n_u = 0;
+        int32_t *cdst = nullptr;              // device: per compressed column of this rank's batch t, its row in the compact buffer
+        int32_t *hot_pos = nullptr;           // device: the same for the slots of the dense hot block (-1 = unused)
+    };
+    std::vector<TStep> tsteps;                // one per lock-step step of an epoch
+    int64_t t_cursor = 0;                     // the next step of the planned schedule
+    int64_t cap = 0;                          // id slots per rank in the plan's all-gathers: the largest per-batch id count of any rank
+    float *cg = nullptr;                      // device: the compact gradient [ scalars (kGradHead) | G_w | G_b | pad | G_V rows ]
+    size_t cg_floats = 0;
+    int msg_kp = 0;                           // the padded factor count the plan was made for
+    const void *planned_data = nullptr;       // ... and the dataset
     hipStream_t cs = nullptr;                 // the collectives' stream
     hipEvent_t ev_ready[kMaxCuts + 1] = {};   // compute stream: interval i of the gradient is final
     hipEvent_t ev_done[kMaxCuts + 1] = {};    // comm stream: interval i's slice has been exchanged
@@ -209,9 +206,7 @@ struct fmhip_comm {
     size_t prof_next = 0;                     // sets handed out since _begin
     int64_t prof_bytes = 0;
     // sharded update (FMHIP_EXCHANGE_SHARDED)
-    hipStream_t as = nullptr;                 // the updates' (and the gradient zeroing's) stream
-    hipEvent_t ev_applied[kMaxCuts + 1] = {}; // apply stream: this rank's share of interval i is updated (its all-gather may start)
-    hipEvent_t ev_gathered = nullptr;         // comm stream: behind the last all-gather enqueued
+    hipEvent_t ev_gathered = nullptr;         // comm stream: behind the last all-gather of a step
     int emu_ranks = 0;                        // > 0: one real rank plays rank 0 of this many (fmhip_comm_emulate_ranks)
     // agreed by fmhip_dp_plan over all ranks: the largest mini-batch of any rank (rows), so that every size check of a
     // step passes or fails on every rank alike
@@ -327,93 +322,150 @@ int reduce_regions(fmhip_model_t m, fmhip_comm_t c, const Region *reg, int n_reg
 }
 
 void free_touched(fmhip_comm_t c) {
-    for (void *p : {(void *)c->ids, (void *)c->ids_sorted, (void *)c->uniq, (void *)c->n_uniq, (void *)c->msg, c->tmp})
-        if (p) (void)hipFree(p);
-    c->ids = c->ids_sorted = c->uniq = c->n_uniq = nullptr;
-    c->msg = nullptr;
-    c->tmp = nullptr;
-    c->tmp_bytes = 0;
+    for (auto &t : c->tsteps)
+        for (void *p : {(void *)t.uni, (void *)t.cdst, (void *)t.hot_pos})
+            if (p) (void)hipFree(p);
+    c->tsteps.clear();
+    if (c->cg) (void)hipFree(c->cg);
+    c->cg = nullptr;
+    c->cg_floats = 0;
+    c->planned_data = nullptr;
+    c->t_cursor = 0;
 }
 
-// buffers of the touched-rows exchange for `cap` id slots per rank (collective sizes depend on it: every rank the same)
-int size_touched(fmhip_model_t m, fmhip_comm_t c, int64_t cap) {
+// compact-gradient layout for a union of n_u rows: offsets of G_w, G_b, G_V and the total, in floats
+struct CompactLayout {
+    size_t n_up, gw, gb, gv, total;
+    CompactLayout(int32_t n_u, int kp) {
+        n_up = ((size_t)n_u + 3) & ~(size_t)3;
+        gw = (size_t)kGradHead;
+        gb = gw + n_up;
+        gv = (gb + n_up + 31) / 32 * 32;
+        total = gv + n_up * (size_t)kp;
+    }
+};
+
+// The plan of the touched-rows exchange (collective): for every lock-step step t < steps, the union of the rows the ranks'
+// batches t touch, and where this rank's columns lie in it.  Plan-time work: one all-gather, one sort and one 4-byte
+// read-back per step — what every STEP used to pay.
+int plan_touched(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, int64_t cap, int64_t steps) {
     free_touched(c);
     c->cap = cap;
     c->msg_kp = m->Kp;
     const size_t n = (size_t)c->world * (size_t)cap;
     if (n > (size_t)INT32_MAX) return fail(FMHIP_ERR_UNSUPPORTED, "%zu id slots exceed the touched-rows exchange's 2^31 limit", n);
-    size_t a = 0, b = 0;
-    int32_t *k = nullptr;
-    HIP_TRY(rocprim::radix_sort_keys(nullptr, a, k, k, n, 0, 32, m->stream));
-    HIP_TRY(rocprim::unique(nullptr, b, k, k, k, n, rocprim::equal_to<int32_t>(), m->stream));
-    c->tmp_bytes = std::max(a, b);
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->ids), std::max<size_t>(n, 1) * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->ids_sorted), std::max<size_t>(n, 1) * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->uniq), std::max<size_t>(n, 1) * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->n_uniq), sizeof(int32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->msg), ((size_t)kGradHead + n * (size_t)(m->Kp + 2)) * sizeof(float)));
-    HIP_TRY(hipMalloc(&c->tmp, c->tmp_bytes + 16));
+    size_t ta = 0, tb = 0;
+    int32_t *kq = nullptr;
+    HIP_TRY(rocprim::radix_sort_keys(nullptr, ta, kq, kq, n, 0, 32, m->stream));
+    HIP_TRY(rocprim::unique(nullptr, tb, kq, kq, kq, n, rocprim::equal_to<int32_t>(), m->stream));
+    const size_t tmp_bytes = std::max(ta, tb);
+    DevBuf<int32_t> ids, sorted, uniq, n_uniq;
+    DevBuf<uint8_t> tmp;
+    TRY(ids.alloc(std::max<size_t>(n, 1)));
+    TRY(sorted.alloc(std::max<size_t>(n, 1)));
+    TRY(uniq.alloc(std::max<size_t>(n, 1)));
+    TRY(n_uniq.alloc(1));
+    TRY(tmp.alloc(tmp_bytes + 16));
+    const int64_t nb = (int64_t)d->batches.size();
+    const int32_t n_hot = d->hot_pages * kHotT;
+    int32_t max_nu = 0;
+    c->tsteps.resize((size_t)steps);
+    for (int64_t t = 0; t < steps; ++t) {
+        auto &ts = c->tsteps[(size_t)t];
+        const bool live = t < nb;
+        const int32_t *feat = live ? d->cfeat.p + d->batches[(size_t)t].col_off : nullptr;
+        const int32_t n_feat = live ? d->batches[(size_t)t].n_cols : 0;
+        hipLaunchKernelGGL(k_fill_ids, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, m->stream, ids.p + (size_t)c->rank * cap, feat, n_feat,
+                           live ? d->d_hot_ids.p : nullptr, live ? n_hot : 0, cap);
+        HIP_TRY(hipGetLastError());
+        TRY(collective(c, ids.p, (size_t)cap, FMHIP_COLL_ALLGATHER_I32, m->stream));
+        size_t tbytes = tmp_bytes;
+        HIP_TRY(rocprim::radix_sort_keys(tmp.p, tbytes, ids.p, sorted.p, n, 0, 32, m->stream));
+        tbytes = tmp_bytes;
+        HIP_TRY(rocprim::unique(tmp.p, tbytes, sorted.p, uniq.p, n_uniq.p, n, rocprim::equal_to<int32_t>(), m->stream));
+        HIP_TRY(hipMemcpyAsync(&ts.n_u, n_uniq.p, sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        max_nu = std::max(max_nu, ts.n_u);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ts.uni), std::max<size_t>((size_t)ts.n_u, 1) * sizeof(int32_t)));
+        HIP_TRY(hipMemcpyAsync(ts.uni, uniq.p, (size_t)ts.n_u * sizeof(int32_t), hipMemcpyDeviceToDevice, m->stream));
+        if (live) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ts.cdst), std::max<size_t>((size_t)n_feat, 1) * sizeof(int32_t)));
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ts.hot_pos), std::max<size_t>((size_t)n_hot, 1) * sizeof(int32_t)));
+            if (n_feat) {
+                hipLaunchKernelGGL(k_positions, dim3((unsigned)((n_feat + 255) / 256)), dim3(256), 0, m->stream, feat, n_feat, ts.uni, ts.n_u, ts.cdst);
+                HIP_TRY(hipGetLastError());
+            }
+            if (n_hot) {
+                hipLaunchKernelGGL(k_positions, dim3((unsigned)((n_hot + 255) / 256)), dim3(256), 0, m->stream, d->d_hot_ids.p, n_hot, ts.uni, ts.n_u,
+                                   ts.hot_pos);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+    }
+    c->cg_floats = CompactLayout(max_nu, m->Kp).total;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->cg), c->cg_floats * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(c->cg, 0, c->cg_floats * sizeof(float), m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    c->planned_data = d;
     return FMHIP_OK;
 }
 
 // One data-parallel step that exchanges only the gradient rows some rank touched (models far wider than a global batch:
-// C5's 2^25 x 64 table moves 8.9 GB per dense all-reduce and ~0.1 of that here).  All on the compute stream:
-//   |B| -> forward -> backward (whole) -> all-gather of every rank's touched ids -> sort + unique = the union U (the same
-//   on every rank) -> pack [head | G rows of U] -> all-reduce -> unpack -> rows-only update of U with lazy weight decay.
-// One 4-byte read-back per step (|U| sizes the all-reduce).  Replicas stay bit-identical: same U, same sums, same update.
+// C5's 2^25 x 64 table moves 8.9 GB per dense all-reduce and ~0.1 of that here).  Step t of the planned schedule:
+//   |B| -> forward -> backward straight into the compact buffer (row j = feature U_t[j]) -> all-reduce of the buffer ->
+//   rows-only update of U_t with lazy weight decay (which zeroes the buffer's rows again).
+// Nothing is sized on the device: no read-back, no host synchronisation.  Replicas stay bit-identical: same U, same sums,
+// same update.
 int dp_step_touched(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0, double regw, double regv) {
     const bool live = batch >= 0;
-    if (c->cap <= 0 || !c->ids || c->msg_kp != m->Kp)
+    if (c->tsteps.empty() || !c->cg || c->msg_kp != m->Kp)
         return fail(FMHIP_ERR_INVALID, "the touched-rows exchange is not planned for this model: call fmhip_dp_plan (every rank)");
     if (!lazy_decay_ok(eta, regw, regv))
         return fail(FMHIP_ERR_UNSUPPORTED, "the touched-rows exchange needs weight decay that fits the tables' scale (0.5 <= 1 - eta*reg <= 1)");
-    int32_t n_feat = 0, n_hot = 0;
-    const int32_t *feat = nullptr, *hot = nullptr;
-    if (live) {
-        const auto &bm = d->batches[(size_t)batch];
-        n_feat = bm.n_cols;
-        feat = d->cfeat.p + bm.col_off;
-        n_hot = d->hot_pages * kHotT;
-        hot = d->d_hot_ids.p;
-    }
+    const bool packed_dirty = m->grad_dirty;      // this step neither writes nor cleans the model's packed gradient
+    const int64_t t = c->t_cursor;
+    const auto &ts = c->tsteps[(size_t)t];
+    const CompactLayout L(ts.n_u, m->Kp);
+    const GradView view{c->cg, c->cg + L.gw, c->cg + L.gb, c->cg + L.gv, ts.cdst, ts.hot_pos};
     const float my_rows = live ? (float)d->batches[(size_t)batch].rows : 0.f;
     hipLaunchKernelGGL(k_set_float, dim3(1), dim3(1), 0, m->stream, c->rows_dev, my_rows);
     HIP_TRY(hipGetLastError());
     TRY(collective(c, c->rows_dev, 1, FMHIP_COLL_SUM_F32, m->stream));
     if (live) {
-        TRY(step_forward(m, d, batch));
-        TRY(step_backward(m, d, batch, 0, INT64_MAX, true, nullptr));
+        // the packed gradient is not written by this step: a pending memset of it (8.9 GB at C5's width) would be wasted
+        m->grad_dirty = false;
+        int rc = step_forward(m, d, batch);
+        if (rc == FMHIP_OK) {
+            m->view = &view;
+            rc = step_backward(m, d, batch, 0, INT64_MAX, true, nullptr);
+            m->view = nullptr;
+        }
+        m->grad_dirty = packed_dirty;
+        TRY(rc);
     } else {
-        // out of rows: contribute zeros — the rows of G are clean after every update, the scalars in front of them keep the
+        // out of rows: the rows of the compact buffer are clean after every update; the scalars in front of them keep the
         // last step's (already exchanged) sums and must not travel again
-        if (m->grad_dirty) HIP_TRY(hipMemsetAsync(m->grad, 0, m->grad_floats() * sizeof(float), m->stream));
-        else HIP_TRY(hipMemsetAsync(m->grad, 0, (size_t)kGradHead * sizeof(float), m->stream));
-        m->grad_dirty = true;
+        HIP_TRY(hipMemsetAsync(c->cg, 0, (size_t)kGradHead * sizeof(float), m->stream));
         m->last_nnz = m->last_rows = 0;
     }
-    const size_t n = (size_t)c->world * (size_t)c->cap;
-    hipLaunchKernelGGL(k_fill_ids, dim3((unsigned)((c->cap + 255) / 256)), dim3(256), 0, m->stream, c->ids + (size_t)c->rank * c->cap, feat,
-                       n_feat, hot, n_hot, c->cap);
-    HIP_TRY(hipGetLastError());
-    TRY(collective(c, c->ids, (size_t)c->cap, FMHIP_COLL_ALLGATHER_I32, m->stream));
-    size_t tb = c->tmp_bytes;
-    HIP_TRY(rocprim::radix_sort_keys(c->tmp, tb, c->ids, c->ids_sorted, n, 0, 32, m->stream));
-    tb = c->tmp_bytes;
-    HIP_TRY(rocprim::unique(c->tmp, tb, c->ids_sorted, c->uniq, c->n_uniq, n, rocprim::equal_to<int32_t>(), m->stream));
-    int32_t n_u = 0;
-    HIP_TRY(hipMemcpyAsync(&n_u, c->n_uniq, sizeof n_u, hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
-    const size_t floats = (size_t)kGradHead + (size_t)n_u * (size_t)(m->Kp + 2);
-    const unsigned blocks = (unsigned)std::min<size_t>((floats + 255) / 256, 8192);
-    hipLaunchKernelGGL(k_pack_rows, dim3(blocks), dim3(256), 0, m->stream, c->uniq, n_u, m->Kp, m->scal(), m->GV(), m->Gw(), m->Gb(), c->msg);
-    HIP_TRY(hipGetLastError());
-    TRY(collective(c, c->msg, floats, FMHIP_COLL_SUM_F32, m->stream));
-    hipLaunchKernelGGL(k_unpack_rows, dim3(blocks), dim3(256), 0, m->stream, c->uniq, n_u, m->Kp, c->msg, m->scal(), m->GV(), m->Gw(), m->Gb());
-    HIP_TRY(hipGetLastError());
-    TRY(step_apply_rows(m, eta, reg0, regw, regv, c->uniq, n_u, c->rows_dev));
-    c->touched_rows_sum += n_u;
-    c->touched_steps += 1;
-    if (c->profiling) c->prof_bytes += (int64_t)(floats * sizeof(float) + (size_t)c->cap * c->world * sizeof(int32_t));
+    m->bw_next_hi = -1;
+    CommProf *pr = next_prof(c);
+    if (pr) {
+        HIP_TRY(hipEventRecord(pr->wait_a, m->stream));
+        HIP_TRY(hipEventRecord(pr->c0[pr->n_coll], m->stream));
+    }
+    TRY(collective(c, c->cg, L.total, FMHIP_COLL_SUM_F32, m->stream));
+    TRY(emu_delay(c, (double)L.total * sizeof(float), m->stream));
+    if (pr) {
+        HIP_TRY(hipEventRecord(pr->c1[pr->n_coll++], m->stream));
+        HIP_TRY(hipEventRecord(pr->wait_b, m->stream));        // nothing overlaps: the whole exchange is exposed
+    }
+    // the step's global sums where fmhip_step_stats / fmhip_dp_epoch read them
+    HIP_TRY(hipMemcpyAsync(m->scal(), c->cg, (size_t)kScalars * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
+    TRY(step_apply_rows(m, eta, reg0, regw, regv, ts.uni, ts.n_u, c->rows_dev, &view));
+    m->grad_dirty = packed_dirty;
+    c->t_cursor = (t + 1) % (int64_t)c->tsteps.size();
+    if (c->profiling) c->prof_bytes += (int64_t)(L.total * sizeof(float));
     return FMHIP_OK;
 }
 
@@ -520,25 +572,7 @@ int dp_step_sharded(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_com
     edge.push_back(m->n1);
     const int n_int = (int)edge.size() - 1;
     const size_t kp = (size_t)m->Kp;
-    const double ar_scale = 1.0, half = 0.5;                          // emulated durations: a reduce-scatter or an all-gather is half an all-reduce
-    // the all-gather of interval i's updated V rows (in place: every rank's share already lies where it belongs)
-    auto gather = [&](int i) -> int {
-        const int64_t lo = edge[(size_t)i], hi_r = i == n_int - 1 ? top : edge[(size_t)i + 1];
-        const int64_t chunk = (hi_r - lo) / W;
-        const int64_t vlo = lo + (int64_t)R * chunk;
-        HIP_TRY(hipStreamWaitEvent(c->cs, c->ev_applied[i], 0));
-        int pi = -1;
-        if (pr && pr->n_coll < kProfColl) {
-            pi = pr->n_coll++;
-            HIP_TRY(hipEventRecord(pr->c0[pi], c->cs));
-        }
-        // one real rank playing `emu_ranks`: the collective runs on its own share (in place), the delay is the interval's
-        TRY(collective(c, m->V.p + (size_t)(c->emu_ranks > 0 ? vlo : lo) * kp, (size_t)chunk * kp, FMHIP_COLL_ALLGATHER_F32, c->cs));
-        TRY(emu_delay(c, half * (double)(hi_r - lo) * kp * sizeof(float), c->cs));
-        if (pi >= 0) HIP_TRY(hipEventRecord(pr->c1[pi], c->cs));
-        HIP_TRY(hipEventRecord(c->ev_gathered, c->cs));
-        return FMHIP_OK;
-    };
+    const double half = 0.5;            // emulated durations: a reduce-scatter or an all-gather is half an all-reduce of the same bytes
     for (int i = n_int - 1; i >= 0; --i) {
         const int64_t lo = edge[(size_t)i], hi = edge[(size_t)i + 1];
         const bool last = i == 0;
@@ -546,7 +580,14 @@ int dp_step_sharded(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_com
         const int64_t hi_r = i == n_int - 1 ? top : hi;              // the top interval reaches into the slack rows
         const int64_t chunk = (hi_r - lo) / W;
         const int64_t vlo = lo + (int64_t)R * chunk, vhi = vlo + chunk;
-        // ---- exchange of the interval's gradient
+        // one real rank playing `emu_ranks`: the collectives run on its own share (in place), the delays are the interval's
+        const size_t count = (size_t)chunk * kp, at = (size_t)(c->emu_ranks > 0 ? vlo : lo) * kp;
+        float *gw = last ? m->grad : m->Gw() + lo;
+        const size_t n_gw = (size_t)(hi - lo) + (last ? (size_t)kGradHead : 0), n_gb = (size_t)(hi - lo);
+        const double gv_bytes = (double)(hi_r - lo) * kp * sizeof(float), head_bytes = (double)(n_gw + n_gb) * sizeof(float);
+        // Everything behind the backward is queued on the comm stream, in order — no event hops between the pieces:
+        //   reduce-scatter of G_V (+ all-reduce of G_w, G_b: one grouped call) -> this rank's share of the update, the other
+        //   shares' gradient rows zeroed (one launch) -> all-gather of the updated V rows
         HIP_TRY(hipEventRecord(c->ev_ready[i], m->stream));
         HIP_TRY(hipStreamWaitEvent(c->cs, c->ev_ready[i], 0));
         int pi = -1;
@@ -554,37 +595,29 @@ int dp_step_sharded(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_com
             pi = pr->n_coll++;
             HIP_TRY(hipEventRecord(pr->c0[pi], c->cs));
         }
-        float *gw = last ? m->grad : m->Gw() + lo;
-        const size_t n_gw = (size_t)(hi - lo) + (last ? (size_t)kGradHead : 0), n_gb = (size_t)(hi - lo);
-        // one real rank playing `emu_ranks`: the collective runs on its own share (in place), the delay is the interval's
-        const size_t rs_count = (size_t)chunk * kp;
-        float *rs_buf = m->GV() + (size_t)(c->emu_ranks > 0 ? vlo : lo) * kp;
         if (!c->ext) NCCL_TRY(rccl().GroupStart());
-        TRY(collective(c, rs_buf, rs_count, FMHIP_COLL_REDUCE_SCATTER_F32, c->cs));
+        TRY(collective(c, m->GV() + at, count, FMHIP_COLL_REDUCE_SCATTER_F32, c->cs));
         TRY(collective(c, gw, n_gw, FMHIP_COLL_SUM_F32, c->cs));
         TRY(collective(c, m->Gb() + lo, n_gb, FMHIP_COLL_SUM_F32, c->cs));
         if (!c->ext) NCCL_TRY(rccl().GroupEnd());
-        const double gv_bytes = (double)(hi_r - lo) * kp * sizeof(float), head_bytes = (double)(n_gw + n_gb) * sizeof(float);
-        TRY(emu_delay(c, half * gv_bytes + ar_scale * head_bytes, c->cs));
+        TRY(emu_delay(c, half * gv_bytes + head_bytes, c->cs));
         if (pi >= 0) HIP_TRY(hipEventRecord(pr->c1[pi], c->cs));
-        HIP_TRY(hipEventRecord(c->ev_done[i], c->cs));
-        // ---- this rank's share of the update, the other shares' rows zeroed (apply stream)
-        HIP_TRY(hipStreamWaitEvent(c->as, c->ev_done[i], 0));
-        TRY(step_apply_shard(m, eta, reg0, regw, regv, lo, hi, vlo, vhi, c->rows_dev, last, c->as));
-        if (vlo > lo) HIP_TRY(hipMemsetAsync(m->GV() + (size_t)lo * kp, 0, (size_t)(vlo - lo) * kp * sizeof(float), c->as));
-        if (hi_r > vhi) HIP_TRY(hipMemsetAsync(m->GV() + (size_t)vhi * kp, 0, (size_t)(hi_r - vhi) * kp * sizeof(float), c->as));
-        HIP_TRY(hipEventRecord(c->ev_applied[i], c->as));
-        // ---- the updated rows travel to every replica — one interval LATER on the comm stream (behind the next interval's
-        // reduce-scatter), so that the collectives never wait for an update: by then this interval's share is long written
-        if (i < n_int - 1) TRY(gather(i + 1));
+        TRY(step_apply_shard(m, eta, reg0, regw, regv, lo, hi, hi_r, vlo, vhi, c->rows_dev, last, c->cs));
+        pi = -1;
+        if (pr && pr->n_coll < kProfColl) {
+            pi = pr->n_coll++;
+            HIP_TRY(hipEventRecord(pr->c0[pi], c->cs));
+        }
+        TRY(collective(c, m->V.p + at, count, FMHIP_COLL_ALLGATHER_F32, c->cs));
+        TRY(emu_delay(c, half * gv_bytes, c->cs));
+        if (pi >= 0) HIP_TRY(hipEventRecord(pr->c1[pi], c->cs));
         if (c->profiling) c->prof_bytes += (int64_t)(gv_bytes + head_bytes);
     }
-    TRY(gather(0));
+    HIP_TRY(hipEventRecord(c->ev_gathered, c->cs));
     m->bw_next_hi = -1;
-    // the next forward reads V (every all-gather must have landed) and the next backward writes G (every zeroing done)
+    // the next forward reads V and the next backward writes G: everything queued on the comm stream must have landed
     if (pr) HIP_TRY(hipEventRecord(pr->wait_a, m->stream));
     HIP_TRY(hipStreamWaitEvent(m->stream, c->ev_gathered, 0));
-    HIP_TRY(hipStreamWaitEvent(m->stream, c->ev_applied[0], 0));
     if (pr) HIP_TRY(hipEventRecord(pr->wait_b, m->stream));
     m->grad_dirty = false;
     return FMHIP_OK;
@@ -593,7 +626,7 @@ int dp_step_sharded(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_com
 // A step's size checks that depend on THIS rank's batch only.  A failure here must not leave the peers waiting in a
 // collective: the caller runs the step with a zero contribution (as a rank that has run out of rows does) and
 // reports the error afterwards.
-int local_checks(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c) {
+int local_checks(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, bool in_schedule = true) {
     (void)m;
     if (batch < 0) return FMHIP_OK;
     const auto &bm = d->batches[(size_t)batch];
@@ -606,9 +639,14 @@ int local_checks(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t
         return fail(FMHIP_ERR_INVALID, "batch %lld has %lld rows, the plan covers batches of up to %lld (a global batch must stay below 2^24 "
                                        "rows): call fmhip_dp_plan with this dataset (every rank)",
                     (long long)batch, (long long)bm.rows, (long long)c->plan_max_rows);
-    if (c->exchange == FMHIP_EXCHANGE_TOUCHED && (int64_t)bm.n_cols + d->hot_pages * kHotT > c->cap)
-        return fail(FMHIP_ERR_INVALID, "batch %lld touches %d rows, the plan allows %lld: call fmhip_dp_plan with this dataset (every rank)",
-                    (long long)batch, bm.n_cols + d->hot_pages * kHotT, (long long)c->cap);
+    if (c->exchange == FMHIP_EXCHANGE_TOUCHED) {
+        // the unions were formed for the lock-step schedule "step t = every rank's batch t" of ONE dataset
+        if (c->planned_data != d)
+            return fail(FMHIP_ERR_INVALID, "the touched-rows exchange was planned for another dataset: call fmhip_dp_plan with this one (every rank)");
+        if (in_schedule && batch != c->t_cursor)
+            return fail(FMHIP_ERR_INVALID, "the touched-rows exchange steps through the planned schedule in order: step %lld takes batch %lld "
+                                           "(or -1 on a rank without it), not batch %lld", (long long)c->t_cursor, (long long)c->t_cursor, (long long)batch);
+    }
     return FMHIP_OK;
 }
 
@@ -656,8 +694,6 @@ static int comm_resources(fmhip_comm *c) {
     for (int i = 0; i <= kMaxCuts && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_ready[i], hipEventDisableTiming);
     for (int i = 0; i <= kMaxCuts && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->as, hipStreamNonBlocking);
-    for (int i = 0; i <= kMaxCuts && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_applied[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->scratch), (kMaxCuts + 1) * sizeof(int64_t));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->rows_dev), 32 * sizeof(float));
@@ -741,12 +777,8 @@ int fmhip_comm_destroy(fmhip_comm_t c) {
     if (!c) return FMHIP_OK;
     (void)hipSetDevice(c->device);
     if (c->cs) (void)hipStreamSynchronize(c->cs);
-    if (c->as) (void)hipStreamSynchronize(c->as);
     for (auto &p : c->prof) destroy_events(p);
-    for (hipEvent_t e : c->ev_applied)
-        if (e) (void)hipEventDestroy(e);
     if (c->ev_gathered) (void)hipEventDestroy(c->ev_gathered);
-    if (c->as) (void)hipStreamDestroy(c->as);
     free_touched(c);
     if (c->comm) (void)rccl().CommDestroy(c->comm);
     for (hipEvent_t e : c->ev_ready)
@@ -790,7 +822,11 @@ int fmhip_dp_exchange_info(fmhip_comm_t c, int *mode, int64_t *id_slots_per_rank
     if (!c) return fail(FMHIP_ERR_INVALID, "communicator is NULL");
     if (mode) *mode = c->exchange;
     if (id_slots_per_rank) *id_slots_per_rank = c->cap;
-    if (mean_union_rows) *mean_union_rows = c->touched_steps ? (double)c->touched_rows_sum / (double)c->touched_steps : 0.0;
+    if (mean_union_rows) {
+        double sum = 0.0;
+        for (const auto &t : c->tsteps) sum += t.n_u;
+        *mean_union_rows = c->tsteps.empty() ? 0.0 : sum / (double)c->tsteps.size();       // over the planned steps
+    }
     return FMHIP_OK;
 }
 
@@ -831,7 +867,7 @@ int fmhip_dp_plan(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, int n_frac
     // its global row count travels as one fp32 sum, exact below 2^24 —, whether some rank's transposes are row-blocked
     // (it cannot cut its backward: then nobody does, same collectives everywhere), the touched-rows table's width, and
     // whether some rank cannot hold the sharded exchange's equal shares.  All ranks pass or fail together.
-    int64_t agree[4] = {0, d->rb_rows != 0, 1, 0};
+    int64_t agree[5] = {0, d->rb_rows != 0, 1, 0, (int64_t)d->batches.size()};
     for (const auto &bm : d->batches) {
         agree[0] = std::max<int64_t>(agree[0], bm.rows);
         agree[2] = std::max<int64_t>(agree[2], (int64_t)bm.n_cols + d->hot_pages * kHotT);
@@ -839,7 +875,7 @@ int fmhip_dp_plan(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, int n_frac
     const int W = c->emu_ranks > 0 ? c->emu_ranks : c->world;
     if (c->exchange == FMHIP_EXCHANGE_SHARDED)
         agree[3] = shard_top(m, W) > m->n1p + (m->grad == m->grad_own.p ? (int64_t)fmhip_model::kSlackRows : 0);
-    TRY(control_i64(m, c, agree, 4, false));
+    TRY(control_i64(m, c, agree, 5, false));
     if ((double)agree[0] * c->world >= 16777216.0)
         return fail(FMHIP_ERR_INVALID, "a global batch of %lld x %d rows exceeds 2^24 (the summed row count travels as one fp32 word): "
                                        "use smaller batches", (long long)agree[0], c->world);
@@ -849,9 +885,10 @@ int fmhip_dp_plan(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, int n_frac
     c->plan_max_rows = agree[0];
     const int64_t blocked = agree[1];
     if (c->exchange == FMHIP_EXCHANGE_TOUCHED) {
-        // the id table's width: the largest number of rows any batch of any rank touches
-        const int64_t cap = agree[2];
-        if (cap != c->cap || c->msg_kp != m->Kp || !c->ids) TRY(size_touched(m, c, cap));
+        if (blocked)
+            return fail(FMHIP_ERR_UNSUPPORTED, "the touched-rows exchange needs transposes without row blocks (some rank's dataset has them)");
+        // id slots per rank = the largest number of rows any batch of any rank touches; steps = the largest batch count
+        TRY(plan_touched(m, d, c, agree[2], agree[4]));
     }
     TRY(control_i64(m, c, cuts, kMaxCuts + 1, true));
     c->cuts.clear();
@@ -882,13 +919,19 @@ int fmhip_dp_epoch(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double et
     // every rank takes the same number of steps — the largest local batch count — and every rank learns whether SOME
     // rank's dataset does not fit the plan (then all of them stop here, none inside a collective)
     int64_t agree[2] = {nb, 0};
-    for (int64_t j = 0; j < nb && !agree[1]; ++j) agree[1] = local_checks(m, d, j, c) != FMHIP_OK;
+    for (int64_t j = 0; j < nb && !agree[1]; ++j) agree[1] = local_checks(m, d, j, c, false) != FMHIP_OK;
     const std::string why = agree[1] ? fmhip_last_error() : "";
     TRY(control_i64(m, c, agree, 2, false));
     if (agree[1])
         return fail(FMHIP_ERR_INVALID, "%s", why.empty() ? "another rank's dataset does not fit the communicator's plan: call fmhip_dp_plan "
                                                            "with the datasets of this epoch (every rank)" : why.c_str());
     const int64_t steps = agree[0];
+    if (c->exchange == FMHIP_EXCHANGE_TOUCHED) {
+        if (steps != (int64_t)c->tsteps.size())
+            return fail(FMHIP_ERR_INVALID, "the touched-rows plan covers %zu steps, this epoch has %lld: call fmhip_dp_plan with this dataset (every rank)",
+                        c->tsteps.size(), (long long)steps);
+        c->t_cursor = 0;
+    }
     for (int64_t j = 0; j < steps; ++j) TRY(dp_step(m, d, j < nb ? j : -1, c, eta, reg0, regw, regv));
     if (stats) {
         memset(stats, 0, sizeof *stats);

@@ -78,6 +78,14 @@ struct BatchMeta {
     int64_t own_off = -1;   // offset (in words) of the batch's bitmap of fixup-owned features, -1 = none
 };
 
+// Where a backward delivers its gradient rows when NOT into the model's packed buffer: the touched-rows exchange
+// (fmhip_comm.hip) points the column walk at a compact buffer that holds one row per feature of the step's union
+struct GradView {
+    float *scal, *Gw, *Gb, *GV;
+    const int32_t *cdst;       // per compressed column of the batch: its row in GV / Gw / Gb
+    const int32_t *hot_pos;    // per slot of the dense hot block: its row (-1 = unused slot)
+};
+
 struct ProfRec {
     int kind;
     hipEvent_t a, b;
@@ -146,6 +154,7 @@ struct fmhip_model {
     DevBuf<float> V, w, w0;
     DevBuf<float> grad_own;
     float *grad = nullptr;        // packed gradient in use (own or bound)
+    const fmhip::host::GradView *view = nullptr;   // set around a backward that writes elsewhere (see GradView)
     bool grad_dirty = false;      // holds a gradient that has not been applied/zeroed
     DevBuf<float> P, e, part, pieces, hot_part;
     bool hot_pending = false;   // the dense hot block's gradient of the current step is still to be formed
@@ -205,14 +214,16 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
 int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double regv, fmhip_dataset_t d = nullptr, int64_t b = -1);
 int step_apply_interval(fmhip_model_t m, double eta, double reg0, double regw, double regv, int64_t lo, int64_t hi,
                         const float *rows, bool last);
-// The sharded update of the feature interval [lo, hi) on stream `s`: V rows [vlo, vhi) (this rank's share; their w too) by
-// the dense pass, the linear weights of the rest of the interval by k_apply_w.  `last`: also steps w0 and closes the step.
-int step_apply_shard(fmhip_model_t m, double eta, double reg0, double regw, double regv, int64_t lo, int64_t hi, int64_t vlo,
-                     int64_t vhi, const float *rows, bool last, hipStream_t s);
+// The sharded update of the feature interval [lo, hi) on stream `s` (one launch): V rows [vlo, vhi) (this rank's share) get
+// the dense update, every linear weight of the interval is stepped, the G_V rows of [lo, hi_r) outside the share are zeroed
+// (hi_r >= hi: the top interval's equal shares reach into the slack rows).  `last`: also steps w0 and closes the step.
+int step_apply_shard(fmhip_model_t m, double eta, double reg0, double regw, double regv, int64_t lo, int64_t hi, int64_t hi_r,
+                     int64_t vlo, int64_t vhi, const float *rows, bool last, hipStream_t s);
 // the rows-only (lazy-decay) update of the feature rows listed on the device (ids < 0 are skipped), |B| from `rows`
 // (device float): the touched-rows exchange of the data-parallel step applies the union of all ranks' rows with it
+// view given: the gradient rows are read from (and zeroed in) its compact arrays, row j belonging to feature feat[j]
 int step_apply_rows(fmhip_model_t m, double eta, double reg0, double regw, double regv, const int32_t *feat, int32_t n_feat,
-                    const float *rows);
+                    const float *rows, const GradView *view = nullptr);
 bool lazy_decay_ok(double eta, double regw, double regv);
 int read_scal(fmhip_model_t m, fmhip_stats *st);
 

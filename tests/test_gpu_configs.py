@@ -471,10 +471,12 @@ def test_bench_with_two_ranks_on_one_gpu():
 @pytest.mark.parametrize("world,n1", [(2, 800), (3, 50_000)])
 def test_touched_rows_exchange_on_one_gpu_host_staged(world, n1):
     """fmhip_dp_exchange(FMHIP_EXCHANGE_TOUCHED): the data-parallel step that exchanges only the gradient rows some rank
-    touched (all-gather of ids -> sorted union -> packed all-reduce -> rows-only update with lazy weight decay), with two and
-    three real ranks on one GPU over the host-staged transport; uneven shards, a rank without rows, a model of 50,000
-    features of which the data touch 800 (the untouched rows must decay exactly as in the oracle's dense update).
-    Replicas bit-identical, same collectives everywhere, the oracle over the global batches matched."""
+    touched — the unions of the lock-step schedule formed once, in the plan (all-gather of ids -> sort -> unique per step),
+    the backward writing straight into a compact buffer with one row per union feature, one all-reduce of that buffer,
+    rows-only update with lazy weight decay — with two and three real ranks on one GPU over the host-staged transport;
+    uneven shards, a rank without rows, a model of 50,000 features of which the data touch 800 (the untouched rows must
+    decay exactly as in the oracle's dense update).  Replicas bit-identical, same collectives everywhere, the oracle over
+    the global batches matched."""
     import tempfile
     port, out = str(_free_port()), os.path.join(tempfile.mkdtemp(), "dp")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_rccl_worker.py"), str(r), str(world), port, out, "host", "",
@@ -490,10 +492,11 @@ def test_touched_rows_exchange_on_one_gpu_host_staged(world, n1):
         np.testing.assert_array_equal(r0["calls"], r1["calls"])
     assert int(r0["steps"]) == 3 and int(r0["rows"]) == 1000
     kinds = r0["calls"][:, 0]
-    assert (kinds == 3).sum() == 6 and (kinds == 0).sum() == 12          # per step: one id all-gather, the row count + the packed rows
-    assert 0 < float(r0["mean_union"]) <= 801                             # the union of the touched rows, not the model
+    # the plan (made once for both epochs): one id all-gather per step of the schedule; per step: the row count + the compact buffer
+    assert (kinds == 3).sum() == 3 and (kinds == 0).sum() == 12
+    assert 0 < float(r0["mean_union"]) <= 802                             # the union of the touched rows (+ one padding entry), not the model
     packed = r0["calls"][(kinds == 0) & (r0["calls"][:, 1] > 1)][:, 1]
-    assert packed.max() <= 32 + 801 * 34 and (packed < 0.1 * n1 * 34).all() or n1 == 800
+    assert len(packed) == 6 and packed.max() <= 1664 + 804 * 32 and ((packed < 0.1 * n1 * 34).all() or n1 == 800)
     w0, w, v = _oracle_two_rank_epochs(n1)
     assert rel(r0["v"], v) <= 1e-5 and rel(r0["w"], w) <= 1e-5 and float(r0["w0"]) == pytest.approx(w0, rel=1e-5, abs=1e-7)
 
