@@ -178,6 +178,100 @@ def committed_pmc(config, k, batch_rows):
     return out
 
 
+STEP_KERNELS = ("k_forward", "k_backward", "k_fixup", "k_apply")
+
+
+def pmc_pass(counters, child_argv, skip=4, timeout_s=300):
+    """One `rocprofv3 --pmc <counters> -- python3 <child_argv>` run (counter collection only: no trace domain beside it) as
+    a CHILD process; -> {kernel: {counter: mean per dispatch after the first `skip` dispatches of that kernel}} for the
+    kernels of the SGD step, or None when rocprofv3 is not there / fails (the caller falls back to the committed profile).
+    Kernel names are folded as in tools/make_pmc_json.py (k_forward_wt -> k_forward, k_backward_p -> k_backward, ...)."""
+    import collections
+    import csv
+    import glob
+    import re
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out_dir = tempfile.mkdtemp(prefix="fmhip_pmc_", dir="/tmp")
+    try:
+        cmd = [exe, "--pmc"] + list(counters) + ["-d", out_dir, "-o", "pmc", "--output-format", "csv", "--", sys.executable] + list(child_argv)
+        env = dict(os.environ, TMPDIR="/tmp")
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+        if r.returncode != 0:
+            sys.stderr.write("[bench] rocprofv3 --pmc %s failed (rc %d): %s\n" % (" ".join(counters), r.returncode, r.stderr.decode()[-400:]))
+            return None
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                m = re.search(r"(k_[a-z_0-9]+)", row["Kernel_Name"])
+                if not m or not m.group(1).startswith(STEP_KERNELS):
+                    continue
+                kn = m.group(1).replace("k_forward_wt", "k_forward").replace("k_forward_lds", "k_forward").replace("k_backward_p", "k_backward").replace("k_apply_rows", "k_apply")
+                agg[kn][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        return {kn: {cn: sum(v[skip:]) / max(len(v[skip:]), 1) for cn, v in cs.items() if len(v) > skip} for kn, cs in agg.items()} or None
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError) as ex:
+        sys.stderr.write("[bench] rocprofv3 --pmc pass failed: %r\n" % (ex,))
+        return None
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+
+
+def live_pmc(child_argv):
+    """Fabric-side traffic per launch of the step's kernels, measured NOW: two rocprofv3 passes (FETCH_SIZE and WRITE_SIZE
+    do not fit one) over tools/pmc_leg.py running the same workload.  Units and the gfx950 correction as
+    MI355X_MICROARCH.md prescribes: both counters are KiB; FETCH_SIZE tallies the 128-B requests of wide (16 B per lane)
+    reads at 64 B — the row gathers and the dense block's streams are such reads, the 4-B index / value streams are not and
+    the counter cannot tell them apart, so the doubled figure is an upper bound.  -> {kernel: {...}} or None."""
+    fetch = pmc_pass(["FETCH_SIZE"], child_argv)
+    write = pmc_pass(["WRITE_SIZE"], child_argv) if fetch else None
+    if not fetch or not write:
+        return None
+    out = {}
+    for kn in fetch:
+        fr, wr = fetch[kn].get("FETCH_SIZE"), write.get(kn, {}).get("WRITE_SIZE")
+        if fr is None or wr is None:
+            continue
+        out[kn] = {"fetch_raw_bytes": int(fr * 1024), "fetch_corrected_bytes": int(2 * fr * 1024), "write_bytes": int(wr * 1024),
+                   "traffic_bytes": int(2 * fr * 1024 + wr * 1024)}
+    if out:
+        out["step"] = {"traffic_bytes": sum(e["traffic_bytes"] for e in out.values())}
+    return out or None
+
+
+def roofline_block(kern, dom, ab, pd, pmc, step_ms, live):
+    """`roofline` of the JSON line for the dominant kernel `dom`: achieved = bytes the rocprofv3 counters saw leave the L2s per
+    launch (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md's units and gfx950 correction) / that kernel's launch duration
+    measured by HIP events in THIS run; frac = achieved / 8 TB/s.  The algorithmic figure of SURVEY §8(d) is kept beside it,
+    flagged: it prices every stored nonzero at a gathered row and is not an HBM rate."""
+    e = kern.get(dom, {})
+    avg_ms = e.get("avg_ms")
+    traffic = e.get("traffic_bytes")
+    basis = "counters"
+    if traffic is None:           # no profile of this configuration anywhere: our own count of the kernel's loads and stores
+        traffic, basis = e.get("requested_bytes_per_launch"), "requested bytes (no counter pass exists for this configuration)"
+    achieved = traffic / (avg_ms * 1e-3) / 1e9 if traffic and avg_ms else None
+    step_traffic = pmc.get("step", {}).get("traffic_bytes")
+    alg = e.get("alg_GBps")
+    return {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": achieved * 1e9 / HBM_PEAK if achieved else None, "traffic": traffic, "basis": basis,
+            "traffic_source": e.get("traffic_source"), "traffic_measured_in_this_run": bool(live),
+            "avg_launch_ms": avg_ms, "nnz_per_launch": pd[dom]["nnz"] / max(pd[dom]["launches"], 1),
+            "what": "achieved = fabric-side bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE: what left the L2s; Infinity-Cache hits "
+                    "are included — the part exposes no DRAM-side or MALL hit counter, profiles/README.md — so an upper bound on HBM bytes) / "
+                    "the launch's duration by HIP events in this run; frac = achieved / 8 TB/s",
+            "step": {"traffic": step_traffic, "achieved": step_traffic / (step_ms * 1e-3) / 1e9 if step_traffic else None,
+                     "frac": step_traffic / (step_ms * 1e-3) / HBM_PEAK if step_traffic else None,
+                     "what": "the same for the whole step: the counters' bytes of all its kernels / the measured step time"},
+            "algorithmic_bytes_per_nnz": ab[dom], "algorithmic_achieved": alg, "algorithmic_frac": alg * 1e9 / HBM_PEAK if alg else None,
+            "algorithmic_note": "SURVEY §8(d)'s figure (4k+4 B for EVERY stored nonzero of the batch / launch time): NOT an HBM rate and may "
+                                "pass the peak — V, P and the gradient live in L2 / Infinity Cache at this size and the nonzeros of the dense "
+                                "hot block cost one streamed value instead of a gathered row",
+            "requested_GBps": e.get("requested_GBps"), "ceiling": e.get("ceiling"), "frac_of_ceiling": e.get("frac_of_ceiling")}
+
+
 def kernel_table(prof, k, kp, req, pmc, table_bytes):
     """Per-kernel: HIP-event time, algorithmic rate, requested-byte rate, the ceiling
     that binds it and the fraction of THAT ceiling."""
@@ -205,9 +299,12 @@ def kernel_table(prof, k, kp, req, pmc, table_bytes):
             else:
                 ent["ceiling"] = {"name": "hbm_stream", "GBps": CEIL["hbm_stream"] / 1e9}
             ent["frac_of_ceiling"] = ent["requested_GBps"] / ent["ceiling"]["GBps"]
-        t = pmc.get("k_" + name, {}).get("traffic_bytes")
-        if t is not None:
-            ent["traffic_from_committed_profile"] = t
+        pe = pmc.get("k_" + name, {})
+        if pe.get("traffic_bytes") is not None:
+            ent["traffic_bytes"] = pe["traffic_bytes"]           # fabric-side: FETCH_SIZE x2 + WRITE_SIZE per launch
+            ent["traffic_source"] = pe.get("traffic_source", "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this configuration)")
+            ent["traffic_GBps"] = pe["traffic_bytes"] / (avg_ms * 1e-3) / 1e9
+            ent["traffic_frac_of_8TBps"] = ent["traffic_GBps"] * 1e9 / HBM_PEAK
         kern[name] = ent
     if "apply" in req and "apply" not in kern and "fixup" in kern:
         # merged finish: the dense update ran inside the fixup launch (fmhip_tune key 11)
@@ -220,66 +317,103 @@ def kernel_table(prof, k, kp, req, pmc, table_bytes):
     return kern
 
 
-def hbm_resident_leg(device, steps=24, rows=500_000, batch_rows=250_000):
-    """A model that does NOT fit the caches: C5's width (2^25 hashed slots, k=64 -> V = 8.6 GB, packed
-    gradient 8.9 GB) on one GPU, Criteo-shaped rows, weight decay on (lazy rows-only update).  The one
-    place where algorithmic bytes are HBM bytes."""
+def hbm_resident_leg(device, steps=48, rows=6_000_000, batch_rows=250_000, hashed_too=True, with_pmc=True):
+    """A model AND a working set that do not fit the caches: C5's width (2^25 hashed slots, k=64 -> V = 8.6 GB, packed
+    gradient 8.9 GB) on one GPU, 6M Criteo-shaped rows = 24 DISTINCT mini-batches of 250k rows, weight decay on (lazy
+    rows-only update).  One batch touches ~0.4M parameter rows (~100 MB of V); 24 different ones in a row push well over
+    1 GB of V rows, 1.5 GB of P and 1.7 GB of index/value streams through the 256 MiB Infinity Cache between two uses of a
+    line (round 2 cycled TWO batches: ~120 MB of V, cache-resident).  Run with the ids relabelled by frequency at load and,
+    for comparison, as hashed.  The one place where the counters' bytes are, to a large part, HBM bytes."""
     from sparkfm_amd import DataSet, FeatureOrder, FMModel, _ffi, synth
     L = _ffi.load()
     n1, k = 1 << 25, 64
-    d = synth.make_config("C5", rows=rows)
-    # hashed slots come in no particular order: relabel by frequency at load (a pure renaming, sparkfm_amd.FeatureOrder)
-    d["col"] = FeatureOrder.fit(d["col"], n1).relabel(d["col"])
-    ds = DataSet.from_arrays(d, batch_rows=batch_rows, device=device).cache()
-    fm = FMModel(n1 - 1, k, seed=5, device=device, init_on_device=True)
-    hm, hd, nb = fm.handle, ds.handle, ds.n_batches
     regs = (0.0, 1e-4, 1e-4)
-    bnnz = [ds.batch_info(b)["nnz"] for b in range(nb)]
-    for j in range(4):
-        _ffi.check(L.fmhip_sgd_step(hm, hd, j % nb, 0.02, *regs, None))
-    _ffi.check(L.fmhip_synchronize(hm))
-    _ffi.check(L.fmhip_profile_begin_rotating(hm))
-    t0 = time.perf_counter()
-    for j in range(steps):
-        _ffi.check(L.fmhip_sgd_step(hm, hd, j % nb, 0.02, *regs, None))
-    _ffi.check(L.fmhip_synchronize(hm))
-    dt = time.perf_counter() - t0
-    prof = _ffi.Profile()
-    _ffi.check(L.fmhip_profile_end(hm, C.byref(prof)))
-    st = _ffi.Stats()
-    _ffi.check(L.fmhip_step_stats(hm, C.byref(st)))
-    nnz = sum(bnnz[j % nb] for j in range(steps))
-    value = nnz / dt
     ab = alg_bytes(k)
-    lay = ds.layout()
-    bi = ds.batch_info(0)
-    share = lay["nnz_sparse"] / max(int(d["row_ptr"][-1]), 1)          # what stayed in the sparse streams (forward)
-    share_b = lay["nnz_sparse_backward"] / max(int(d["row_ptr"][-1]), 1)  # ... in the transposes (backward)
+    t0 = time.time()
+    d = synth.make_config("C5", rows=rows)
+    t_gen = time.time() - t0
+    col_hashed = d["col"]
+    nnz_total = int(d["row_ptr"][-1])
+
+    def run(col, n_steps, name):
+        d["col"] = col
+        ds = DataSet.from_arrays(d, batch_rows=batch_rows, device=device).cache()
+        fm = FMModel(n1 - 1, k, seed=5, device=device, init_on_device=True)
+        hm, hd, nb = fm.handle, ds.handle, ds.n_batches
+        bnnz = [ds.batch_info(b)["nnz"] for b in range(nb)]
+        for j in range(min(nb, 8)):
+            _ffi.check(L.fmhip_sgd_step(hm, hd, j % nb, 0.02, *regs, None))
+        _ffi.check(L.fmhip_synchronize(hm))
+        _ffi.check(L.fmhip_profile_begin_sampled(hm, 2))
+        t1 = time.perf_counter()
+        for j in range(n_steps):
+            _ffi.check(L.fmhip_sgd_step(hm, hd, (8 + j) % nb, 0.02, *regs, None))
+        _ffi.check(L.fmhip_synchronize(hm))
+        dt = time.perf_counter() - t1
+        prof = _ffi.Profile()
+        _ffi.check(L.fmhip_profile_end(hm, C.byref(prof)))
+        st = _ffi.Stats()
+        _ffi.check(L.fmhip_step_stats(hm, C.byref(st)))
+        nnz = sum(bnnz[(8 + j) % nb] for j in range(n_steps))
+        lay = ds.layout()
+        bi = ds.batch_info(0)
+        touched = [ds.batch_info(b)["n_columns"] for b in range(nb)]
+        res = dict(name=name, value=nnz / dt, step_ms=dt / n_steps * 1e3, steps=n_steps, batches=nb, prof=prof, lay=lay, bi=bi,
+                   mse=st.sse / max(st.rows, 1), nonfinite=st.nonfinite, touched_rows_per_batch=float(np.mean(touched)))
+        ds.unpersist()
+        fm.close(discard=True)
+        return res
+
+    t0 = time.time()
+    col_rel = FeatureOrder.fit(col_hashed, n1).relabel(col_hashed)      # a pure renaming (sparkfm_amd.FeatureOrder), outside any timed region
+    t_rel = time.time() - t0
+    r = run(col_rel, steps, "relabelled")
+    lay, bi, prof = r["lay"], r["bi"], r["prof"]
+    share = lay["nnz_sparse"] / max(nnz_total, 1)            # what stayed in the sparse streams (forward)
+    share_b = lay["nnz_sparse_backward"] / max(nnz_total, 1)   # ... in the transposes (backward)
     req = requested_bytes(64, bi["rows"], bi["nnz"], int(bi["nnz"] * share), bi["n_columns"], bool(lay["hot_ids"]),
                           bi["n_columns"], False, n1, False, int(bi["nnz"] * share_b), lay["hot_pages"])
     pmc = committed_pmc("C5hbm", k, batch_rows)
+    live = None
+    if with_pmc:
+        # counters of THIS workload shape, measured now (8 distinct batches are enough to defeat the Infinity Cache; the
+        # 24-batch run above is the timed one)
+        live = live_pmc([os.path.join(ROOT, "tools", "pmc_leg.py"), "c5hbm", "--rows", "2000000", "--batch-rows", str(batch_rows)])
+        for kn, e in (live or {}).items():
+            pmc.setdefault(kn, {}).update(e, traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py invocation "
+                                                            "(tools/pmc_leg.py c5hbm, 8 distinct batches)")
     kern = kernel_table(prof, k, 64, req, pmc, {"forward": n1 * 64 * 4, "backward": bi["rows"] * 64 * 4})
     step_req = sum(e.get("requested_bytes_per_launch", 0) for e in kern.values())
-    step_ms = dt / steps * 1e3
+    step_ms = r["step_ms"]
     fabric = pmc.get("step", {}).get("traffic_bytes")
-    out = {"workload": "C5 width on one GPU: %d Criteo-shaped rows x 2^25 hashed slots (relabelled by frequency at load), k=64 "
-                       "(V = %.1f GB), batch %d rows, eta 0.02, regw = regv = 1e-4 (lazy rows-only update)" % (rows, n1 * k * 4 / 1e9, batch_rows),
-           "value": value, "unit": "nnz/s", "ms_per_step": step_ms, "steps": steps,
+    out = {"workload": "C5 width on one GPU: %d Criteo-shaped rows x 2^25 hashed slots (relabelled by frequency at load), k=64 (V = %.1f GB), "
+                       "%d DISTINCT batches of %d rows (%.2f M parameter rows touched per batch), eta 0.02, regw = regv = 1e-4 (lazy rows-only update)" %
+                       (rows, n1 * k * 4 / 1e9, r["batches"], batch_rows, r["touched_rows_per_batch"] / 1e6),
+           "value": r["value"], "unit": "nnz/s", "ms_per_step": step_ms, "steps": r["steps"], "distinct_batches": r["batches"],
+           "touched_V_bytes_per_batch": r["touched_rows_per_batch"] * 64 * 4,
            "hot_block_features": len(lay["hot_ids"]), "hot_block_features_gradient_side": len(lay["hot_ids_all"]),
            "share_of_nonzeros_in_sparse_streams": share, "share_of_nonzeros_in_transposes": share_b,
-           "alg_bytes_per_nnz": ab["step"], "alg_GBps": value * ab["step"] / 1e9,
+           "alg_bytes_per_nnz": ab["step"], "alg_GBps": r["value"] * ab["step"] / 1e9,
            "requested_bytes_per_step": step_req, "requested_GBps": step_req / (step_ms * 1e-3) / 1e9,
-           "fabric_traffic_bytes_per_step_from_committed_profile": fabric,
+           "fabric_traffic_bytes_per_step": fabric,
+           "fabric_traffic_source": ("live rocprofv3 --pmc passes of this run" if live else "profiles/pmc_traffic.json (committed passes)") if fabric else None,
            "fabric_GBps": fabric / (step_ms * 1e-3) / 1e9 if fabric else None,
            "frac_of_8TBps": fabric / (step_ms * 1e-3) / HBM_PEAK if fabric else None,
            "note": "three byte counts, never to be mixed: ALGORITHMIC (8k+16 B for every stored nonzero: the 13 numeric fields and the "
                    "small vocabularies sit in the dense hot block, popular slots hit the caches, so this exceeds what HBM moves), REQUESTED "
                    "(our own count of the kernels' loads and stores, whatever level serves them) and FABRIC (rocprofv3 FETCH_SIZE x2 + "
-                   "WRITE_SIZE of the committed passes over this very workload, profiles/pmc_traffic.json: Infinity-Cache hits included, "
-                   "so an upper bound on HBM bytes).  frac_of_8TBps = fabric bytes / this run's step time / 8 TB/s.",
-           "kernels": kern, "last_batch_mse": st.sse / max(st.rows, 1), "nonfinite": st.nonfinite}
-    ds.unpersist()
-    fm.close(discard=True)
+                   "WRITE_SIZE: requests that left the L2s; Infinity-Cache hits are still included, no DRAM-side counter separates them on "
+                   "this part — profiles/README.md — so an upper bound on HBM bytes).  frac_of_8TBps = fabric bytes / this run's step time / 8 TB/s.",
+           "kernels": kern, "last_batch_mse": r["mse"], "nonfinite": r["nonfinite"],
+           "setup_s": {"generate": t_gen, "relabel": t_rel}}
+    del col_rel
+    if hashed_too:
+        h = run(col_hashed, max(steps // 2, 8), "hashed")
+        pd = h["prof"].as_dict()
+        out["ids_as_hashed"] = {"value": h["value"], "unit": "nnz/s", "ms_per_step": h["step_ms"], "steps": h["steps"],
+                                "kernel_ms": {n: p["ms"] / p["launches"] for n, p in pd.items() if p["launches"]},
+                                "last_batch_mse": h["mse"], "nonfinite": h["nonfinite"],
+                                "note": "the same rows with the slots numbered as the hash left them (no frequency relabelling at load)"}
     return out
 
 
@@ -374,6 +508,9 @@ def main():
     ap.add_argument("--eta", type=float, default=0.02)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the sustained / HBM-resident / ALS legs")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not run the rocprofv3 --pmc child passes that measure the kernels' fabric-side traffic in this run "
+                         "(roofline.traffic then comes from the committed profile, profiles/pmc_traffic.json)")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"],
                     help="rccl: the library's own communicator (fmhip_dp_step); torch: torch.distributed all-reduce "
                          "orchestrated from Python (sparkfm_amd.distributed.DataParallelSGD)")
@@ -734,6 +871,14 @@ def main():
             kp *= 2
         packed = k < kp
         pmc = committed_pmc(config, k, batch_rows)
+        live = None
+        if world == 1 and not use_dp and not args.no_pmc and config in ("C2", "C3") and not args.tune and not args.hot_pages:
+            # the counters of THIS workload, measured now: rocprofv3 child processes over tools/pmc_leg.py (same config,
+            # rows and batch; the committed profile is the fallback when rocprofv3 is not available)
+            live = live_pmc([os.path.join(ROOT, "tools", "pmc_leg.py"), config.lower(), "--rows", str(rows), "--batch-rows", str(batch_rows)])
+            for kn, e in (live or {}).items():
+                pmc.setdefault(kn, {}).update(e, traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py invocation "
+                                                                "(tools/pmc_leg.py: the same workload)")
         bi = binfo[0]
         lay = ds.layout()
         hot = len(lay["hot_ids"]) > 0
@@ -748,7 +893,6 @@ def main():
         # the dominant kernel = the longest launch (not the largest sampled total: kinds are sampled in rotation)
         dom = max(("forward", "backward"), key=lambda n: kern.get(n, {}).get("avg_ms", 0.0))
         pd = prof.as_dict()
-        achieved = kern[dom]["alg_GBps"] if dom in kern else float("nan")
         value = total_nnz / elapsed
         step_ms = elapsed / args.steps * 1e3
         # fraction of the step's time that the kernels' own ceilings account for (<= 1 when no kernel beats its ceiling)
@@ -777,20 +921,7 @@ def main():
                                      if exchange == "rccl" and dp.cuts else
                                      ("inside the library, one %s per step" % ("reduce-scatter + all-gather" if dp.exchange == "sharded" else "all-reduce") if exchange == "rccl" else
                                       ("torch.distributed, orchestrated from Python" if exchange == "torch" else "none")))},
-            "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
-                         "traffic": kern.get(dom, {}).get("traffic_from_committed_profile"),
-                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this configuration; not measured in this run)",
-                         "alg_bytes_per_nnz": ab[dom], "nnz_per_launch": pd[dom]["nnz"] / max(pd[dom]["launches"], 1),
-                         "avg_launch_ms": kern[dom]["avg_ms"] if dom in kern else None,
-                         "note": "achieved = ALGORITHMIC bytes (SURVEY §8(d): 4k+4 B for EVERY stored nonzero of the batch) / launch time. "
-                                 "It is not an HBM rate and may pass the HBM peak: at this size V, P and the gradient live in L2 / Infinity "
-                                 "Cache, and the nonzeros of the dense hot block (config.dense_hot_block) cost one streamed value instead of a "
-                                 "gathered row.  The bytes the kernel really asks for and the ceiling that binds them: requested_GBps, ceiling, "
-                                 "frac_of_ceiling (<= 1)",
-                         "requested_GBps": kern.get(dom, {}).get("requested_GBps"),
-                         "ceiling": kern.get(dom, {}).get("ceiling"),
-                         "frac_of_ceiling": kern.get(dom, {}).get("frac_of_ceiling")},
+            "roofline": roofline_block(kern, dom, ab, pd, pmc, step_ms, live is not None),
             "step_roofline": {"alg_bytes_per_nnz": ab["step"], "alg_GBps": value / world * ab["step"] / 1e9,
                               "requested_bytes_per_step": sum(e.get("requested_bytes_per_launch", 0) for e in kern.values()),
                               "time_at_ceilings_ms": explained_ms, "frac": explained_ms / step_ms,
@@ -849,7 +980,7 @@ def main():
             del d
             extra = {}
             try:
-                extra["hbm_resident"] = hbm_resident_leg(local_rank)
+                extra["hbm_resident"] = hbm_resident_leg(local_rank, with_pmc=not args.no_pmc)
             except Exception as ex:   # noqa: BLE001
                 extra["hbm_resident"] = {"error": repr(ex)}
             try:

@@ -325,6 +325,18 @@ def test_bench_roofline_helpers():
     pmc = bench.committed_pmc("C5", 64, 250_000)
     assert {"k_forward", "k_backward", "step"} <= set(pmc) and 0 < pmc["k_forward"]["l2_hit"] < 1
     assert bench.alg_bytes(32) == {"forward": 140, "backward": 132, "step": 272}
+    # the roofline object: achieved = the counters' bytes per launch / the launch's duration, frac = that / 8 TB/s (<= 1 for
+    # any real kernel); the algorithmic figure rides beside it, flagged, and may pass 1
+    kern = {"backward": {"avg_ms": 0.160, "traffic_bytes": 1_020_000_000, "traffic_source": "x", "alg_GBps": 8200.0,
+                         "requested_GBps": 6400.0, "frac_of_ceiling": 0.58, "ceiling": {"GBps": 11100.0}}}
+    pd = {"backward": {"nnz": 10_000_000 * 12, "launches": 12}}
+    r = bench.roofline_block(kern, "backward", bench.alg_bytes(32), pd, {"step": {"traffic_bytes": 1_500_000_000}}, 0.29, True)
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["traffic"] == 1_020_000_000
+    assert r["achieved"] == pytest.approx(1.02e9 / 160e-6 / 1e9) and r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and r["frac"] < 1
+    assert r["algorithmic_frac"] == pytest.approx(8200.0 / 8000.0) and r["traffic_measured_in_this_run"] is True
+    assert r["step"]["frac"] == pytest.approx(1.5e9 / 0.29e-3 / 8e12) and r["nnz_per_launch"] == 10_000_000
+    r2 = bench.roofline_block({"backward": {"avg_ms": 0.2, "requested_bytes_per_launch": 8e8}}, "backward", bench.alg_bytes(32), pd, {}, 0.3, False)
+    assert r2["traffic"] == 8e8 and "requested" in r2["basis"] and r2["frac"] == pytest.approx(8e8 / 0.2e-3 / 8e12)
 
 
 # ---- the JVM side (jvm/HipSGD.scala + jvm/fmhip_jni.c): no JDK / scalac in this image, so the sources are checked

@@ -62,6 +62,7 @@ def main():
     write, _ = load_pmc(tag, "write", skip)
     l2, _ = load_pmc(tag, "l2", skip)
     sq, _ = load_pmc(tag, "sq", skip)
+    extra = {name: load_pmc(tag, name, skip)[0] for name in ("ta", "tcp", "ea", "ea2")}
     lines.append("")
     lines.append("# rocprofv3 --pmc, one pass per group (mean per dispatch after the first %d dispatches of each kernel)" % skip)
     entries = []
@@ -84,6 +85,15 @@ def main():
             parts.append("TCC_HIT=%.0f TCC_MISS=%.0f L2_hit=%.3f" % (hit, miss, h))
         if kn in sq:
             parts.append(" ".join("%s=%.3g" % (c, v) for c, v in sorted(sq[kn].items())))
+        for name in ("ta", "tcp", "ea", "ea2"):
+            if kn in extra[name]:
+                parts.append(" ".join("%s=%.4g" % (c, v) for c, v in sorted(extra[name][kn].items())))
+        ea = dict(extra["ea"].get(kn, {}), **extra["ea2"].get(kn, {}))
+        if "TCC_EA0_RDREQ_sum" in ea:
+            # the request-size breakdown behind FETCH_SIZE: 128-B requests (TCC_BUBBLE), 32-B ones, the rest 64 B
+            b128, b32, tot = ea.get("TCC_BUBBLE_sum", 0.0), ea.get("TCC_EA0_RDREQ_32B_sum", 0.0), ea["TCC_EA0_RDREQ_sum"]
+            parts.append("read requests: %.3g x128B %.3g x32B %.3g x64B = %.1f MB by request size; to DRAM (MC) %.3g of %.3g" %
+                         (b128, b32, tot - b128 - b32, (b128 * 128 + b32 * 32 + (tot - b128 - b32) * 64) / 1e6, ea.get("TCC_EA0_RDREQ_DRAM_sum", float("nan")), tot))
         lines.append("%-44s %s" % (full.get(kn, kn), " | ".join(parts)))
         if fr is not None and wr is not None:
             ent = {"config": config, "k": k, "batch_rows": batch_rows, "kernel": kn.replace("k_forward_wt", "k_forward").replace("k_backward_p", "k_backward").replace("k_apply_rows", "k_apply"),

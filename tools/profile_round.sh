@@ -8,7 +8,7 @@ tag=${1:-r02}; shift || true
 cd "$(dirname "$0")/.."
 root=$PWD
 export TMPDIR=/tmp
-BENCH="python3 $root/bench.py --no-cpu-baseline --no-extra --steps 12 --warmup 4 $*"
+BENCH="python3 $root/bench.py --no-cpu-baseline --no-extra --no-pmc --steps 12 --warmup 4 $*"
 run() { # name, rocprof args...
   local name=$1; shift
   (cd /tmp && rocprofv3 "$@" -d $root/gpurun_out/${tag}_$name -o $name --output-format csv -- $BENCH > $root/gpurun_out/${tag}_$name.log 2>&1) || { echo "$name failed"; tail -5 $root/gpurun_out/${tag}_$name.log; return 1; }
@@ -20,13 +20,21 @@ if [ -z "$ONLY_C5" ]; then
   run write --pmc WRITE_SIZE
   run l2 --pmc TCC_HIT_sum TCC_MISS_sum
   run sq --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
+  # the texture path (the "line-request bound" claim) and the raw memory-side request counters behind FETCH_SIZE
+  run ta --pmc TA_TA_BUSY_sum TA_BUFFER_WAVEFRONTS_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE || true
+  run tcp --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum || true
+  run ea --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum TCC_EA0_RDREQ_DRAM_sum || true
+  run ea2 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_DRAM_sum TCC_REQ_sum || true
 fi
 # the HBM-resident leg (C5 width) on its own
 if [ -z "$SKIP_C5" ]; then
-  BENCH="python3 $root/tools/run_c5_shape.py 16"
+  BENCH="python3 $root/tools/run_c5_shape.py 24 ${C5_ROWS:-6000000}"
   tag=${tag}_c5
   run stats --kernel-trace --stats
   run fetch --pmc FETCH_SIZE
   run write --pmc WRITE_SIZE
   run l2 --pmc TCC_HIT_sum TCC_MISS_sum
+  run ta --pmc TA_TA_BUSY_sum TA_BUFFER_WAVEFRONTS_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE || true
+  run ea --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum TCC_EA0_RDREQ_DRAM_sum || true
+  run ea2 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_DRAM_sum TCC_REQ_sum || true
 fi

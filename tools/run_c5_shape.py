@@ -2,7 +2,7 @@
 """The HBM-resident leg of bench.py on its own (so that rocprofv3 can wrap exactly this workload):
 C5's width — 2^25 hashed slots, k=64, V = 8.6 GB — on one GPU, Criteo-shaped rows, weight decay on.
 
-    python3 tools/run_c5_shape.py [steps] [rows]
+    python3 tools/run_c5_shape.py [steps] [rows]        (never starts the rocprofv3 child passes itself: it is what they wrap)
 """
 import json
 import os
@@ -13,5 +13,5 @@ import bench  # noqa: E402
 
 if __name__ == "__main__":
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-    rows = int(sys.argv[2]) if len(sys.argv) > 2 else 500_000
-    print(json.dumps(bench.hbm_resident_leg(0, steps=steps, rows=rows)))
+    rows = int(sys.argv[2]) if len(sys.argv) > 2 else 6_000_000
+    print(json.dumps(bench.hbm_resident_leg(0, steps=steps, rows=rows, hashed_too='--hashed-too' in sys.argv, with_pmc=False)))
