@@ -123,8 +123,10 @@ int fmhip_device_count(int *count);
  *          fixup launch — the rows the fixups assemble update themselves from registers, every other row is
  *          updated by extra workgroups beside them (bandwidth-bound work next to latency-bound work) — instead
  *          of as a launch of its own.  Bit-identical; 0 = separate update launch.
- *   key 12 pages of the dense hot block (1..4, default 4): 1 = the two-sided page only (round-1 layout); more = the next
- *          most frequent features that pass the density test are dense on the gradient side (fmhip_dataset_hot_pages)
+ *   key 12 pages of the dense hot block (1..8, default 8): 1 = the two-sided page only (round-1 layout); more = the next
+ *          most frequent features that pass the density test (present in >= 2.5 % of the rows) are dense on the gradient
+ *          side (fmhip_dataset_hot_pages).  Models of up to 32 (padded) factors form all 8 pages in one pass over P, wider
+ *          ones 4 pages per pass
  * Keys 3, 5 and 12 are only the DEFAULTS of fmhip_dataset_create (read at the time of the call; they decide the
  * layout of the dataset being built and nothing else) — fmhip_dataset_create_opts states them per dataset;
  * every other key is read by the next launch. */
@@ -166,7 +168,7 @@ int fmhip_dataset_create_f32(int device, int64_t n_rows, const int64_t *row_ptr,
 typedef struct fmhip_dataset_opts {
     int32_t struct_size;
     int32_t hot_block;       /* dense hot block: -1 = library default (fmhip_tune keys 5, 12), 0 = off, n >= 1 = on with up
-                              * to n pages of 16 features (1 = the two-sided page only, 2..4 = gradient-side pages too) */
+                              * to n pages of 16 features (1 = the two-sided page only, 2..8 = gradient-side pages too) */
     int64_t batch_rows;      /* <= 0: one batch */
     int64_t row_block_rows;  /* rows per row block of the transposes: -1 = library default (key 3), 0 = none */
 } fmhip_dataset_opts;
@@ -389,7 +391,7 @@ int fmhip_dataset_layout(fmhip_dataset_t d, int32_t *n_hot, int32_t *hot_ids, in
  * entries stay in the rows the forward walks and leave the transposes the backward walks.  n_pages; n_ids and ids
  * (room for 16 * FMHIP_HOT_PAGES, nullable): the features of ALL pages; nnz_sparse_backward: the stored nonzeros left
  * in the transposes. */
-#define FMHIP_HOT_PAGES 4
+#define FMHIP_HOT_PAGES 8
 int fmhip_dataset_hot_pages(fmhip_dataset_t d, int32_t *n_pages, int32_t *n_ids, int32_t *ids, int64_t *nnz_sparse_backward);
 int fmhip_profile_begin(fmhip_model_t m);                  /* start recording HIP events around every kernel */
 /* same, but each SGD step times only ONE kernel kind, rotating forward -> backward -> fixup ->

@@ -159,7 +159,7 @@ __device__ __forceinline__ void hot_backward_body(const HotArgs &a, int bx, int 
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[p][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        constexpr int U = NJ <= 4 ? 4 : 2;                     // 4-row steps whose loads are in flight together
+        constexpr int U = (NJ <= 4 && PG <= 4) ? 4 : 2;        // 4-row steps whose loads are in flight together (registers: U x (PG + NJ))
         for (int r0 = r_beg; r0 < r_end; r0 += 4 * U) {
             float x[U][PG], e[U], b[U][NJ];
 #pragma unroll

@@ -20,9 +20,10 @@ constexpr int kHotT = 16;           // slots of one page of the dense hot block 
 // GRADIENT side only: their entries stay in the CSR stream the forward walks (a longer dense prologue costs the forward
 // its occupancy — profiles/r02_experiments.md §18) but leave the CSC stream, where every entry costs the backward a P-row
 // gather; the MFMA block product below forms their gradient rows in the same pass over P as page 0's.
-constexpr int kHotPages = 4;
-// pages the gradient-side block product carries through one pass over P (its accumulators: pages x Kp/16 x 4 VGPRs)
-constexpr int hot_pages_max(int Kp) { return Kp <= 64 ? kHotPages : 1; }
+constexpr int kHotPages = 8;
+// pages the gradient-side block product carries through ONE pass over P (its accumulators: pages x Kp/16 x 4 VGPRs: 64 at
+// 8 pages x Kp = 32 and at 4 pages x Kp = 64); a dataset with more pages than that takes several passes
+constexpr int hot_pages_max(int Kp) { return Kp <= 32 ? 8 : (Kp <= 64 ? 4 : 1); }
 extern int g_tune[kTuneCount];
 
 // padded factor count: 4 * LPN * J with LPN = lanes per row-slot (<= 16), J float4 per lane

@@ -28,7 +28,8 @@ using namespace fmhip;
 #define FMHIP_FIN_BLOCKS 2048     // cap on the merged finish's update workgroups (beside ~2k fixup workgroups at C3)
 #endif
 
-static_assert(FMHIP_HOT_PAGES == kHotPages && kHotPages * kHotT <= 64, "header and kernels disagree on the hot pages (64-bit slot masks)");
+static_assert(FMHIP_HOT_PAGES == kHotPages && kHotPages * kHotT <= 128, "header and kernels disagree on the hot pages (128-bit slot masks)");
+typedef unsigned __int128 slotmask_t;      // one bit per slot of the dense hot block
 static_assert(FMHIP_RANGE_LEN == kRangeLen, "header and kernels disagree on the CSC range length");
 
 namespace fmhip {
@@ -255,7 +256,7 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     std::vector<int64_t> sp_ptr;
     std::unique_ptr<int32_t[]> sp_col_buf;
     std::unique_ptr<float[]> sp_val_buf, xhot_buf;
-    std::vector<uint64_t> hot_masks;
+    std::vector<slotmask_t> hot_masks;
     std::vector<int64_t> bwd_out;          // per batch: entries of the gradient-side pages (in the CSR, not in the CSC)
     std::vector<uint32_t> drop_bits;       // bitmap over feature ids: the gradient-side pages' features
     bool split = false;
@@ -286,10 +287,11 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
         }
         // candidates in descending order of frequency (ties: ascending id).  Page 0 is dense for the forward too, where a
         // slot costs every row a multiply-add chain: it takes features present in >= 10 % of the rows.  A gradient-side slot
-        // costs a row 4 streamed bytes and saves a P-row gather per entry: those pages take features down to 5 %.
+        // costs a row 4 streamed bytes and saves, per entry, an 8-byte stream read, a P-row gather and an e gather (~2 line
+        // requests of the texture path, which is what bounds the column walk): those pages take features down to 2.5 %.
         std::vector<int32_t> cand;
         for (int32_t f = 0; f <= dim; ++f)
-            if ((int64_t)cnt[(size_t)f] * 20 >= sampled_rows) cand.push_back(f);
+            if ((int64_t)cnt[(size_t)f] * 40 >= sampled_rows) cand.push_back(f);
         std::sort(cand.begin(), cand.end(), [&](int32_t x, int32_t y) { return cnt[(size_t)x] != cnt[(size_t)y] ? cnt[(size_t)x] > cnt[(size_t)y] : x < y; });
         const size_t max_rest = (size_t)kHotT * (size_t)((want_rb > 0 ? 1 : max_hot_pages) - 1);
         std::vector<int8_t> slot((size_t)dim + 1, -1);
@@ -305,25 +307,25 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
             used = p0 < 2 ? 0 : p0 + std::min(cand.size() - p0, max_rest);
             if (!used) break;
             for (size_t j = 0; j < used; ++j) slot[(size_t)cand[j]] = slot_of(j);
-            std::vector<uint64_t> badv((size_t)T, 0u);
+            std::vector<slotmask_t> badv((size_t)T, 0u);
             parallel_chunks(n_rows, T, [&](int t, int64_t lo, int64_t hi) {
-                uint64_t bad = 0;
+                slotmask_t bad = 0;
                 for (int64_t r = lo; r < hi; ++r) {
-                    uint64_t seen = 0;
+                    slotmask_t seen = 0;
                     int64_t keep = 0;
                     for (int64_t p = row_ptr[r]; p < row_ptr[r + 1]; ++p) {
                         const int8_t h = slot[(size_t)col[p]];
                         if (h < 0 || h >= kHotT) ++keep;
                         if (h < 0) continue;
-                        if ((seen >> h & 1u) || (float)val[p] == 0.f) bad |= (uint64_t)1 << h;
-                        seen |= (uint64_t)1 << h;
+                        if ((seen >> h & 1u) || (float)val[p] == 0.f) bad |= (slotmask_t)1 << h;
+                        seen |= (slotmask_t)1 << h;
                     }
                     sp_ptr[(size_t)r + 1] = keep;
                 }
                 badv[(size_t)t] = bad;
             });
-            uint64_t bad = 0;
-            for (uint64_t x : badv) bad |= x;
+            slotmask_t bad = 0;
+            for (slotmask_t x : badv) bad |= x;
             if (!bad) break;
             std::vector<int32_t> ok;
             for (size_t j = 0; j < cand.size(); ++j) {
@@ -363,11 +365,11 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
             xhot_buf.reset(new float[page_floats * (size_t)pages]);
             int32_t *sp_col = sp_col_buf.get();
             float *sp_val = sp_val_buf.get(), *xhot = xhot_buf.get();
-            std::vector<std::vector<uint64_t>> tmask((size_t)T, std::vector<uint64_t>((size_t)nb, 0u));
+            std::vector<std::vector<slotmask_t>> tmask((size_t)T, std::vector<slotmask_t>((size_t)nb, 0u));
             std::vector<std::vector<int64_t>> tout((size_t)T, std::vector<int64_t>((size_t)nb, 0));
             parallel_chunks(n_rows, T, [&](int t, int64_t lo, int64_t hi) {
                 for (int64_t r = lo; r < hi; ++r) {
-                    uint64_t seen = 0;
+                    slotmask_t seen = 0;
                     int64_t o = sp_ptr[(size_t)r], outb = 0;
                     for (int pg = 0; pg < pages; ++pg) {
                         float *xr = xhot + (size_t)pg * page_floats + (size_t)r * kHotT;
@@ -376,7 +378,7 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
                     for (int64_t p = row_ptr[r]; p < row_ptr[r + 1]; ++p) {
                         const int8_t h = slot[(size_t)col[p]];
                         if (h >= 0) {
-                            seen |= (uint64_t)1 << h;
+                            seen |= (slotmask_t)1 << h;
                             xhot[(size_t)(h / kHotT) * page_floats + (size_t)r * kHotT + (h % kHotT)] = (float)val[p];
                         }
                         if (h < 0 || h >= kHotT) {
@@ -1448,7 +1450,7 @@ int fmhip_dataset_batch_info(fmhip_dataset_t d, int64_t batch, int64_t *row0, in
     if (row0) *row0 = bm.row0;
     if (rows) *rows = bm.rows;
     if (nnz) *nnz = bm.nnz_total;
-    if (n_columns) *n_columns = bm.n_feats + __builtin_popcountll(bm.hot_mask);
+    if (n_columns) *n_columns = bm.n_feats + __builtin_popcountll((uint64_t)bm.hot_mask) + __builtin_popcountll((uint64_t)(bm.hot_mask >> 64));
     return FMHIP_OK;
 }
 

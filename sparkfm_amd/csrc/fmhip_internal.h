@@ -74,7 +74,7 @@ struct BatchMeta {
     int64_t mp_off = 0;     // offset into mp_feat; mp_ptr offset is mp_off + batch index
     int32_t n_pieces = 0;   // piece rows those features need
     int64_t nnz_total = 0;  // stored nonzeros of the batch incl. those held in the dense hot block
-    uint64_t hot_mask = 0;  // hot slots (all pages) with at least one nonzero in this batch
+    unsigned __int128 hot_mask = 0;  // hot slots (all pages: up to 128) with at least one nonzero in this batch
     int64_t own_off = -1;   // offset (in words) of the batch's bitmap of fixup-owned features, -1 = none
 };
 

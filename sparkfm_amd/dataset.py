@@ -163,7 +163,7 @@ class DataSet(Features):
         """How the library laid the rows out: ids held in the dense hot block, nonzeros left in the sparse streams."""
         n, ids, sp = C.c_int32(), np.full(16, -1, np.int32), C.c_int64()
         _ffi.check(_ffi.load().fmhip_dataset_layout(self.handle, C.byref(n), _ffi.ptr(ids), C.byref(sp)))
-        pages, n_all, all_ids, spb = C.c_int32(), C.c_int32(), np.full(64, -1, np.int32), C.c_int64()
+        pages, n_all, all_ids, spb = C.c_int32(), C.c_int32(), np.full(128, -1, np.int32), C.c_int64()
         _ffi.check(_ffi.load().fmhip_dataset_hot_pages(self.handle, C.byref(pages), C.byref(n_all), _ffi.ptr(all_ids), C.byref(spb)))
         # hot_ids: the two-sided page; hot_ids_all: with the gradient-side pages; nnz_sparse(_backward): entries left in the
         # rows the forward walks / in the transposes the backward walks

@@ -82,7 +82,7 @@ int main(void) {
     CHECK(fmhip_comm_create_external(NULL, 0, 1, NULL, NULL, NULL) == FMHIP_ERR_INVALID);
     CHECK(fmhip_dp_exchange(NULL, FMHIP_EXCHANGE_TOUCHED) == FMHIP_ERR_INVALID);
     CHECK(fmhip_dataset_hot_pages(NULL, NULL, NULL, NULL, NULL) == FMHIP_ERR_INVALID);
-    CHECK(FMHIP_HOT_PAGES * 16 <= 64 && FMHIP_COLL_ALLGATHER_I32 == 3);
+    CHECK(FMHIP_HOT_PAGES * 16 <= 128 && FMHIP_COLL_ALLGATHER_I32 == 3 && FMHIP_COLL_ALLGATHER_F32 == 5 && FMHIP_EXCHANGE_SHARDED == 2);
     printf("c_abi_smoke ok (fmhip %d)\n", fmhip_version());
     return 0;
 }

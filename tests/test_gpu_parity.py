@@ -232,14 +232,15 @@ def hot_problem(seed, n_rows, n1, k, n_hot, dup_feature=None, zero_feature=None,
                                                       (16, 5, None, None, 3), (64, 9, 2, None, 3), (100, 16, None, 3, 3),
                                                       (8, 12, 0, 1, 3), (32, 48, None, None, 3), (32, 41, 20, 30, 2),
                                                       (64, 45, 3, None, 3), (16, 35, None, 1, 3), (100, 40, 25, None, 3), (32, 70, 50, None, 4),
-                                                      (64, 64, None, None, 4)])
+                                                      (64, 64, None, None, 4), (32, 100, None, None, 8), (64, 128, 5, None, 8),
+                                                      (32, 90, 60, 70, 6)])
 @pytest.mark.parametrize("flat", [0, 1])
 def test_dense_hot_block(fmhip, request, k, n_hot, dup, zero, pages, flat):
     """fmhip_tune(5, 1): the most frequent features (>= 10 % of the rows, none that occurs twice in a row or with a stored
-    zero) are held in dense [rows][16] pages: the 16 most frequent leave the sparse streams on both sides, up to 48 more
-    (fmhip_tune key 12 = pages) leave the transposes only and get their gradient rows from the same MFMA block product.
-    Forward, gradient, transposes, epochs and the feature-chunked backward must not notice.  k = 100 (Kp = 128) takes the
-    pages one pass over P each.  flat=1: the same on the flat-address kernels (fmhip_tune key 8)."""
+    zero) are held in dense [rows][16] pages: the 16 most frequent leave the sparse streams on both sides, up to 112 more
+    (fmhip_tune key 12 = pages, at most 8) leave the transposes only and get their gradient rows from the same MFMA block
+    product.  Forward, gradient, transposes, epochs and the feature-chunked backward must not notice.  k <= 32 forms all 8
+    pages in one pass over P, k = 64 four pages per pass (so 8 pages take two), k = 100 (Kp = 128) one pass per page.  flat=1: the same on the flat-address kernels (fmhip_tune key 8)."""
     from sparkfm_amd import _ffi
     L = _ffi.load()
     L.fmhip_tune(8, flat)
@@ -253,7 +254,7 @@ def test_dense_hot_block(fmhip, request, k, n_hot, dup, zero, pages, flat):
         ds, fm = make(fmhip, a, batch_rows=br)
     finally:
         L.fmhip_tune(5, 1)
-        L.fmhip_tune(12, 4)
+        L.fmhip_tune(12, 8)
     lay = ds.layout()
     refused = {int(hot_ids[i]) for i in (dup, zero) if i is not None}
     dense = set(lay["hot_ids_all"])
