@@ -160,6 +160,41 @@ def als_c1(device):
             "cpu_oracle_s_per_epoch": cpu_s, "nnz": nnz}
 
 
+def als_long(device, shapes=((100_000, 1_000, 10), (1_000_000, 1_000, 10), (1_000_000, 100, 10)), k=8):
+    """ALS.learn (S/fm/lib/ALS.scala:15-75) where its columns are long — the regime a GPU can win: datasets beyond the LDS
+    sweep (more than 10,000 rows), uniform ids, columns of 10^3 (one-workgroup runs), 10^4 and 10^5 entries (the chip-wide
+    two-launch step of als_kernels.hip).  One epoch on the GPU (fp64, fmhip_als_epoch) beside the CPU oracle's (one core:
+    the sweep is a sequential recurrence), and the largest parameter difference between the two."""
+    import oracle
+    from sparkfm_amd import DataSet, FMModel, HipALS, synth
+    out = []
+    for n_rows, n_feat, nnz_r in shapes:
+        d = synth.make_zipf(synth.BASE_SEED + 77, n_rows, n_feat, nnz_r, nnz_r, zipf_s=0.0)
+        ds = DataSet.from_arrays(d, name="als", device=device).cache()
+        fm = FMModel(ds.dimension, k, seed=1, device=device)
+        w0, w, v = fm.w0, fm.w.copy(), fm.v.copy()
+        als = HipALS.run()
+        als.learn(fm, ds)                                   # warm-up (allocations); also the epoch that is compared
+        _ = fm.w0
+        g = (fm.w0, fm.w.copy(), fm.v.copy())
+        t = time.perf_counter()
+        als.learn(fm, ds)
+        _ = fm.w0                                           # pulls the fp64 result: includes the sync
+        gpu_s = time.perf_counter() - t
+        val, y = d["val"].astype(np.float64), d["y"].astype(np.float64)
+        t = time.perf_counter()
+        o = oracle.als_epoch(w0, w, v, 0.0, 0.0, 10.0, d["row_ptr"], d["col"], val, y)
+        cpu_s = time.perf_counter() - t
+        err = max(abs(g[0] - o[0]), float(np.abs(g[1] - o[1]).max()), float(np.abs(g[2] - o[2]).max()))
+        nnz = int(d["row_ptr"][-1])
+        out.append({"rows": n_rows, "features": n_feat, "k": k, "nnz": nnz, "column_entries": nnz // n_feat,
+                    "gpu_s_per_epoch": gpu_s, "cpu_oracle_s_per_epoch": cpu_s, "cpu_over_gpu": cpu_s / gpu_s,
+                    "max_abs_parameter_difference_after_one_epoch": err})
+        ds.unpersist()
+        fm.close()
+    return out
+
+
 def committed_pmc(config, k, batch_rows):
     """Counter-derived figures of the committed rocprofv3 --pmc passes for this configuration
     (profiles/pmc_traffic.json): {kernel: {traffic_bytes, l2_hit}}; empty when no pass exists."""
@@ -988,6 +1023,10 @@ def main():
             except Exception as ex:   # noqa: BLE001
                 extra["c4_one_gpu"] = {"error": repr(ex)}
             extra["als_c1"] = als_c1(local_rank)
+            try:
+                extra["als_long_columns"] = als_long(local_rank)
+            except Exception as ex:   # noqa: BLE001
+                extra["als_long_columns"] = {"error": repr(ex)}
             out["extra"] = extra
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dp:

@@ -28,11 +28,17 @@ struct AlsArgs {
     // fp64 parameters, reference layout v[f + i*k]
     double *w0, *w, *v;
     double reg0, regw, regv;
-    // workspace: e[n_rows]; q[n_rows * k] (the LDS sweep takes every factor's q from an up-front pass; the
-    // fallback sweep uses the first n_rows)
-    double *e, *q;
+    // workspace: e[n_rows]; q[n_rows * k] (every factor's q comes from an up-front pass over the feature-sorted rows);
+    // part[2 * kAlsMaxParts + 2]: per-workgroup partial sums of a long column's chip-wide step
+    double *e, *q, *part;
 };
 
-hipError_t launch_als_epoch(const AlsArgs &a, hipStream_t s);
+constexpr int kAlsMaxParts = 512;       // workgroups of a chip-wide column step
+// Columns of at least this many entries take the chip-wide two-launch step, shorter ones the one-workgroup walk
+// (FMHIP_ALS_LONG in the environment overrides it: a test / measurement knob)
+constexpr int kAlsLongColumn = 8192;
+
+// h_cfeat / h_cptr: HOST copies of cfeat / cptr (the sweep's launch plan follows the column lengths)
+hipError_t launch_als_epoch(const AlsArgs &a, const int32_t *h_cfeat, const int32_t *h_cptr, hipStream_t s);
 
 }  // namespace fmhip

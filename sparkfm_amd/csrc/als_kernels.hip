@@ -6,14 +6,23 @@
 // workgroup; the parallelism is inside a column (its entries are spread over the 1024 threads,
 // sums are tree-reduced in a fixed order).  All arithmetic is fp64 without fma contraction — the
 // reference runs on the JVM, which never fuses — so an epoch tracks the fp64 oracle to ~1e-13.
-// Two sweeps:
+// Three shapes of the sweep:
 //  * k_als_sweep_lds — residuals e and the factor's q live in LDS (n_rows * 16 B <= 160,000 B: BASELINE config 1's
 //    10,000 rows fill it exactly); ONE wave walks the columns (a column of ~100 entries is two wave-iterations: no
 //    workgroup barrier per feature, wave sums by DPP row reductions), the next column's entries are prefetched
-//    while the current one is reduced; the other waves compute q per factor from the feature-sorted rows.
-//  * k_als_sweep — the general fallback: e, q in global memory, columns spread over the whole workgroup,
-//    ~3 barriers per (feature, factor).
+//    while the current one is reduced.
+//  Larger datasets keep e and q in global memory and follow a launch plan made from the column lengths:
+//  * k_als_cols_wg — a RUN of consecutive short columns by one workgroup (~3 barriers per column);
+//  * k_als_col_sums + k_als_col_update — ONE long column (>= kAlsLongColumn entries) on the whole chip: every
+//    workgroup sums its slice (sum h^2, sum e*h), the second launch adds the partials in a fixed tree (every workgroup
+//    the same bits), forms theta* and updates its slice of e and q.  The dependency between consecutive columns is the
+//    launch boundary — no device-side grid barrier to get wrong.  A column of 10^5 entries costs a CPU core ~0.2 ms per
+//    step and this path two launches.
+// Every factor's q comes from one up-front pass over the feature-sorted rows (k_als_q_all), the per-row order of the
+// reference's transposed pass.
 #include "als_kernels.h"
+
+#include <cstdlib>
 
 namespace fmhip {
 namespace {
@@ -75,91 +84,126 @@ __device__ __forceinline__ void block_sum2(double &x, double &y, double (*sh)[kA
     y = ty;
 }
 
-// One ALS.learn pass after the residuals: w0 (:19-28), the linear weights (:36-43), then for every
-// factor the q term (:50,146-150) and the factor sweep (:52-68).
-template <int kAlsBlock>   // threads of the single workgroup: 256 for short columns (cheaper barriers), 1024 for long ones
-__global__ __launch_bounds__(kAlsBlock) void k_als_sweep(AlsArgs a) {
+// drawGlobalBias :152-154 = computeTheta(w0, reg0, sum e, size), then e += w0* - w0 (:19-28) — once per epoch, one workgroup
+template <int kAlsBlock>
+__global__ __launch_bounds__(kAlsBlock) void k_als_w0(AlsArgs a) {
+#pragma clang fp contract(off)
+    __shared__ double sh[2][kAlsBlock / 64];
+    const int tid = threadIdx.x;
+    double se = 0.0, dummy = 0.0;
+    for (int64_t r = tid; r < a.n_rows; r += kAlsBlock) se += a.e[r];
+    block_sum2<kAlsBlock>(se, dummy, sh);
+    const double w0 = *a.w0;
+    const double w0n = compute_theta(w0, a.reg0, se, (double)a.n_rows);
+    if (is_updatable(w0n, w0)) {
+        const double d = w0n - w0;
+        for (int64_t r = tid; r < a.n_rows; r += kAlsBlock) a.e[r] = a.e[r] + d;
+    }
+    __syncthreads();
+    if (tid == 0) *a.w0 = w0n;
+}
+
+// The closed-form steps of the consecutive columns [s_lo, s_hi) by ONE workgroup, in order (S/fm/lib/ALS.scala:36-43
+// linear weights, :52-68 factor f): the run of SHORT columns between two long ones.  e and q in global memory.
+template <int kAlsBlock, bool FACTOR>   // threads: 256 for short columns (cheaper barriers), 1024 for longer ones
+__global__ __launch_bounds__(kAlsBlock) void k_als_cols_wg(AlsArgs a, double *q, int s_lo, int s_hi, int f) {
 #pragma clang fp contract(off)
     __shared__ double sh[2][kAlsBlock / 64];
     const int tid = threadIdx.x;
     const int k = a.k;
-    // ---- global bias: drawGlobalBias :152-154 = computeTheta(w0, reg0, sum e, size)
-    {
-        double se = 0.0, dummy = 0.0;
-        for (int64_t r = tid; r < a.n_rows; r += kAlsBlock) se += a.e[r];
-        block_sum2<kAlsBlock>(se, dummy, sh);
-        const double w0 = *a.w0;
-        const double w0n = compute_theta(w0, a.reg0, se, (double)a.n_rows);
-        if (is_updatable(w0n, w0)) {
-            const double d = w0n - w0;
-            for (int64_t r = tid; r < a.n_rows; r += kAlsBlock) a.e[r] = a.e[r] + d;
-        }
-        __syncthreads();
-        if (tid == 0) *a.w0 = w0n;
-        __syncthreads();
-    }
-    // ---- linear weights: `0 until num_attribute` (quirk Q1: slot n is never trained)
-    for (int s = 0; s < a.n_cols; ++s) {
+    const double reg = FACTOR ? a.regv : a.regw;
+    for (int s = s_lo; s < s_hi; ++s) {
         const int64_t i = a.cfeat[s];
-        if (i >= a.num_attribute) continue;
+        if (i >= a.num_attribute) continue;                       // `0 until num_attribute` (quirk Q1: slot n is never trained)
         const int c0 = a.cptr[s], c1 = a.cptr[s + 1];
+        double *par = FACTOR ? a.v + f + i * k : a.w + i;
+        const double th = *par;
         double shs = 0.0, seh = 0.0;
         for (int p = c0 + tid; p < c1; p += kAlsBlock) {
+            const uint32_t r = a.crow[p] & 0x7fffffffu;
             const double x = a.cval[p];
-            shs += x * x;
-            seh += a.e[a.crow[p] & 0x7fffffffu] * x;
+            const double h = FACTOR ? x * q[r] - x * x * th : x;      // :56-58 / :40
+            shs += h * h;
+            seh += a.e[r] * h;
         }
         block_sum2<kAlsBlock>(shs, seh, sh);
-        const double th = a.w[i];
-        const double thn = compute_theta(th, a.regw, seh, shs);
-        if (is_updatable(thn, th)) {
-            const double d = thn - th;
-            for (int p = c0 + tid; p < c1; p += kAlsBlock) a.e[a.crow[p] & 0x7fffffffu] += a.cval[p] * d;
+        const double tn = compute_theta(th, reg, seh, shs);
+        const double d = tn - th;
+        const bool upd = is_updatable(tn, th);
+        for (int p = c0 + tid; p < c1; p += kAlsBlock) {
+            const uint32_t r = a.crow[p] & 0x7fffffffu;
+            const double x = a.cval[p];
+            if (upd) {
+                const double h = FACTOR ? x * q[r] - x * x * th : x;
+                a.e[r] += h * d;                                  // updateError :194-198
+            }
+            if (FACTOR) q[r] += x * d;                            // :60-62
         }
         __syncthreads();
-        if (tid == 0) a.w[i] = thn;
+        if (tid == 0) *par = tn;                                  // :40 / :64
         __syncthreads();
     }
-    // ---- factors
-    for (int f = 0; f < k; ++f) {
-        for (int64_t r = tid; r < a.n_rows; r += kAlsBlock) a.q[r] = 0.0;
-        __syncthreads();
-        for (int s = 0; s < a.n_cols; ++s) {                    // precomputeTermQ: every slot, ascending feature id
-            const double vfi = a.v[f + (int64_t)a.cfeat[s] * k];
-            const int c0 = a.cptr[s], c1 = a.cptr[s + 1];
-            for (int p = c0 + tid; p < c1; p += kAlsBlock) a.q[a.crow[p] & 0x7fffffffu] += vfi * a.cval[p];
-            __syncthreads();
+}
+
+// ---- one LONG column on the whole chip: two launches -------------------------------------------------
+constexpr int kColBlock = 256;
+
+// launch 1: workgroup g sums its contiguous slice of the column -> part[2g], part[2g + 1]; part[2G] = theta
+template <bool FACTOR>
+__global__ __launch_bounds__(kColBlock) void k_als_col_sums(AlsArgs a, const double *q, int c0, int c1, int64_t i, int f) {
+#pragma clang fp contract(off)
+    __shared__ double sh[2][kColBlock / 64];
+    const int tid = threadIdx.x, G = (int)gridDim.x;
+    const int per = (c1 - c0 + G - 1) / G;
+    const int lo = c0 + (int)blockIdx.x * per, hi = lo + per < c1 ? lo + per : c1;
+    const double th = FACTOR ? a.v[f + i * a.k] : a.w[i];
+    double shs = 0.0, seh = 0.0;
+    for (int p = lo + tid; p < hi; p += kColBlock) {
+        const uint32_t r = a.crow[p] & 0x7fffffffu;
+        const double x = a.cval[p];
+        const double h = FACTOR ? x * q[r] - x * x * th : x;
+        shs += h * h;
+        seh += a.e[r] * h;
+    }
+    block_sum2<kColBlock>(shs, seh, sh);
+    if (tid == 0) {
+        a.part[2 * blockIdx.x] = shs;
+        a.part[2 * blockIdx.x + 1] = seh;
+        if (blockIdx.x == 0) a.part[2 * G] = th;      // the update launch must not read a parameter another workgroup is writing
+    }
+}
+
+// launch 2: every workgroup adds the G partials in the same fixed tree (the same bits everywhere), forms theta* and
+// updates its slice of e (and q); workgroup 0 stores the parameter
+template <bool FACTOR>
+__global__ __launch_bounds__(kColBlock) void k_als_col_update(AlsArgs a, double *q, int c0, int c1, int64_t i, int f) {
+#pragma clang fp contract(off)
+    __shared__ double sh[2][kColBlock / 64];
+    const int tid = threadIdx.x, G = (int)gridDim.x;
+    double shs = 0.0, seh = 0.0;
+    for (int g = tid; g < G; g += kColBlock) {       // G <= kAlsMaxParts = 2 * kColBlock: at most two terms per thread
+        shs += a.part[2 * g];
+        seh += a.part[2 * g + 1];
+    }
+    block_sum2<kColBlock>(shs, seh, sh);
+    const double th = a.part[2 * G];
+    const double tn = compute_theta(th, FACTOR ? a.regv : a.regw, seh, shs);
+    const double d = tn - th;
+    const bool upd = is_updatable(tn, th);
+    const int per = (c1 - c0 + G - 1) / G;
+    const int lo = c0 + (int)blockIdx.x * per, hi = lo + per < c1 ? lo + per : c1;
+    for (int p = lo + tid; p < hi; p += kColBlock) {
+        const uint32_t r = a.crow[p] & 0x7fffffffu;       // the rows of a column are distinct (als_dup is refused): no two writers
+        const double x = a.cval[p];
+        if (upd) {
+            const double h = FACTOR ? x * q[r] - x * x * th : x;
+            a.e[r] += h * d;
         }
-        for (int s = 0; s < a.n_cols; ++s) {
-            const int64_t i = a.cfeat[s];
-            if (i >= a.num_attribute) continue;
-            const int c0 = a.cptr[s], c1 = a.cptr[s + 1];
-            const double vfi = a.v[f + i * k];
-            double shs = 0.0, seh = 0.0;
-            for (int p = c0 + tid; p < c1; p += kAlsBlock) {
-                const uint32_t r = a.crow[p] & 0x7fffffffu;
-                const double x = a.cval[p];
-                const double h = x * a.q[r] - x * x * vfi;        // :56-58
-                shs += h * h;
-                seh += a.e[r] * h;
-            }
-            block_sum2<kAlsBlock>(shs, seh, sh);
-            const double vn = compute_theta(vfi, a.regv, seh, shs);
-            const double d = vn - vfi;
-            const bool upd = is_updatable(vn, vfi);
-            for (int p = c0 + tid; p < c1; p += kAlsBlock) {
-                const uint32_t r = a.crow[p] & 0x7fffffffu;
-                const double x = a.cval[p];
-                if (upd) {
-                    const double h = x * a.q[r] - x * x * vfi;
-                    a.e[r] += h * d;                              // updateError :194-198
-                }
-                a.q[r] += x * d;                                  // :60-62
-            }
-            __syncthreads();
-            if (tid == 0) a.v[f + i * k] = vn;                    // :64
-            __syncthreads();
-        }
+        if (FACTOR) q[r] += x * d;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        if (FACTOR) a.v[f + i * a.k] = tn;
+        else a.w[i] = tn;
     }
 }
 
@@ -352,29 +396,70 @@ __global__ __launch_bounds__(kLdsSweepThreads) void k_als_sweep_lds(AlsArgs a, c
 
 }  // namespace
 
-hipError_t launch_als_epoch(const AlsArgs &a, hipStream_t s) {
+namespace {
+
+template <bool FACTOR>
+hipError_t sweep_pass(const AlsArgs &a, const int32_t *h_cfeat, const int32_t *h_cptr, int f, int long_col, bool wide_wg, hipStream_t s) {
+    double *q = a.q + (FACTOR ? (int64_t)f * a.n_rows : 0);
+    int s0 = 0;
+    while (s0 < a.n_cols) {
+        const int len = h_cptr[s0 + 1] - h_cptr[s0];
+        if (len >= long_col) {
+            if (h_cfeat[s0] < a.num_attribute) {
+                int G = (len + 2047) / 2048;
+                if (G > kAlsMaxParts) G = kAlsMaxParts;
+                hipLaunchKernelGGL((k_als_col_sums<FACTOR>), dim3((unsigned)G), dim3(kColBlock), 0, s, a, q, h_cptr[s0], h_cptr[s0 + 1], (int64_t)h_cfeat[s0], f);
+                hipLaunchKernelGGL((k_als_col_update<FACTOR>), dim3((unsigned)G), dim3(kColBlock), 0, s, a, q, h_cptr[s0], h_cptr[s0 + 1], (int64_t)h_cfeat[s0], f);
+            }
+            ++s0;
+            continue;
+        }
+        int s1 = s0 + 1;
+        while (s1 < a.n_cols && h_cptr[s1 + 1] - h_cptr[s1] < long_col) ++s1;
+        if (wide_wg) hipLaunchKernelGGL((k_als_cols_wg<1024, FACTOR>), dim3(1), dim3(1024), 0, s, a, q, s0, s1, f);
+        else hipLaunchKernelGGL((k_als_cols_wg<256, FACTOR>), dim3(1), dim3(256), 0, s, a, q, s0, s1, f);
+        s0 = s1;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_als_epoch(const AlsArgs &a, const int32_t *h_cfeat, const int32_t *h_cptr, hipStream_t s) {
     int64_t blocks = (a.n_rows + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_als_residual, dim3((unsigned)blocks), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (a.scol && (size_t)a.n_rows * 2 * sizeof(double) <= kAlsLdsBytes) {
+    int64_t qb = (a.n_rows * a.k + 255) / 256;
+    if (qb > 4096) qb = 4096;
+    hipLaunchKernelGGL(k_als_q_all, dim3((unsigned)(qb < 1 ? 1 : qb)), dim3(256), 0, s, a, a.q);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    int long_col = kAlsLongColumn;
+    if (const char *ev = getenv("FMHIP_ALS_LONG")) long_col = atoi(ev) > 0 ? atoi(ev) : long_col;
+    if ((size_t)a.n_rows * 2 * sizeof(double) <= kAlsLdsBytes && !getenv("FMHIP_ALS_NO_LDS")) {
         // e and q fit the LDS of one CU: the one-wave column walk
         e = hipFuncSetAttribute((const void *)k_als_sweep_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAlsLdsBytes);
         if (e != hipSuccess) return e;
-        int64_t qb = (a.n_rows * a.k + 255) / 256;
-        if (qb > 4096) qb = 4096;
-        hipLaunchKernelGGL(k_als_q_all, dim3((unsigned)(qb < 1 ? 1 : qb)), dim3(256), 0, s, a, a.q);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
         hipLaunchKernelGGL(k_als_sweep_lds, dim3(1), dim3(kLdsSweepThreads), (size_t)a.n_rows * 2 * sizeof(double), s, a, a.q);
         return hipGetLastError();
     }
-    // mean column length decides the workgroup size (a barrier over 4 waves is ~3x cheaper than over 16)
-    const int64_t nnz = a.n_cols > 0 ? a.nnz : 0;
-    if (a.n_cols > 0 && nnz / a.n_cols < 512) hipLaunchKernelGGL(k_als_sweep<256>, dim3(1), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_als_sweep<1024>, dim3(1), dim3(1024), 0, s, a);
-    return hipGetLastError();
+    // e and q in global memory: w0, then one pass per parameter group following the column lengths — a run of short
+    // columns is one launch of one workgroup, a long column two chip-wide launches
+    hipLaunchKernelGGL(k_als_w0<1024>, dim3(1), dim3(1024), 0, s, a);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    // the short columns' mean length decides their workgroup size (a barrier over 4 waves is ~3x cheaper than over 16)
+    int64_t short_nnz = 0, n_short = 0;
+    for (int c = 0; c < a.n_cols; ++c) {
+        const int len = h_cptr[c + 1] - h_cptr[c];
+        if (len < long_col) { short_nnz += len; ++n_short; }
+    }
+    const bool wide_wg = n_short > 0 && short_nnz / n_short >= 512;
+    if ((e = sweep_pass<false>(a, h_cfeat, h_cptr, 0, long_col, wide_wg, s)) != hipSuccess) return e;
+    for (int f = 0; f < a.k; ++f)
+        if ((e = sweep_pass<true>(a, h_cfeat, h_cptr, f, long_col, wide_wg, s)) != hipSuccess) return e;
+    return hipSuccess;
 }
 
 }  // namespace fmhip

@@ -1704,6 +1704,7 @@ int fmhip_als_epoch(fmhip_model_t m, fmhip_dataset_t d, double reg0, double regw
     TRY(m->als_v.ensure(nv));
     TRY(m->als_e.ensure(nr));
     TRY(m->als_q.ensure(nr * (size_t)m->k));
+    TRY(m->als_part.ensure(2 * (size_t)kAlsMaxParts + 2));
     HIP_TRY(hipMemcpyAsync(m->als_w0.p, &m->h_w0, sizeof(double), hipMemcpyHostToDevice, m->stream));
     HIP_TRY(hipMemcpyAsync(m->als_w.p, m->h_w.data(), n1 * sizeof(double), hipMemcpyHostToDevice, m->stream));
     HIP_TRY(hipMemcpyAsync(m->als_v.p, m->h_v.data(), nv * sizeof(double), hipMemcpyHostToDevice, m->stream));
@@ -1733,7 +1734,8 @@ int fmhip_als_epoch(fmhip_model_t m, fmhip_dataset_t d, double reg0, double regw
         a.regv = regv;
         a.e = m->als_e.p;
         a.q = m->als_q.p;
-        HIP_TRY(launch_als_epoch(a, m->stream));
+        a.part = m->als_part.p;
+        HIP_TRY(launch_als_epoch(a, d->h_cfeat.data(), d->h_cptr.data(), m->stream));
     }
     std::vector<double> w(n1), v(nv);
     double w0 = 0.0;

@@ -172,7 +172,7 @@ struct fmhip_model {
     std::vector<double> h_w, h_v;
     double h_w0 = 0.0;
     bool host64_fresh = false;
-    DevBuf<double> als_w0, als_w, als_v, als_e, als_q;
+    DevBuf<double> als_w0, als_w, als_v, als_e, als_q, als_part;
     bool profiling = false;
     bool prof_rotate = false;     // time one kernel kind per step, rotating
     int prof_period = 1;          // ... and only on every prof_period-th step

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""BASELINE config 1's ALS epoch on the GPU beside the CPU oracle (bench.py's als_c1 leg on its own, for rocprofv3)."""
+"""bench.py's ALS legs on their own (for rocprofv3): BASELINE config 1's epoch, and the long-column shapes."""
 import json
 import os
 import sys
@@ -7,4 +7,4 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
-print(json.dumps(bench.als_c1(0)))
+print(json.dumps({"als_c1": bench.als_c1(0), "als_long_columns": bench.als_long(0)}))

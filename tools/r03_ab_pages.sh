@@ -2,8 +2,10 @@
 # Run ON THE GPU BOX: pages of the dense hot block (fmhip_tune key 12), 4 against 8, per configuration; one bench line each.
 set -e
 cd "$(dirname "$0")/.."
-for cfg in ${1:-"C3 C5 C4 C2"}; do
-  for pages in ${2:-"4 6 8"}; do
+cfgs=${1:-C3 C5 C4 C2}
+pagelist=${2:-4 6 8}
+for cfg in $cfgs; do
+  for pages in $pagelist; do
     timeout -k 10 200 python3 bench.py --config $cfg --no-extra --no-cpu-baseline --no-pmc --hot-pages $pages --steps 120 --warmup 12 \
       > gpurun_out/r03_pages_${cfg}_$pages.json 2> gpurun_out/r03_pages_${cfg}_$pages.err
     python3 - <<PY

@@ -4,7 +4,7 @@
 #   tools/r03_emulate.sh "8:300 8:200 8:450 4:300 2:300" [extra bench args]
 set -e
 cd "$(dirname "$0")/.."
-specs=${1:-"8:300"}; shift || true
+specs=${1:-8:300}; shift || true
 for spec in $specs; do
   tag=${spec/:/_}
   timeout -k 10 300 python3 bench.py --gpus 1 --force-dp --config C4 --emulate-allreduce $spec --no-cpu-baseline --steps 60 --warmup 8 "$@" \
