@@ -87,7 +87,9 @@ typedef struct fmhip_profile {
 int fmhip_version(void);
 const char *fmhip_last_error(void);
 int fmhip_device_count(int *count);
-/* tuning knobs (process-wide; results are identical across variants up to fp32 rounding):
+/* tuning knobs — fmhip_tune sets the PROCESS-WIDE DEFAULT of a key, fmhip_model_tune overrides it for one model (value < 0:
+ * back to the default); a launch reads the model's value if it has one, else the default as it stands then.  Results are
+ * identical across variants up to fp32 rounding.  Not synchronised: set the knobs before the threads that use them start.
  *   key 0  forward kernel : 60 = LDS w-tile (default: the linear weights of the 6144 lowest feature ids
  *                           are staged in LDS), 0 = plain global-memory gathers, 20 = LDS V-tile (rows of
  *                           the lowest-id features of V staged in LDS); the tiles only help when ids are
@@ -123,13 +125,14 @@ int fmhip_device_count(int *count);
  *          fixup launch — the rows the fixups assemble update themselves from registers, every other row is
  *          updated by extra workgroups beside them (bandwidth-bound work next to latency-bound work) — instead
  *          of as a launch of its own.  Bit-identical; 0 = separate update launch.
- *   key 12 pages of the dense hot block (1..8, default 8): 1 = the two-sided page only (round-1 layout); more = the next
+ *   key 12 pages of the dense hot block (1..8, default 4): 1 = the two-sided page only (round-1 layout); more = the next
  *          most frequent features that pass the density test (present in >= 2.5 % of the rows) are dense on the gradient
- *          side (fmhip_dataset_hot_pages).  Models of up to 32 (padded) factors form all 8 pages in one pass over P, wider
- *          ones 4 pages per pass
+ *          side (fmhip_dataset_hot_pages).  Models of up to 32 (padded) factors form up to 8 pages in one pass over P, wider
+ *          ones 4 pages per pass.  Pages 5-8 are there to be measured: on C2-C5 they neither gained nor lost (the features
+ *          they add sit at the break-even density)
  * Keys 3, 5 and 12 are only the DEFAULTS of fmhip_dataset_create (read at the time of the call; they decide the
- * layout of the dataset being built and nothing else) — fmhip_dataset_create_opts states them per dataset;
- * every other key is read by the next launch. */
+ * layout of the dataset being built and nothing else) — fmhip_dataset_create_opts states them per dataset and
+ * fmhip_model_tune refuses them; every other key is read by the next launch. */
 int fmhip_tune(int key, int value);
 
 /* ---- model: `new FMModel(num_attribute, num_factor)`  S/fm/FMModel.scala:9-22 -- */
@@ -138,6 +141,8 @@ int fmhip_tune(int key, int value);
  * hipStream_t (NULL = the library creates its own non-blocking stream). */
 int fmhip_model_create(int device, int64_t num_attribute, int32_t num_factor, void *stream, fmhip_model_t *out);
 int fmhip_model_destroy(fmhip_model_t m);
+/* overrides a tuning key (see fmhip_tune) for THIS model only; value < 0 = follow the process-wide default again */
+int fmhip_model_tune(fmhip_model_t m, int key, int value);
 /* padded_factors: floats per device row (whole 128-B lines: 32, 64, 128 or 256) */
 int fmhip_model_info(fmhip_model_t m, int64_t *num_attribute, int32_t *num_factor, int32_t *padded_factors);
 /* The reference's own initialisation, drawn on the device: w0 = 0, w = 0, v ~ N(mean, stdev)

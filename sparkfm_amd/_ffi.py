@@ -31,7 +31,7 @@ SYMBOLS = (
     "fmhip_dp_step", "fmhip_dp_epoch", "fmhip_comm_profile_begin", "fmhip_comm_profile_end", "fmhip_shard_rows", "fmhip_comm_emulate",
     "fmhip_feature_counts", "fmhip_rank_from_counts", "fmhip_relabel_columns", "fmhip_dataset_hot_pages",
     "fmhip_comm_create_external", "fmhip_stream_wait", "fmhip_device_read", "fmhip_device_write",
-    "fmhip_dp_exchange", "fmhip_dp_exchange_info", "fmhip_comm_emulate_ranks",
+    "fmhip_dp_exchange", "fmhip_dp_exchange_info", "fmhip_comm_emulate_ranks", "fmhip_model_tune",
 )
 UNIQUE_ID_BYTES = 128
 
@@ -104,6 +104,7 @@ def load():
     L.fmhip_tune.argtypes = [C.c_int, C.c_int]
     L.fmhip_model_create.argtypes = [C.c_int, i64, i32, vp, P(vp)]
     L.fmhip_model_destroy.argtypes = [vp]
+    L.fmhip_model_tune.argtypes = [vp, C.c_int, C.c_int]
     L.fmhip_model_info.argtypes = [vp, P(i64), P(i32), P(i32)]
     L.fmhip_model_set_params.argtypes = [vp, dbl, vp, vp]
     L.fmhip_model_get_params.argtypes = [vp, P(dbl), vp, vp]

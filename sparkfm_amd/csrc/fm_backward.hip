@@ -768,7 +768,7 @@ hipError_t bwd_dispatch(const BwdArgs &a, hipStream_t s) {
     dim3 g((unsigned)((a2.xcd_chunk > 0 ? a2.xcd_chunk * 8 : nblk) + a.hot_blocks)), b(kBlock);
     // the pipelined kernel needs P to fit a 32-bit buffer view (< 4 GiB per batch); for k > 64 (J > 1)
     // its register footprint spills, so those sizes take the plain walk
-    const bool pipe = J == 1 && a.p_bytes && g_tune[kTuneBwd] == 1;
+    const bool pipe = J == 1 && a.p_bytes && a.pipelined == 1;
 #define FMHIP_BW(PACKED_, HOT_)                                                               \
     if (pipe) hipLaunchKernelGGL((k_backward_p<LPN, J, PACKED_, HOT_>), g, b, 0, s, a2);      \
     else hipLaunchKernelGGL((k_backward<LPN, J, PACKED_, HOT_>), g, b, 0, s, a2)

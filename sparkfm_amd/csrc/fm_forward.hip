@@ -5,7 +5,7 @@
 
 namespace fmhip {
 
-int g_tune[kTuneCount] = {60, 1, 0, 0, 0, 1, 0, 1, 0, 1, 0, 1, kHotPages};   // forward: w-tile kernel; backward: pipelined; tile rows: auto; row blocks, XCD placement: off; hot block: on; row order: on; forced flat loads: off; lazy decay: on; fused update: off; merged finish: on; hot pages: all
+int g_tune[kTuneCount] = {60, 1, 0, 0, 0, 1, 0, 1, 0, 1, 0, 1, 4};   // forward: w-tile kernel; backward: pipelined; tile rows: auto; row blocks, XCD placement: off; hot block: on; row order: on; forced flat loads: off; lazy decay: on; fused update: off; merged finish: on; hot pages: 4 of up to kHotPages (pages 5-8 measured: no gain, profiles/r03_experiments.md)
 
 int padded_factors(int k) {
     int kp = 32;   // a row is at least one 128-B line: the cost of a gather is per line, not per byte
@@ -15,12 +15,12 @@ int padded_factors(int k) {
 
 int forward_wt_occupancy(int Kp);   // workgroups of k_forward_wt one CU holds (defined next to the kernel)
 
-int forward_blocks_wt(int Kp, int64_t n_rows) {
+int forward_blocks_wt(int Kp, int64_t n_rows, int occ_cap) {
     // persistent: as many workgroups as the chip holds at once (24 KiB of LDS each; the register count
     // decides: 5 per CU at Kp = 32, fewer for wider rows), rows grid-strided
     const int64_t need = forward_blocks(Kp, n_rows);
     int occ = forward_wt_occupancy(Kp);
-    if (g_tune[kTuneFwdOcc] > 0 && g_tune[kTuneFwdOcc] < occ) occ = g_tune[kTuneFwdOcc];   // experiment knob: fewer resident workgroups
+    if (occ_cap > 0 && occ_cap < occ) occ = occ_cap;   // experiment knob (tuning key 6): fewer resident workgroups
     const int64_t cap = (int64_t)256 * occ;
     return (int)(need < cap ? need : cap);
 }
@@ -427,12 +427,12 @@ struct FwdPlan { int var; int blocks; };
 template <int LPN, int J>
 FwdPlan fwd_plan(const FwdArgs &a) {
     constexpr int KP = 4 * LPN * J;
-    int var = g_tune[kTuneFwd];
+    int var = a.variant;
     if (a.pack_k >= 0) var = 0;
     if (var == 20 && (!a.v_bytes || a.hot_T || a.tile_rows < 1)) var = a.hot_T ? 60 : 0;
     if (var == 60 && a.wt_rows < 1) var = 0;
     if (var != 20 && var != 60) var = 0;
-    const int blocks = var == 60 ? forward_blocks_wt(KP, a.n_rows) : var == 20 ? forward_blocks_lds(a.n_rows) : forward_blocks(KP, a.n_rows);
+    const int blocks = var == 60 ? forward_blocks_wt(KP, a.n_rows, a.occ_cap) : var == 20 ? forward_blocks_lds(a.n_rows) : forward_blocks(KP, a.n_rows);
     return {var, blocks};
 }
 

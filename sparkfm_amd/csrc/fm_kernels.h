@@ -24,7 +24,7 @@ constexpr int kHotPages = 8;
 // pages the gradient-side block product carries through ONE pass over P (its accumulators: pages x Kp/16 x 4 VGPRs: 64 at
 // 8 pages x Kp = 32 and at 4 pages x Kp = 64); a dataset with more pages than that takes several passes
 constexpr int hot_pages_max(int Kp) { return Kp <= 32 ? 8 : (Kp <= 64 ? 4 : 1); }
-extern int g_tune[kTuneCount];
+extern int g_tune[kTuneCount];     // process-wide DEFAULTS (fmhip_tune); a model may override a key (fmhip_model_tune)
 
 // padded factor count: 4 * LPN * J with LPN = lanes per row-slot (<= 16), J float4 per lane
 int padded_factors(int k);
@@ -32,7 +32,7 @@ int padded_factors(int k);
 constexpr int kMaxFwdBlocks = 16384;
 int forward_blocks(int Kp, int64_t n_rows);
 int forward_blocks_lds(int64_t n_rows);           // grid of the LDS V-tile forward
-int forward_blocks_wt(int Kp, int64_t n_rows);    // grid of the w-tile forward
+int forward_blocks_wt(int Kp, int64_t n_rows, int occ_cap = 0);    // grid of the w-tile forward
 
 enum FwdMode { kFwdTrain = 0, kFwdResidual = 1, kFwdQ = 2 };
 
@@ -62,6 +62,9 @@ struct FwdArgs {
     // lazy weight decay: the stored tables hold U with V = sv * U and w = sw * (stored w) (both 1 unless
     // rows-only updates with decay are pending, fm_apply.hip); the row epilogue applies them
     float sv, sw;
+    // host-side launch choices (the model's tuning keys 0 and 6; the kernels never read them)
+    int32_t variant;   // 60 = LDS w-tile kernel, 20 = LDS V-tile kernel, 0 = plain
+    int32_t occ_cap;   // cap on the w-tile kernel's resident workgroups per CU (0 = all that fit)
 };
 
 // Fused update (single-GPU step, nothing to exchange): a finished gradient row is applied to its parameter row on
@@ -160,6 +163,7 @@ struct BwdArgs {
     // partial sums while the others walk the sparse stream; pages * kHotT extra workgroups of k_fixup finish it
     HotArgs hot;
     int32_t hot_blocks;
+    int32_t pipelined;         // host-side launch choice (the model's tuning key 1): 1 = k_backward_p where it applies
 };
 
 

@@ -711,7 +711,7 @@ FwdArgs fwd_args(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm) {
         // tables of 4 GiB and more do not fit a 32-bit buffer view and take the flat-address kernels
         // (fmhip_tune key 8 forces those for any size, so that tests reach them on small inputs)
         const uint64_t vb = (uint64_t)m->n1p * m->Kp * sizeof(float);
-        a.v_bytes = (vb < 0xffffffffull && !g_tune[kTuneFlat]) ? (uint32_t)vb : 0u;
+        a.v_bytes = (vb < 0xffffffffull && !m->tv(kTuneFlat)) ? (uint32_t)vb : 0u;
     }
     a.sv = (float)m->sv;
     a.sw = (float)m->sw;
@@ -720,7 +720,7 @@ FwdArgs fwd_args(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm) {
     a.row0 = bm.row0;
     // longest-first row order: pays for wide rows only (k=64: -8 %); at Kp = 32 it changes nothing but the
     // locality of the per-row streams (forward FETCH_SIZE 184 -> 269 MB), so narrow models walk in stored order
-    a.order = (g_tune[kTuneRowOrder] && m->Kp >= 64) ? d->row_order.p + bm.row0 : nullptr;
+    a.order = (m->tv(kTuneRowOrder) && m->Kp >= 64) ? d->row_order.p + bm.row0 : nullptr;
     a.n_rows = (int32_t)bm.rows;
     a.P = m->P.p;
     a.e = m->e.p;
@@ -733,9 +733,11 @@ FwdArgs fwd_args(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm) {
     {
         // LDS V-tile size: as many hot rows as fit 128 KiB (+ their w), capped by the model
         int64_t t = (128 * 1024) / ((int64_t)m->Kp * 4);
-        if (g_tune[kTuneTile] > 0) t = g_tune[kTuneTile];
+        if (m->tv(kTuneTile) > 0) t = m->tv(kTuneTile);
         a.tile_rows = (int32_t)std::min<int64_t>(t, m->n1);
-        a.wt_rows = (int32_t)std::min<int64_t>(g_tune[kTuneTile] > 0 ? g_tune[kTuneTile] : 6144, m->n1);   // 24 KiB
+        a.wt_rows = (int32_t)std::min<int64_t>(m->tv(kTuneTile) > 0 ? m->tv(kTuneTile) : 6144, m->n1);   // 24 KiB
+        a.variant = m->tv(kTuneFwd);
+        a.occ_cap = m->tv(kTuneFwdOcc);
     }
     return a;
 }
@@ -761,12 +763,13 @@ BwdArgs bwd_args(fmhip_model_t m, fmhip_dataset_t d, int64_t b) {
     a.n_ranges = bm.n_ranges;
     a.rho_lo = 0;
     a.rho_hi = bm.n_ranges;
-    a.xcd_chunk = g_tune[kTuneXcd] > 0 ? 1 : 0;
+    a.xcd_chunk = m->tv(kTuneXcd) > 0 ? 1 : 0;
+    a.pipelined = m->tv(kTuneBwd);
     a.n_split = bm.n_split;
     a.P = m->P.p;
     {
         const uint64_t pb = (uint64_t)bm.rows * m->Kp * sizeof(float);
-        a.p_bytes = (pb < 0xffffffffull && !g_tune[kTuneFlat]) ? (uint32_t)pb : 0u;
+        a.p_bytes = (pb < 0xffffffffull && !m->tv(kTuneFlat)) ? (uint32_t)pb : 0u;
     }
     a.e = m->e.p;
     a.GV = m->GV();
@@ -945,7 +948,7 @@ int step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double *acc, con
 bool plan_fused(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double eta, double reg0, double regw, double regv, FusedPlan *p) {
     const double dv = 1.0 - eta * regv, dw = 1.0 - eta * regw;
     const bool decay = regw != 0.0 || regv != 0.0;
-    const bool lazy_ok = !decay || (g_tune[kTuneLazy] && dv >= 0.5 && dw >= 0.5 && dv <= 1.0 && dw <= 1.0);
+    const bool lazy_ok = !decay || (m->tv(kTuneLazy) && dv >= 0.5 && dw >= 0.5 && dv <= 1.0 && dw <= 1.0);
     const BatchMeta &bm0 = d->batches[(size_t)b];
     p->eta = eta;
     p->reg0 = reg0;
@@ -959,12 +962,12 @@ bool plan_fused(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double eta, doubl
     // cannot ride in the scale) it runs inside the fixup launch, beside the fixups, instead of as a launch of its own
     const int64_t touched = (int64_t)bm0.n_cols + d->hot_pages * kHotT;
     const bool rows_only = lazy_ok && touched * 2 <= m->n1;
-    if (g_tune[kTuneMerged] && !g_tune[kTuneFused] && d->rb_rows == 0 && !rows_only && bm0.own_off >= 0 && d->dimension <= m->n) {
+    if (m->tv(kTuneMerged) && !m->tv(kTuneFused) && d->rb_rows == 0 && !rows_only && bm0.own_off >= 0 && d->dimension <= m->n) {
         p->mode = 2;
         p->sv_out = p->sw_out = 1.0;      // the dense pass folds the scale
         return true;
     }
-    if (!g_tune[kTuneFused] || d->rb_rows != 0) return false;
+    if (!m->tv(kTuneFused) || d->rb_rows != 0) return false;
     if (!lazy_ok) return false;
     p->mode = 1;
     p->sv_out = m->sv * dv;
@@ -1007,7 +1010,7 @@ int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double reg
     double sv_out = 1.0, sw_out = 1.0;
     const double dv = 1.0 - eta * regv, dw = 1.0 - eta * regw;
     const bool decay = regw != 0.0 || regv != 0.0;
-    if (d && b >= 0 && d->rb_rows == 0 && (!decay || (g_tune[kTuneLazy] && dv >= 0.5 && dw >= 0.5 && dv <= 1.0 && dw <= 1.0))) {
+    if (d && b >= 0 && d->rb_rows == 0 && (!decay || (m->tv(kTuneLazy) && dv >= 0.5 && dw >= 0.5 && dv <= 1.0 && dw <= 1.0))) {
         const BatchMeta &bm = d->batches[(size_t)b];
         const int64_t touched = (int64_t)bm.n_cols + d->hot_pages * kHotT;
         if (touched * 2 <= m->n1) {     // otherwise the dense, perfectly coalesced pass is as cheap
@@ -1128,15 +1131,15 @@ int step_apply_shard(fmhip_model_t m, double eta, double reg0, double regw, doub
 }
 
 // can weight decay ride in the tables' scale for this (eta, reg)?  (no decay at all: trivially)
-bool lazy_decay_ok(double eta, double regw, double regv) {
+bool lazy_decay_ok(fmhip_model_t m, double eta, double regw, double regv) {
     const double dv = 1.0 - eta * regv, dw = 1.0 - eta * regw;
     if (regw == 0.0 && regv == 0.0) return true;
-    return g_tune[kTuneLazy] && dv >= 0.5 && dw >= 0.5 && dv <= 1.0 && dw <= 1.0;
+    return m->tv(kTuneLazy) && dv >= 0.5 && dw >= 0.5 && dv <= 1.0 && dw <= 1.0;
 }
 
 int step_apply_rows(fmhip_model_t m, double eta, double reg0, double regw, double regv, const int32_t *feat, int32_t n_feat,
                     const float *rows, const GradView *view) {
-    if (!lazy_decay_ok(eta, regw, regv))
+    if (!lazy_decay_ok(m, eta, regw, regv))
         return fail(FMHIP_ERR_UNSUPPORTED, "a rows-only update needs weight decay that fits the tables' scale (0.5 <= 1 - eta*reg <= 1)");
     const double sv_out = m->sv * (1.0 - eta * regv), sw_out = m->sw * (1.0 - eta * regw);
     ApplyArgs a{};
@@ -1269,6 +1272,15 @@ int fmhip_tune(int key, int value) {
     return FMHIP_OK;
 }
 
+int fmhip_model_tune(fmhip_model_t m, int key, int value) {
+    if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
+    if (key < 0 || key >= kTuneCount) return fail(FMHIP_ERR_INVALID, "unknown tuning key %d", key);
+    if (key == kTuneRowBlock || key == kTuneHot || key == kTuneHotPages)
+        return fail(FMHIP_ERR_INVALID, "tuning key %d decides a DATASET's layout: state it in fmhip_dataset_opts (or the process default, fmhip_tune)", key);
+    m->tune[key] = value < 0 ? -1 : value;
+    return FMHIP_OK;
+}
+
 int fmhip_device_count(int *count) {
     if (!count) return fail(FMHIP_ERR_INVALID, "count is NULL");
     *count = 0;
@@ -1288,6 +1300,7 @@ int fmhip_model_create(int device, int64_t num_attribute, int32_t num_factor, vo
     fmhip_model *m = new (std::nothrow) fmhip_model();
     if (!m) return fail(FMHIP_ERR_NOMEM, "out of host memory");
     m->device = device;
+    for (int &t : m->tune) t = -1;          // every key follows the process-wide default until fmhip_model_tune says otherwise
     m->n = num_attribute;
     m->n1 = num_attribute + 1;
     m->n1p = (m->n1 + 3) & ~(int64_t)3;

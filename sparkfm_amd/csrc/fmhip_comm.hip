@@ -420,7 +420,7 @@ int dp_step_touched(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_com
     const bool live = batch >= 0;
     if (c->tsteps.empty() || !c->cg || c->msg_kp != m->Kp)
         return fail(FMHIP_ERR_INVALID, "the touched-rows exchange is not planned for this model: call fmhip_dp_plan (every rank)");
-    if (!lazy_decay_ok(eta, regw, regv))
+    if (!lazy_decay_ok(m, eta, regw, regv))
         return fail(FMHIP_ERR_UNSUPPORTED, "the touched-rows exchange needs weight decay that fits the tables' scale (0.5 <= 1 - eta*reg <= 1)");
     const bool packed_dirty = m->grad_dirty;      // this step neither writes nor cleans the model's packed gradient
     const int64_t t = c->t_cursor;

@@ -173,6 +173,10 @@ struct fmhip_model {
     double h_w0 = 0.0;
     bool host64_fresh = false;
     DevBuf<double> als_w0, als_w, als_v, als_e, als_q, als_part;
+    // per-model overrides of the tuning keys (fmhip_model_tune); -1 = the process-wide default (fmhip_tune) as it stands
+    // at the time of the launch
+    int tune[fmhip::kTuneCount];
+    int tv(int key) const { return tune[key] >= 0 ? tune[key] : fmhip::g_tune[key]; }
     bool profiling = false;
     bool prof_rotate = false;     // time one kernel kind per step, rotating
     int prof_period = 1;          // ... and only on every prof_period-th step
@@ -224,7 +228,7 @@ int step_apply_shard(fmhip_model_t m, double eta, double reg0, double regw, doub
 // view given: the gradient rows are read from (and zeroed in) its compact arrays, row j belonging to feature feat[j]
 int step_apply_rows(fmhip_model_t m, double eta, double reg0, double regw, double regv, const int32_t *feat, int32_t n_feat,
                     const float *rows, const GradView *view = nullptr);
-bool lazy_decay_ok(double eta, double regw, double regv);
+bool lazy_decay_ok(fmhip_model_t m, double eta, double regw, double regv);
 int read_scal(fmhip_model_t m, fmhip_stats *st);
 
 }  // namespace host

@@ -523,13 +523,13 @@ def test_als_sweeps_lds_and_fallback(fmhip, n_rows, n1, k):
     fm.close()
 
 
-@pytest.mark.parametrize("n_rows,n1,k,long_col", [(30000, 9, 3, None), (12000, 40, 2, "1500"), (11000, 60, 2, "1")])
+@pytest.mark.parametrize("n_rows,n1,k,long_col", [(30000, 9, 3, None), (12000, 40, 2, "1050"), (11000, 60, 2, "1")])
 def test_als_long_columns_on_the_whole_chip(fmhip, monkeypatch, n_rows, n1, k, long_col):
     """Datasets past the LDS sweep follow a launch plan made from the column lengths (als_kernels.hip): columns of at
     least kAlsLongColumn = 8192 entries take the chip-wide step (partial sums per workgroup, a fixed tree over the
     partials, the update of e and q slice by slice), runs of shorter ones a single workgroup.  9 features over 30,000
     rows: every column is long by size; FMHIP_ALS_LONG lowers the mark so that long and short columns alternate
-    (1500) and so that EVERY column, down to single entries, goes through the two launches (1).  Two epochs against
+    (1050) and so that EVERY column, down to single entries, goes through the two launches (1).  Two epochs against
     the fp64 oracle; quirk Q1 (the last slot is never trained) included."""
     from helpers import random_problem
     if long_col:
@@ -538,7 +538,7 @@ def test_als_long_columns_on_the_whole_chip(fmhip, monkeypatch, n_rows, n1, k, l
     ds = fmhip.DataSet(a["row_ptr"], a["col"], a["val"], a["y"]).cache()
     lens = np.bincount(a["col"], minlength=n1)
     mark = int(long_col) if long_col else 8192
-    assert (lens >= mark).any() and (long_col != "1500" or (lens < mark).any())
+    assert (lens >= mark).any() and (long_col != "1050" or (lens < mark).any())
     fm = fmhip.FMModel(n1 - 1, k)
     fm.w0, fm.w, fm.v = a["w0"], a["w"], a["v"]
     fm.reg0, fm.regw, fm.regv = 0.01, 0.1, 5.0

@@ -254,7 +254,7 @@ def test_dense_hot_block(fmhip, request, k, n_hot, dup, zero, pages, flat):
         ds, fm = make(fmhip, a, batch_rows=br)
     finally:
         L.fmhip_tune(5, 1)
-        L.fmhip_tune(12, 8)
+        L.fmhip_tune(12, 4)
     lay = ds.layout()
     refused = {int(hot_ids[i]) for i in (dup, zero) if i is not None}
     dense = set(lay["hot_ids_all"])
