@@ -13,7 +13,7 @@ LIB = os.path.join(LIBDIR, "libfmhip.so")
 SYNTH = os.path.join(LIBDIR, "libfmsynth.so")
 
 HIP_SOURCES = ["fm_forward.hip", "fm_backward.hip", "fm_apply.hip", "als_kernels.hip", "csc_build.hip", "fmhip_api.hip",
-               "fmhip_comm.hip"]
+               "fmhip_dataset.hip", "fmhip_step.hip", "fmhip_comm.hip"]
 HIP_DEPS = ["fm_kernels.h", "fm_device.h", "als_kernels.h", "csc_build.h", "fmhip_internal.h",
             os.path.join("..", "..", "include", "fmhip.h")]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]

@@ -1,6 +1,7 @@
 // fmhip_internal.h — host-side state behind the opaque handles of include/fmhip.h, shared by the
-// translation units of libfmhip.so (fmhip_api.hip: datasets, models, the single-GPU step;
-// fmhip_comm.hip: the data-parallel step over RCCL).  Not installed, not part of the ABI.
+// translation units of libfmhip.so (fmhip_api.hip: the C ABI of models, scoring and training; fmhip_dataset.hip:
+// datasets; fmhip_step.hip: the single-GPU step in pieces; fmhip_comm.hip: the data-parallel step).
+// Not installed, not part of the ABI.
 #pragma once
 #include "../../include/fmhip.h"
 #include "fm_kernels.h"
@@ -199,7 +200,11 @@ struct fmhip_model {
 namespace fmhip {
 namespace host {
 
+extern thread_local std::string g_err;    // the calling thread's last error message (fmhip_api.hip)
 int set_device(int device);
+// ---- fmhip_step.hip
+int ensure_workspace(fmhip_model_t m, fmhip_dataset_t d);
+FwdArgs fwd_args(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm);
 int check_pair(fmhip_model_t m, fmhip_dataset_t d);
 int check_train(fmhip_model_t m, fmhip_dataset_t d);      // + the dataset must have its transposes
 int check_batch(fmhip_dataset_t d, int64_t batch);
@@ -215,6 +220,13 @@ struct FusedPlan {
 };
 int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo, int64_t feat_hi, bool finish, double *acc,
                   const FusedPlan *fused = nullptr);
+// forward + backward + fixup of one batch into the packed gradient (fused: straight into the parameters)
+int step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double *acc, const FusedPlan *fused = nullptr);
+// can this step's update run inside the fixup launch / the column walk?  (fills *p; false: a launch of its own, step_apply)
+bool plan_fused(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double eta, double reg0, double regw, double regv, FusedPlan *p);
+int finish_fused(fmhip_model_t m, const FusedPlan &p);      // what step_apply leaves behind, for a step planned fused
+int fold_scales(fmhip_model_t m);                           // lazily decayed tables back to scale 1
+int read_acc(fmhip_model_t m, fmhip_stats *st);             // the fp64 epoch accumulators (synchronises)
 int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double regv, fmhip_dataset_t d = nullptr, int64_t b = -1);
 int step_apply_interval(fmhip_model_t m, double eta, double reg0, double regw, double regv, int64_t lo, int64_t hi,
                         const float *rows, bool last);

@@ -8,12 +8,12 @@ name=$1; rev=${2:-HEAD}
 root=$(cd "$(dirname "$0")/.." && pwd)
 tmp=$(mktemp -d /tmp/fmhip_variant.XXXXXX)
 mkdir -p $tmp/sparkfm_amd/csrc $tmp/include
-for f in fm_forward.hip fm_backward.hip fm_apply.hip fm_device.h fm_kernels.h als_kernels.hip als_kernels.h csc_build.hip csc_build.h fmhip_api.hip fmhip_comm.hip fmhip_internal.h; do
+for f in fm_forward.hip fm_backward.hip fm_apply.hip fm_device.h fm_kernels.h als_kernels.hip als_kernels.h csc_build.hip csc_build.h fmhip_api.hip fmhip_dataset.hip fmhip_step.hip fmhip_comm.hip fmhip_internal.h; do
   if [ "$rev" = WORK ]; then cp $root/sparkfm_amd/csrc/$f $tmp/sparkfm_amd/csrc/$f; else git -C $root show $rev:sparkfm_amd/csrc/$f > $tmp/sparkfm_amd/csrc/$f; fi
 done
 if [ "$rev" = WORK ]; then cp $root/include/fmhip.h $tmp/include/fmhip.h; else git -C $root show $rev:include/fmhip.h > $tmp/include/fmhip.h; fi
 objs=""
-for f in fm_forward fm_backward fm_apply als_kernels csc_build fmhip_api fmhip_comm; do
+for f in fm_forward fm_backward fm_apply als_kernels csc_build fmhip_api fmhip_dataset fmhip_step fmhip_comm; do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC $EXTRA_FLAGS -c $tmp/sparkfm_amd/csrc/$f.hip -o $tmp/$f.o &
   objs="$objs $tmp/$f.o"
 done
