@@ -19,6 +19,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXTRA_PASSES = ("ta", "ta2", "ta3", "tcp", "tcp2", "ea", "ea2")      # tools/profile_round.sh
 
 
 def short(name):
@@ -62,7 +63,7 @@ def main():
     write, _ = load_pmc(tag, "write", skip)
     l2, _ = load_pmc(tag, "l2", skip)
     sq, _ = load_pmc(tag, "sq", skip)
-    extra = {name: load_pmc(tag, name, skip)[0] for name in ("ta", "tcp", "ea", "ea2")}
+    extra = {name: load_pmc(tag, name, skip)[0] for name in EXTRA_PASSES}
     lines.append("")
     lines.append("# rocprofv3 --pmc, one pass per group (mean per dispatch after the first %d dispatches of each kernel)" % skip)
     entries = []
@@ -85,7 +86,7 @@ def main():
             parts.append("TCC_HIT=%.0f TCC_MISS=%.0f L2_hit=%.3f" % (hit, miss, h))
         if kn in sq:
             parts.append(" ".join("%s=%.3g" % (c, v) for c, v in sorted(sq[kn].items())))
-        for name in ("ta", "tcp", "ea", "ea2"):
+        for name in EXTRA_PASSES:
             if kn in extra[name]:
                 parts.append(" ".join("%s=%.4g" % (c, v) for c, v in sorted(extra[name][kn].items())))
         ea = dict(extra["ea"].get(kn, {}), **extra["ea2"].get(kn, {}))
