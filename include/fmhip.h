@@ -99,7 +99,9 @@ int fmhip_device_count(int *count);
  *   key 3  default rows per row block of the transposes fmhip_dataset_create builds (0 = off):
  *          entries sorted by (row block, feature) so a block's slice of P stays L2-resident in the
  *          backward; features occurring in several blocks are summed by an extra fixup pass
- *   key 4  XCD-aware workgroup placement in the backward (0 = off, default)
+ *   key 4  XCD-aware workgroup placement in the backward: 0 = off (default); 1 = XCD x walks the x-th eighth of the stream
+ *          (pays with row-blocked transposes, key 3); 2 = band-affine: XCD x walks the ranges of long columns that fall into
+ *          ITS row bands first (whole-batch backward of feature-sorted transposes; wave sums off)
  *   key 5  default for the dense hot block of the datasets fmhip_dataset_create builds (1 = on; 0 = off): in a
  *          dataset of more than one mini-batch the (at most 16) features present in >= 10 % of the rows —
  *          none that occurs twice in a row or with a stored zero — leave the sparse streams for a dense

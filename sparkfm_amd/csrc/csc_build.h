@@ -35,4 +35,9 @@ hipError_t csc_build_batch(hipStream_t s, const CscScratch &sc, const int64_t *r
                            int32_t nnz, int key_bits, int32_t rb_rows, int rb_bits, uint32_t *crow, float *cval,
                            double *cval64, const uint32_t *drop = nullptr, int32_t drop_key = 0);
 
+// first[rho], last[rho] = the batch-local rows of the first and the last entry of range rho (kRangeLen entries each) of
+// the transposed stream crow[0 .. nnz): what the band-affine placement of the backward's ranges is planned from
+hipError_t csc_range_rows(hipStream_t s, const uint32_t *crow, int32_t nnz, int32_t range_len, int32_t n_ranges, int32_t *first,
+                          int32_t *last);
+
 }  // namespace fmhip

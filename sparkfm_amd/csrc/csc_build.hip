@@ -96,4 +96,23 @@ hipError_t csc_build_batch(hipStream_t s, const CscScratch &sc, const int64_t *r
     return hipGetLastError();
 }
 
+namespace {
+__global__ __launch_bounds__(256) void k_range_rows(const uint32_t *crow, int32_t nnz, int32_t range_len, int32_t n_ranges, int32_t *first,
+                                                    int32_t *last) {
+    const int32_t rho = (int32_t)(blockIdx.x * 256 + threadIdx.x);
+    if (rho >= n_ranges) return;
+    const int64_t beg = (int64_t)rho * range_len;
+    const int64_t end = beg + range_len < nnz ? beg + range_len : nnz;
+    first[rho] = (int32_t)(crow[beg] & 0x7fffffffu);
+    last[rho] = (int32_t)(crow[end - 1] & 0x7fffffffu);
+}
+}  // namespace
+
+hipError_t csc_range_rows(hipStream_t s, const uint32_t *crow, int32_t nnz, int32_t range_len, int32_t n_ranges, int32_t *first,
+                          int32_t *last) {
+    if (n_ranges < 1) return hipSuccess;
+    hipLaunchKernelGGL(k_range_rows, dim3((unsigned)((n_ranges + 255) / 256)), dim3(256), 0, s, crow, nnz, range_len, n_ranges, first, last);
+    return hipGetLastError();
+}
+
 }  // namespace fmhip

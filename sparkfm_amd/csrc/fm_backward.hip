@@ -343,8 +343,15 @@ struct RangeWalk {
         // xcd_chunk > 0: XCD-aware placement — workgroups b, b+8, b+16, .. share an XCD (round-robin
         // dispatch), so XCD x is given the x-th contiguous eighth of the stream: with a row-blocked
         // stream that is a few whole row blocks, whose slice of P then lives in that XCD's L2 only.
-        const int blk = a.xcd_chunk > 0 ? (bx & 7) * a.xcd_chunk + (bx >> 3) : bx;
-        rho = (a.rho_lo / SLOTS + blk) * SLOTS + threadIdx.x / LPN;
+        if (a.xlist) {
+            // band-affine placement: this workgroup's ranges come from the list of the XCD it runs on (see BwdArgs::xlist)
+            const int x = bx & (kXcds - 1), j = (bx >> 3) * SLOTS + (int)(threadIdx.x / LPN);
+            if (j >= a.xlen[x]) return false;
+            rho = a.xlist[a.xoff[x] + j];
+        } else {
+            const int blk = a.xcd_chunk > 0 ? (bx & 7) * a.xcd_chunk + (bx >> 3) : bx;
+            rho = (a.rho_lo / SLOTS + blk) * SLOTS + threadIdx.x / LPN;
+        }
         if (rho < a.rho_lo || rho >= a.rho_hi) return false;
         beg = rho * kRangeLen;
         const int end = (beg + kRangeLen < a.nnz) ? beg + kRangeLen : a.nnz;
@@ -352,7 +359,7 @@ struct RangeWalk {
         ca = a.cptr[seg];
         const int cb = a.cptr[seg + 1];                       // the column open at `beg`
         wbeg = (rho - (int)((threadIdx.x & 63) / LPN)) * kRangeLen;
-        clean = (ca <= wbeg) && (cb >= wbeg + WS * kRangeLen);   // wave-uniform by construction
+        clean = !a.no_wave_sum && (ca <= wbeg) && (cb >= wbeg + WS * kRangeLen);   // wave-uniform by construction
         is_head = ca < beg;
         p0 = beg;
         stop = end;
@@ -593,12 +600,13 @@ struct ColumnUnits {
     static constexpr int WS = 64 / LPN;
     static constexpr int WSPAN = WS * kRangeLen;
     int ca, ra, w_lo, nw, nl, r2, count;
-    __device__ __forceinline__ ColumnUnits(int ca_, int cb) : ca(ca_) {
+    // no_wave: the launch that wrote the partials formed no wave sums (band-affine placement): every range is a unit
+    __device__ __forceinline__ ColumnUnits(int ca_, int cb, bool no_wave) : ca(ca_) {
         ra = ca / kRangeLen;
         const int rb = (cb - 1) / kRangeLen;
         w_lo = (ca + WSPAN - 1) / WSPAN;
         const int w_hi = cb / WSPAN;                              // clean waves [w_lo, w_hi)
-        nw = w_hi > w_lo ? w_hi - w_lo : 0;
+        nw = (w_hi > w_lo && !no_wave) ? w_hi - w_lo : 0;
         nl = nw ? w_lo * WS - ra : rb - ra + 1;                   // leading single ranges
         r2 = w_hi * WS;                                           // first trailing range
         count = nw ? nl + nw + (rb - r2 + 1) : nl;
@@ -654,7 +662,7 @@ __global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
         const int idx = blockIdx.x * SLOTS + threadIdx.x / LPN;
         if (idx >= a.n_split_short) return;
         const int seg = a.split_short[idx];
-        const ColumnUnits<LPN, J> cu(a.cptr[seg], a.cptr[seg + 1]);
+        const ColumnUnits<LPN, J> cu(a.cptr[seg], a.cptr[seg + 1], a.no_wave_sum != 0);
         for (int t = 0; t < cu.count; ++t) {
             const float *pr = cu.row(a.part, t);
             const float4 *p4 = reinterpret_cast<const float4 *>(pr) + l;
@@ -673,7 +681,7 @@ __global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
     const int idx = (int)blockIdx.x - blocks_short;
     if (idx >= a.n_split) return;
     const int seg = a.split_seg[idx];
-    const ColumnUnits<LPN, J> cu(a.cptr[seg], a.cptr[seg + 1]);
+    const ColumnUnits<LPN, J> cu(a.cptr[seg], a.cptr[seg + 1], a.no_wave_sum != 0);
     constexpr int STRIDE = (kBlock / 64) * WS;
     int t = wv * WS + ws;
     for (; t + 3 * STRIDE < cu.count; t += 4 * STRIDE) {
@@ -765,6 +773,13 @@ hipError_t bwd_dispatch(const BwdArgs &a, hipStream_t s) {
     if (a.rho_hi > a.rho_lo) nblk = (a.rho_hi - 1) / SLOTS - a.rho_lo / SLOTS + 1;
     BwdArgs a2 = a;
     a2.xcd_chunk = a.xcd_chunk > 0 ? (nblk + 7) / 8 : 0;      // blocks per XCD
+    if (a.xlist) {
+        // band-affine placement: kXcds interleaved lists, workgroup b takes SLOTS ranges of list b % 8
+        int longest = 0;
+        for (int x = 0; x < kXcds; ++x) longest = a.xlen[x] > longest ? a.xlen[x] : longest;
+        nblk = kXcds * ((longest + SLOTS - 1) / SLOTS);
+        a2.xcd_chunk = 0;
+    }
     dim3 g((unsigned)((a2.xcd_chunk > 0 ? a2.xcd_chunk * 8 : nblk) + a.hot_blocks)), b(kBlock);
     // the pipelined kernel needs P to fit a 32-bit buffer view (< 4 GiB per batch); for k > 64 (J > 1)
     // its register footprint spills, so those sizes take the plain walk

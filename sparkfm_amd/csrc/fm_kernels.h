@@ -6,6 +6,8 @@
 namespace fmhip {
 
 constexpr int kRangeLen = 64;      // == FMHIP_RANGE_LEN
+constexpr int kXcds = 8;           // L2 domains of an MI355X (workgroups are dispatched round-robin over them)
+constexpr int kRowBands = 16;      // row bands of the band-affine placement: two per XCD, 2 MB of P each at 250k-row batches of Kp = 32
 constexpr int kExtend = 16;        // a slot finishes a column that ends this close behind its range
 constexpr int kPartPad = 4;        // partial row = Kp floats + {sum e*x, sum e*x^2, pad, pad}
 constexpr int kScalars = 8;        // packed-gradient tail: {sum e, sum e^2, rows, nonfinite, ...}
@@ -130,6 +132,14 @@ struct BwdArgs {
     int32_t n_ranges;
     int32_t rho_lo, rho_hi;    // ranges this launch walks (whole batch: 0, n_ranges)
     int32_t xcd_chunk;         // > 0: XCD-aware workgroup placement (set by the launcher)
+    // Band-affine placement (whole-batch launches only; xlist != NULL): workgroup b — dispatched round-robin, so on XCD
+    // b % 8 — walks the ranges xlist[xoff[b % 8] + (b / 8) * SLOTS + slot] (none past xlen[b % 8]).  A range that lies inside
+    // one long column covers a narrow band of rows (a column's entries ascend by row): the plan gives XCD x the ranges of
+    // ITS row bands first, so their P rows — 2 MB per band — stay in that XCD's L2 instead of coming from the Infinity
+    // Cache, the latency that bounds the gather rate.  Wave sums are off in such a launch (no_wave_sum also tells k_fixup).
+    const int32_t *xlist;
+    int32_t xoff[kXcds], xlen[kXcds];
+    int32_t no_wave_sum;
     int32_t n_split;
     int32_t n_split_short;
     const float *P;            // [rows][Kp]

@@ -132,6 +132,47 @@ void parallel_chunks(int64_t n, int threads, F f) {
     for (auto &th : pool) th.join();
 }
 
+// Band-affine placement of one batch's ranges (BwdArgs::xlist).  first/last: the rows of the first and last entry of every
+// range.  A range that lies inside ONE column and spans at most a band and a half of rows is "affine" to the band of its
+// middle row; XCD x owns bands 2x and 2x + 1 (kRowBands = 2 * kXcds) and its list starts with their ranges, band by band,
+// so that one band's slice of P (rows / 16 x 4 Kp bytes: 2 MB at 250k rows of Kp = 32) is what that XCD's L2 holds while
+// they are walked; every other range is "free" and fills the lists up to equal length.  Returns the affine count.
+int32_t plan_bands(const HostBatch &hb, int32_t cnnz, int64_t rows, const std::vector<int32_t> &first, const std::vector<int32_t> &last,
+                   std::vector<int32_t> (&lists)[kXcds]) {
+    const int32_t n_ranges = (int32_t)hb.range_seg.size();
+    const int64_t band_rows = std::max<int64_t>((rows + kRowBands - 1) / kRowBands, 1);
+    std::vector<int32_t> by_band[kRowBands], free_ranges;
+    for (int32_t rho = 0; rho < n_ranges; ++rho) {
+        const int32_t beg = rho * kRangeLen, end = std::min(beg + kRangeLen, cnnz);
+        const int32_t seg = hb.range_seg[(size_t)rho];
+        const bool one_column = hb.cptr[(size_t)seg] <= beg && hb.cptr[(size_t)seg + 1] >= end;
+        const int64_t span = (int64_t)last[(size_t)rho] - first[(size_t)rho];
+        if (one_column && end - beg == kRangeLen && span >= 0 && span * 2 <= band_rows * 3) {
+            const int64_t band = std::min<int64_t>(((int64_t)first[(size_t)rho] + last[(size_t)rho]) / 2 / band_rows, kRowBands - 1);
+            by_band[band].push_back(rho);
+        } else {
+            free_ranges.push_back(rho);
+        }
+    }
+    int32_t affine = 0;
+    for (int x = 0; x < kXcds; ++x) {
+        lists[x].clear();
+        for (int b = 0; b < kRowBands / kXcds; ++b) {
+            const auto &v = by_band[x * (kRowBands / kXcds) + b];
+            lists[x].insert(lists[x].end(), v.begin(), v.end());
+            affine += (int32_t)v.size();
+        }
+    }
+    // the free ranges top the lists up, shortest list first (they end up within one range of each other unless the bands
+    // themselves are lopsided)
+    size_t next = 0;
+    const size_t target = ((size_t)n_ranges + kXcds - 1) / kXcds;
+    for (int x = 0; x < kXcds && next < free_ranges.size(); ++x)
+        while (lists[x].size() < target && next < free_ranges.size()) lists[x].push_back(free_ranges[next++]);
+    for (int x = 0; next < free_ranges.size(); x = (x + 1) % kXcds) lists[x].push_back(free_ranges[next++]);
+    return affine;
+}
+
 // scoring = true: rows + labels only (FMModel.predict / Model.computeRMSE on held-out data,
 // S/driver.scala:100-112) — no transposes, no hot block, nothing a training step needs
 // hot_opt: -1 = the process-wide defaults (fmhip_tune keys 5, 12), 0 = no hot block, n >= 1 = up to n pages of it;
@@ -495,7 +536,8 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
         d->rb_rows = rb_bits > 0 ? rb_rows : 0;
         const int32_t rb_div = d->rb_rows > 0 ? (int32_t)std::min<int64_t>(d->rb_rows, INT32_MAX) : INT32_MAX;
         std::vector<int32_t> cnt((size_t)dim + 2, 0), base((size_t)dim + 2, 0);
-        DevBuf<int32_t> keys_a, keys_b, rowid, starts, feats, count;
+        DevBuf<int32_t> keys_a, keys_b, rowid, starts, feats, count, rr_first, rr_last;
+        std::vector<int32_t> h_first, h_last, xlist_all;
         DevBuf<uint32_t> idx_a, idx_b;
         DevBuf<uint8_t> flags, tmp;
         CscScratch sc;
@@ -546,6 +588,35 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
                 return fail(FMHIP_ERR_HIP, "device transpose of batch %lld failed: %s", (long long)b, hipGetErrorString(he));
             }
             finish_batch_meta(hb, bm.cnnz, cnt, base);
+            // band-affine placement of the ranges (large batches of feature-sorted transposes only)
+            if (d->rb_rows == 0 && hb.range_seg.size() >= 4096) {
+                const int32_t nr = (int32_t)hb.range_seg.size();
+                if ((size_t)nr > rr_first.n && ((rc = rr_first.alloc((size_t)nr)) || (rc = rr_last.alloc((size_t)nr)))) {
+                    delete d;
+                    return rc;
+                }
+                h_first.resize((size_t)nr);
+                h_last.resize((size_t)nr);
+                he = csc_range_rows(nullptr, d->crow.p + bm.nnz0, bm.cnnz, kRangeLen, nr, rr_first.p, rr_last.p);
+                if (he == hipSuccess) he = hipMemcpy(h_first.data(), rr_first.p, (size_t)nr * sizeof(int32_t), hipMemcpyDeviceToHost);
+                if (he == hipSuccess) he = hipMemcpy(h_last.data(), rr_last.p, (size_t)nr * sizeof(int32_t), hipMemcpyDeviceToHost);
+                if (he != hipSuccess) {
+                    delete d;
+                    return fail(FMHIP_ERR_HIP, "range rows of batch %lld: %s", (long long)b, hipGetErrorString(he));
+                }
+                std::vector<int32_t> lists[kXcds];
+                BatchMeta &bmw = d->batches[(size_t)b];
+                bmw.x_affine = plan_bands(hb, bm.cnnz, bm.rows, h_first, h_last, lists);
+                for (int x = 0; x < kXcds; ++x) {
+                    bmw.xoff[x] = (int64_t)xlist_all.size();
+                    bmw.xlen[x] = (int32_t)lists[x].size();
+                    xlist_all.insert(xlist_all.end(), lists[x].begin(), lists[x].end());
+                }
+            }
+        }
+        if ((rc = upload(d->xlist, xlist_all.data(), xlist_all.size()))) {
+            delete d;
+            return rc;
         }
     }
     pt.lap("device transposes + metadata");

@@ -77,6 +77,11 @@ struct BatchMeta {
     int64_t nnz_total = 0;  // stored nonzeros of the batch incl. those held in the dense hot block
     unsigned __int128 hot_mask = 0;  // hot slots (all pages: up to 128) with at least one nonzero in this batch
     int64_t own_off = -1;   // offset (in words) of the batch's bitmap of fixup-owned features, -1 = none
+    // band-affine placement of the backward's ranges (fmhip_dataset.hip: plan_bands): per XCD a list of range ids, the
+    // ranges of its own row bands first; xoff[x] = offset of list x in fmhip_dataset::xlist, -1 = no plan for this batch
+    int64_t xoff[fmhip::kXcds] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    int32_t xlen[fmhip::kXcds] = {};
+    int32_t x_affine = 0;   // ranges that were placed by their band (the rest fill the lists evenly)
 };
 
 // Where a backward delivers its gradient rows when NOT into the model's packed buffer: the touched-rows exchange
@@ -115,6 +120,7 @@ struct fmhip_dataset {
     // columns, hot block) — the merged finish lets those update themselves and skips them in its dense pass
     DevBuf<uint32_t> own_bits;
     int64_t own_words = 0;       // words per batch
+    DevBuf<int32_t> xlist;       // band-affine range lists of all batches (BatchMeta::xoff)
     std::vector<int32_t> h_cfeat, h_cptr, h_split, h_split_short;   // host copies (feature-chunked backward needs them)
     int64_t rb_rows = 0;       // rows per row block of the transposes (0 = not row-blocked)
     int32_t max_pieces = 0;

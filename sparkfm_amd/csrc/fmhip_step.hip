@@ -151,7 +151,7 @@ BwdArgs bwd_args(fmhip_model_t m, fmhip_dataset_t d, int64_t b) {
     a.n_ranges = bm.n_ranges;
     a.rho_lo = 0;
     a.rho_hi = bm.n_ranges;
-    a.xcd_chunk = m->tv(kTuneXcd) > 0 ? 1 : 0;
+    a.xcd_chunk = m->tv(kTuneXcd) == 1 ? 1 : 0;
     a.pipelined = m->tv(kTuneBwd);
     a.n_split = bm.n_split;
     a.P = m->P.p;
@@ -239,6 +239,13 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
     if (d->rb_rows > 0 && !whole)
         return fail(FMHIP_ERR_UNSUPPORTED, "feature-interval backward is not available on a row-blocked dataset");
     if (whole) {   // the common case needs no host-side searches
+        if (m->tv(kTuneXcd) == 2 && bm.xoff[0] >= 0 && d->rb_rows == 0) {
+            // band-affine placement (tuning key 4 = 2): XCD x walks the ranges of its own row bands first (BwdArgs::xlist)
+            ba.xlist = d->xlist.p;
+            for (int x = 0; x < kXcds; ++x) { ba.xoff[x] = (int32_t)bm.xoff[x]; ba.xlen[x] = bm.xlen[x]; }
+            ba.no_wave_sum = 1;
+            ba.xcd_chunk = 0;
+        }
         if (finish) {
             ba.red_bsum = m->bsum.p;
             ba.red_nblocks = m->fwd_parts;

@@ -422,6 +422,49 @@ def test_dense_hot_block_chunked_backward(fmhip):
     fm.close()
 
 
+@pytest.mark.parametrize("k,hot", [(32, 1), (32, 0), (64, 1), (16, 1)])
+def test_band_affine_placement_of_the_backward(fmhip, request, k, hot):
+    """fmhip_model_tune(m, 4, 2): the whole-batch backward takes its ranges from per-XCD lists — the ranges of long columns
+    that fall into an XCD's own row bands first (fmhip_dataset.hip: plan_bands) — and forms no wave sums.  Which slot walks a
+    range changes nothing about what the range contributes: the gradient must agree with the default placement (to the
+    summation order of the cut columns' partials) and with the oracle, run to run bit-identical, and training must track
+    the oracle.  Batches of ~400k transposed entries (6,000 ranges: the plan exists from 4,096 on), Zipf ids so that some
+    columns span hundreds of ranges, with and without the dense hot block."""
+    from sparkfm_amd import _ffi, synth
+    L = _ffi.load()
+    L.fmhip_tune(5, hot)
+    request.addfinalizer(lambda: L.fmhip_tune(5, 1))
+    d = synth.make_zipf(4100 + k, 40_000, 3000, 10, 30, zipf_s=1.05)
+    rng = np.random.default_rng(k)
+    a = dict(n1=3000, k=k, row_ptr=d["row_ptr"], col=d["col"], val=d["val"].astype(np.float64), y=d["y"].astype(np.float64),
+             w0=0.1, w=rng.normal(0, 0.05, 3000), v=rng.normal(0, 0.05, (k, 3000)))
+    br = 20_000
+    ds, fm = make(fmhip, a, batch_rows=br)
+    grads = {}
+    for mode in (0, 2, 2):
+        _ffi.check(L.fmhip_model_tune(fm.handle, 4, mode))
+        grads.setdefault(mode, []).append(fm.batchGradient(ds, 1))
+    (gv0, gw0, g00, st0), = grads[0]
+    (gv2, gw2, g02, st2), (gv2b, gw2b, _, _) = grads[2]
+    np.testing.assert_array_equal(gv2, gv2b)                      # deterministic
+    np.testing.assert_array_equal(gw2, gw2b)
+    assert st0["nnz"] == st2["nnz"] and g00 == g02
+    ogv, ogw, og0, osse, _ = oracle.batch_grad(a["w0"], a["w"], a["v"], br, 2 * br, a["row_ptr"], a["col"], a["val"], a["y"], threads=8)
+    check_grad(gv2, gw2, ogv, ogw, np.abs(a["v"]).max())
+    check_grad(gv2, gw2, gv0, gw0, np.abs(a["v"]).max())
+    # training with the placement on: the fused step (merged finish / rows-only update) must take it too
+    eta, regs = 0.02, (0.0, 1e-3, 1e-3)
+    sgd = fmhip.HipSGD(eta=eta, reg0=regs[0], regw=regs[1], regv=regs[2])
+    w0, w, v = a["w0"], a["w"], a["v"]
+    for _ in range(2):
+        fm = sgd.learn(fm, ds)
+        w0, w, v, sse = oracle.sgd_epoch(w0, w, v, br, a["row_ptr"], a["col"], a["val"], a["y"], eta, *regs, threads=8)
+        assert sgd.last_stats["sse"] == pytest.approx(sse, rel=1e-5)
+    assert np.linalg.norm(fm.v - v) <= 1e-4 * np.linalg.norm(v) and np.linalg.norm(fm.w - w) <= 1e-4 * np.linalg.norm(w)
+    ds.unpersist()
+    fm.close()
+
+
 def test_transpose_is_bit_exact(fmhip):
     """The device-resident per-batch transposes (S/DataSet.scala:31-38) against the oracle's:
     feature ids, row ids and values must match exactly (index gathers are bit-exact)."""
