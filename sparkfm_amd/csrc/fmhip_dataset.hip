@@ -134,22 +134,29 @@ void parallel_chunks(int64_t n, int threads, F f) {
 
 // Band-affine placement of one batch's ranges (BwdArgs::xlist).  first/last: the rows of the first and last entry of every
 // range.  A range that lies inside ONE column and spans at most a band and a half of rows is "affine" to the band of its
-// middle row; XCD x owns bands 2x and 2x + 1 (kRowBands = 2 * kXcds) and its list starts with their ranges, band by band,
+// middle row; XCD x owns bands 2x and 2x + 1 (kRowBands = 2 * kXcds by default) and its list starts with their ranges, band by band,
 // so that one band's slice of P (rows / 16 x 4 Kp bytes: 2 MB at 250k rows of Kp = 32) is what that XCD's L2 holds while
 // they are walked; every other range is "free" and fills the lists up to equal length.  Returns the affine count.
 int32_t plan_bands(const HostBatch &hb, int32_t cnnz, int64_t rows, const std::vector<int32_t> &first, const std::vector<int32_t> &last,
                    std::vector<int32_t> (&lists)[kXcds]) {
     const int32_t n_ranges = (int32_t)hb.range_seg.size();
-    const int64_t band_rows = std::max<int64_t>((rows + kRowBands - 1) / kRowBands, 1);
-    std::vector<int32_t> by_band[kRowBands], free_ranges;
+    int n_bands = kRowBands;
+    if (const char *ev = getenv("FMHIP_ROW_BANDS")) {           // measurement knob: a multiple of kXcds, at most 8 per XCD
+        const int v = atoi(ev);
+        if (v >= kXcds && v <= 8 * kXcds && v % kXcds == 0) n_bands = v;
+    }
+    const int per_xcd = n_bands / kXcds;
+    const int64_t band_rows = std::max<int64_t>((rows + n_bands - 1) / n_bands, 1);
+    std::vector<std::vector<int32_t>> by_band((size_t)n_bands);
+    std::vector<int32_t> free_ranges;
     for (int32_t rho = 0; rho < n_ranges; ++rho) {
         const int32_t beg = rho * kRangeLen, end = std::min(beg + kRangeLen, cnnz);
         const int32_t seg = hb.range_seg[(size_t)rho];
         const bool one_column = hb.cptr[(size_t)seg] <= beg && hb.cptr[(size_t)seg + 1] >= end;
         const int64_t span = (int64_t)last[(size_t)rho] - first[(size_t)rho];
         if (one_column && end - beg == kRangeLen && span >= 0 && span * 2 <= band_rows * 3) {
-            const int64_t band = std::min<int64_t>(((int64_t)first[(size_t)rho] + last[(size_t)rho]) / 2 / band_rows, kRowBands - 1);
-            by_band[band].push_back(rho);
+            const int64_t band = std::min<int64_t>(((int64_t)first[(size_t)rho] + last[(size_t)rho]) / 2 / band_rows, n_bands - 1);
+            by_band[(size_t)band].push_back(rho);
         } else {
             free_ranges.push_back(rho);
         }
@@ -157,19 +164,24 @@ int32_t plan_bands(const HostBatch &hb, int32_t cnnz, int64_t rows, const std::v
     int32_t affine = 0;
     for (int x = 0; x < kXcds; ++x) {
         lists[x].clear();
-        for (int b = 0; b < kRowBands / kXcds; ++b) {
-            const auto &v = by_band[x * (kRowBands / kXcds) + b];
+        for (int b = 0; b < per_xcd; ++b) {
+            const auto &v = by_band[(size_t)(x * per_xcd + b)];
             lists[x].insert(lists[x].end(), v.begin(), v.end());
             affine += (int32_t)v.size();
         }
     }
-    // the free ranges top the lists up, shortest list first (they end up within one range of each other unless the bands
-    // themselves are lopsided)
-    size_t next = 0;
-    const size_t target = ((size_t)n_ranges + kXcds - 1) / kXcds;
-    for (int x = 0; x < kXcds && next < free_ranges.size(); ++x)
-        while (lists[x].size() < target && next < free_ranges.size()) lists[x].push_back(free_ranges[next++]);
-    for (int x = 0; next < free_ranges.size(); x = (x + 1) % kXcds) lists[x].push_back(free_ranges[next++]);
+    // The free ranges follow in blocks of 32 consecutive ranges, each block to the list that is shortest so far: close to the
+    // round-robin of the default placement — every XCD gets hot (few columns per range) and cold (a flush per entry)
+    // stretches of the stream alike; handing each XCD one contiguous eighth instead left the XCD with the coldest
+    // features far behind the others (C4: backward 203 -> 268 us) — and the lists end within a block of each other.
+    constexpr size_t kBlockRanges = 32;
+    for (size_t next = 0; next < free_ranges.size(); next += kBlockRanges) {
+        int best = 0;
+        for (int x = 1; x < kXcds; ++x)
+            if (lists[x].size() < lists[best].size()) best = x;
+        const size_t hi = std::min(next + kBlockRanges, free_ranges.size());
+        lists[best].insert(lists[best].end(), free_ranges.begin() + (std::ptrdiff_t)next, free_ranges.begin() + (std::ptrdiff_t)hi);
+    }
     return affine;
 }
 
