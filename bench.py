@@ -947,6 +947,9 @@ def main():
                                            "features_backward": len(lay["hot_ids_all"]),
                                            "share_of_nonzeros_left_to_the_forward": lay["nnz_sparse"] / max(int(d["row_ptr"][-1]), 1),
                                            "share_of_nonzeros_left_to_the_backward": lay["nnz_sparse_backward"] / max(int(d["row_ptr"][-1]), 1)},
+                       "backward_band_plan": {"ranges": lay["ranges"], "planned": lay["planned_ranges"], "band_affine": lay["band_affine_ranges"],
+                                              "share_band_affine": lay["band_affine_ranges"] / max(lay["ranges"], 1),
+                                              "note": "ranges of long columns walked on the XCD that owns their row band (fmhip_tune key 4)"},
                        "parallelism": "dp%d" % world, "exchange": exchange,
                        "transport": ("host-staged gloo over fmhip_comm_create_external, all ranks on GPU 0 (a rehearsal of the N-rank flow, "
                                      "not a measurement)" if args.transport == "host" and use_dp else ("RCCL" if use_dp else "none")),

@@ -31,7 +31,7 @@ SYMBOLS = (
     "fmhip_dp_step", "fmhip_dp_epoch", "fmhip_comm_profile_begin", "fmhip_comm_profile_end", "fmhip_shard_rows", "fmhip_comm_emulate",
     "fmhip_feature_counts", "fmhip_rank_from_counts", "fmhip_relabel_columns", "fmhip_dataset_hot_pages",
     "fmhip_comm_create_external", "fmhip_stream_wait", "fmhip_device_read", "fmhip_device_write",
-    "fmhip_dp_exchange", "fmhip_dp_exchange_info", "fmhip_comm_emulate_ranks", "fmhip_model_tune",
+    "fmhip_dp_exchange", "fmhip_dp_exchange_info", "fmhip_comm_emulate_ranks", "fmhip_model_tune", "fmhip_dataset_band_plan",
 )
 UNIQUE_ID_BYTES = 128
 
@@ -164,6 +164,7 @@ def load():
     L.fmhip_device_read.argtypes = [vp, vp, C.c_size_t, vp]
     L.fmhip_device_write.argtypes = [vp, vp, C.c_size_t, vp]
     L.fmhip_dataset_hot_pages.argtypes = [vp, P(C.c_int32), P(C.c_int32), vp, P(i64)]
+    L.fmhip_dataset_band_plan.argtypes = [vp, P(i64), P(i64), P(i64)]
     L.fmhip_feature_counts.argtypes = [i64, vp, i64, vp]
     L.fmhip_rank_from_counts.argtypes = [i64, vp, vp, vp]
     L.fmhip_relabel_columns.argtypes = [i64, vp, i64, vp, vp]

@@ -134,13 +134,16 @@ void parallel_chunks(int64_t n, int threads, F f) {
 
 // Band-affine placement of one batch's ranges (BwdArgs::xlist).  first/last: the rows of the first and last entry of every
 // range.  A range that lies inside ONE column and spans at most a band and a half of rows is "affine" to the band of its
-// middle row; XCD x owns bands 2x and 2x + 1 (kRowBands = 2 * kXcds by default) and its list starts with their ranges, band by band,
+// middle row; XCD x owns a run of consecutive bands (two at 250k-row batches) and its list starts with their ranges, band by band,
 // so that one band's slice of P (rows / 16 x 4 Kp bytes: 2 MB at 250k rows of Kp = 32) is what that XCD's L2 holds while
 // they are walked; every other range is "free" and fills the lists up to equal length.  Returns the affine count.
 int32_t plan_bands(const HostBatch &hb, int32_t cnnz, int64_t rows, const std::vector<int32_t> &first, const std::vector<int32_t> &last,
                    std::vector<int32_t> (&lists)[kXcds]) {
     const int32_t n_ranges = (int32_t)hb.range_seg.size();
-    int n_bands = kRowBands;
+    // bands of about 16k rows (2 MB of P at Kp = 32, 4 MB at Kp = 64: C3 and C5's width measured the same with 16 and 32
+    // bands of 250k rows), a multiple of the XCD count, at most 8 per XCD
+    int n_bands = (int)std::min<int64_t>(((rows + 16383) / 16384 + kXcds - 1) / kXcds * kXcds, 8 * kXcds);
+    n_bands = std::max(n_bands, kRowBands);
     if (const char *ev = getenv("FMHIP_ROW_BANDS")) {           // measurement knob: a multiple of kXcds, at most 8 per XCD
         const int v = atoi(ev);
         if (v >= kXcds && v <= 8 * kXcds && v % kXcds == 0) n_bands = v;
@@ -855,6 +858,19 @@ int fmhip_dataset_hot_pages(fmhip_dataset_t d, int32_t *n_pages, int32_t *n_ids,
     if (n_pages) *n_pages = d->hot_pages;
     if (n_ids) *n_ids = n;
     if (nnz_sparse_backward) *nnz_sparse_backward = d->scoring_only ? 0 : d->nnz_sparse_bwd;
+    return FMHIP_OK;
+}
+
+int fmhip_dataset_band_plan(fmhip_dataset_t d, int64_t *n_ranges, int64_t *planned_ranges, int64_t *band_affine_ranges) {
+    if (!d) return fail(FMHIP_ERR_INVALID, "dataset is NULL");
+    int64_t all = 0, planned = 0, affine = 0;
+    for (const auto &bm : d->batches) {
+        all += bm.n_ranges;
+        if (bm.xoff[0] >= 0) { planned += bm.n_ranges; affine += bm.x_affine; }
+    }
+    if (n_ranges) *n_ranges = all;
+    if (planned_ranges) *planned_ranges = planned;
+    if (band_affine_ranges) *band_affine_ranges = affine;
     return FMHIP_OK;
 }
 

@@ -167,8 +167,11 @@ class DataSet(Features):
         _ffi.check(_ffi.load().fmhip_dataset_hot_pages(self.handle, C.byref(pages), C.byref(n_all), _ffi.ptr(all_ids), C.byref(spb)))
         # hot_ids: the two-sided page; hot_ids_all: with the gradient-side pages; nnz_sparse(_backward): entries left in the
         # rows the forward walks / in the transposes the backward walks
+        nr, planned, affine = C.c_int64(), C.c_int64(), C.c_int64()
+        _ffi.check(_ffi.load().fmhip_dataset_band_plan(self.handle, C.byref(nr), C.byref(planned), C.byref(affine)))
         return dict(hot_ids=ids[:n.value].tolist(), nnz_sparse=int(sp.value), hot_pages=int(pages.value),
-                    hot_ids_all=all_ids[:n_all.value].tolist(), nnz_sparse_backward=int(spb.value))
+                    hot_ids_all=all_ids[:n_all.value].tolist(), nnz_sparse_backward=int(spb.value),
+                    ranges=int(nr.value), planned_ranges=int(planned.value), band_affine_ranges=int(affine.value))
 
     def transposeInput(self, batch=0):
         """transposeInput (S/DataSet.scala:48, :31-38) of one mini-batch, read back from the GPU:
