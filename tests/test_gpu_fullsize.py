@@ -108,7 +108,7 @@ def test_c5_two_to_the_24_rows_at_the_real_width(fmhip):
     assert nb == 68 and ds.info()["nnz"] == nnz
 
     def make_model():
-        fm = fmhip.FMModel(n1 - 1, k, seed=7, init_stdev=0.05, init_on_device=True)
+        fm = fmhip.FMModel(n1 - 1, k, seed=7, init_on_device=True)          # the reference's N(0, 0.01) init
         fm.handle
         return fm
 
