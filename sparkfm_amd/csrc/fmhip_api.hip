@@ -225,6 +225,14 @@ int fmhip_model_get_rows(fmhip_model_t m, int64_t n, const int32_t *ids, double 
     for (int64_t j = 0; j < n; ++j)
         if (ids[j] < 0 || ids[j] > m->n) return fail(FMHIP_ERR_SHAPE, "feature id %d outside [0, %lld]", ids[j], (long long)m->n);
     if (n == 0) return FMHIP_OK;
+    if (m->host64_fresh) {   // nothing has trained in fp32 since the masters were written: the exact fp64 values, as get_params
+        for (int64_t j = 0; j < n; ++j) {
+            if (w) w[j] = m->h_w[(size_t)ids[j]];
+            if (v)
+                for (int f = 0; f < m->k; ++f) v[f + j * (int64_t)m->k] = m->h_v[(size_t)f + (size_t)ids[j] * m->k];
+        }
+        return FMHIP_OK;
+    }
     TRY(set_device(m->device));
     DevBuf<int32_t> dids;
     DevBuf<float> dv, dw;

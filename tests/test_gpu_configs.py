@@ -250,6 +250,31 @@ def test_scoring_only_rows_and_the_demo_flow(fmhip, tmp_path):
     test.unpersist()
 
 
+def test_get_rows_serves_the_fp64_masters_while_they_are_fresh(fmhip):
+    """`fm.w(i)` / `fm.v(::, i)` of a few features (fmhip_model_get_rows): right after the parameters were set the exact
+    doubles come back (as fmhip_model_get_params returns them), not their fp32 device copies; once an fp32 step has run,
+    the device values."""
+    from sparkfm_amd import synth
+    d = synth.make_zipf(5, 600, 90, 3, 12, zipf_s=1.05)
+    rng = np.random.default_rng(8)
+    w, v = rng.normal(0, 0.1, 90) + 1e-11, rng.normal(0, 0.1, (8, 90)) + 1e-11      # not representable in fp32
+    ds = fmhip.DataSet.from_arrays(d, batch_rows=300).cache()
+    fm = fmhip.FMModel(89, 8)
+    fm.w0, fm.w, fm.v = 0.25, w, v
+    ids = np.array([3, 0, 89, 3, 41], np.int32)
+    fm.handle
+    w_r, v_r = fm.rows(ids)
+    np.testing.assert_array_equal(w_r, w[ids])
+    np.testing.assert_array_equal(v_r, v[:, ids])
+    fmhip.HipSGD(eta=0.01).learn(fm, ds)
+    w_r, v_r = fm.rows(ids)
+    np.testing.assert_array_equal(w_r, fm.w[ids])
+    np.testing.assert_array_equal(v_r, fm.v[:, ids])
+    assert (w_r.astype(np.float32) == w_r).all() and not np.array_equal(v_r, v[:, ids])
+    ds.unpersist()
+    fm.close()
+
+
 def test_device_side_init(fmhip):
     """fmhip_model_init_normal: `new FMModel` drawn on the GPU — N(mean, stdev) moments, w = w0 = 0,
     reproducible per seed, padding untouched (k=20 -> 32 floats per row)."""
