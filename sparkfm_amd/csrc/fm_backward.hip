@@ -345,9 +345,11 @@ struct RangeWalk {
         // stream that is a few whole row blocks, whose slice of P then lives in that XCD's L2 only.
         if (a.xlist) {
             // band-affine placement: this workgroup's ranges come from the list of the XCD it runs on (see BwdArgs::xlist)
-            const int x = bx & (kXcds - 1), j = (bx >> 3) * SLOTS + (int)(threadIdx.x / LPN);
-            if (j >= a.xlen[x]) return false;
-            rho = a.xlist[a.xoff[x] + j];
+            const int x = bx & (kXcds - 1);
+            int j = (bx >> 3) * SLOTS + (int)(threadIdx.x / LPN), sg = 0;
+            while (sg < kXSegs && j >= a.xseg_len[x][sg]) j -= a.xseg_len[x][sg++];
+            if (sg == kXSegs) return false;
+            rho = a.xlist[a.xseg_off[x][sg] + j];
         } else {
             const int blk = a.xcd_chunk > 0 ? (bx & 7) * a.xcd_chunk + (bx >> 3) : bx;
             rho = (a.rho_lo / SLOTS + blk) * SLOTS + threadIdx.x / LPN;
@@ -776,7 +778,11 @@ hipError_t bwd_dispatch(const BwdArgs &a, hipStream_t s) {
     if (a.xlist) {
         // band-affine placement: kXcds interleaved lists, workgroup b takes SLOTS ranges of list b % 8
         int longest = 0;
-        for (int x = 0; x < kXcds; ++x) longest = a.xlen[x] > longest ? a.xlen[x] : longest;
+        for (int x = 0; x < kXcds; ++x) {
+            int len = 0;
+            for (int sg = 0; sg < kXSegs; ++sg) len += a.xseg_len[x][sg];
+            longest = len > longest ? len : longest;
+        }
         nblk = kXcds * ((longest + SLOTS - 1) / SLOTS);
         a2.xcd_chunk = 0;
     }

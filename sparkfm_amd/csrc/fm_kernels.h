@@ -7,6 +7,7 @@ namespace fmhip {
 
 constexpr int kRangeLen = 64;      // == FMHIP_RANGE_LEN
 constexpr int kXcds = 8;           // L2 domains of an MI355X (workgroups are dispatched round-robin over them)
+constexpr int kXSegs = 9;          // runs of one XCD's range list: up to 8 row bands + the share of the unplaced ranges
 constexpr int kRowBands = 16;      // row bands of the band-affine placement: two per XCD, 2 MB of P each at 250k-row batches of Kp = 32
 constexpr int kExtend = 16;        // a slot finishes a column that ends this close behind its range
 constexpr int kPartPad = 4;        // partial row = Kp floats + {sum e*x, sum e*x^2, pad, pad}
@@ -132,13 +133,15 @@ struct BwdArgs {
     int32_t n_ranges;
     int32_t rho_lo, rho_hi;    // ranges this launch walks (whole batch: 0, n_ranges)
     int32_t xcd_chunk;         // > 0: XCD-aware workgroup placement (set by the launcher)
-    // Band-affine placement (whole-batch launches only; xlist != NULL): workgroup b — dispatched round-robin, so on XCD
-    // b % 8 — walks the ranges xlist[xoff[b % 8] + (b / 8) * SLOTS + slot] (none past xlen[b % 8]).  A range that lies inside
-    // one long column covers a narrow band of rows (a column's entries ascend by row): the plan gives XCD x the ranges of
-    // ITS row bands first, so their P rows — 2 MB per band — stay in that XCD's L2 instead of coming from the Infinity
-    // Cache, the latency that bounds the gather rate.  Wave sums are off in such a launch (no_wave_sum also tells k_fixup).
+    // Band-affine placement (xlist != NULL): workgroup b — dispatched round-robin, so on XCD b % 8 — walks the ranges at
+    // positions (b / 8) * SLOTS + slot of XCD b % 8's list, which is the concatenation of up to kXSegs runs of xlist
+    // (xseg_off / xseg_len: one run per row band the XCD owns, then its share of the other ranges; a feature-interval
+    // launch passes the sub-runs that fall into its range window).  A range that lies inside one long column covers a
+    // narrow band of rows (a column's entries ascend by row): the plan gives XCD x the ranges of ITS row bands first, so
+    // their P rows — 2 MB per band — stay in that XCD's L2 instead of coming from the Infinity Cache, the latency that
+    // bounds the gather rate.  Wave sums are off in such a launch (no_wave_sum also tells k_fixup).
     const int32_t *xlist;
-    int32_t xoff[kXcds], xlen[kXcds];
+    int32_t xseg_off[kXcds][kXSegs], xseg_len[kXcds][kXSegs];
     int32_t no_wave_sum;
     int32_t n_split;
     int32_t n_split_short;

@@ -138,15 +138,15 @@ void parallel_chunks(int64_t n, int threads, F f) {
 // so that one band's slice of P (rows / 16 x 4 Kp bytes: 2 MB at 250k rows of Kp = 32) is what that XCD's L2 holds while
 // they are walked; every other range is "free" and fills the lists up to equal length.  Returns the affine count.
 int32_t plan_bands(const HostBatch &hb, int32_t cnnz, int64_t rows, const std::vector<int32_t> &first, const std::vector<int32_t> &last,
-                   std::vector<int32_t> (&lists)[kXcds]) {
+                   std::vector<int32_t> (&lists)[kXcds], int32_t (&seg)[kXcds][kXSegs + 1]) {
     const int32_t n_ranges = (int32_t)hb.range_seg.size();
     // bands of about 16k rows (2 MB of P at Kp = 32, 4 MB at Kp = 64: C3 and C5's width measured the same with 16 and 32
     // bands of 250k rows), a multiple of the XCD count, at most 8 per XCD
-    int n_bands = (int)std::min<int64_t>(((rows + 16383) / 16384 + kXcds - 1) / kXcds * kXcds, 8 * kXcds);
+    int n_bands = (int)std::min<int64_t>(((rows + 16383) / 16384 + kXcds - 1) / kXcds * kXcds, (kXSegs - 1) * kXcds);
     n_bands = std::max(n_bands, kRowBands);
     if (const char *ev = getenv("FMHIP_ROW_BANDS")) {           // measurement knob: a multiple of kXcds, at most 8 per XCD
         const int v = atoi(ev);
-        if (v >= kXcds && v <= 8 * kXcds && v % kXcds == 0) n_bands = v;
+        if (v >= kXcds && v <= (kXSegs - 1) * kXcds && v % kXcds == 0) n_bands = v;
     }
     const int per_xcd = n_bands / kXcds;
     const int64_t band_rows = std::max<int64_t>((rows + n_bands - 1) / n_bands, 1);
@@ -167,11 +167,14 @@ int32_t plan_bands(const HostBatch &hb, int32_t cnnz, int64_t rows, const std::v
     int32_t affine = 0;
     for (int x = 0; x < kXcds; ++x) {
         lists[x].clear();
-        for (int b = 0; b < per_xcd; ++b) {
+        for (int b = 0; b < kXSegs - 1; ++b) {                     // one run per band (runs of bands the XCD does not have: empty)
+            seg[x][b] = (int32_t)lists[x].size();
+            if (b >= per_xcd) continue;
             const auto &v = by_band[(size_t)(x * per_xcd + b)];
             lists[x].insert(lists[x].end(), v.begin(), v.end());
             affine += (int32_t)v.size();
         }
+        seg[x][kXSegs - 1] = (int32_t)lists[x].size();            // the last run: this XCD's share of the other ranges
     }
     // The free ranges follow in blocks of 32 consecutive ranges, each block to the list that is shortest so far: close to the
     // round-robin of the default placement — every XCD gets hot (few columns per range) and cold (a flush per entry)
@@ -185,6 +188,7 @@ int32_t plan_bands(const HostBatch &hb, int32_t cnnz, int64_t rows, const std::v
         const size_t hi = std::min(next + kBlockRanges, free_ranges.size());
         lists[best].insert(lists[best].end(), free_ranges.begin() + (std::ptrdiff_t)next, free_ranges.begin() + (std::ptrdiff_t)hi);
     }
+    for (int x = 0; x < kXcds; ++x) seg[x][kXSegs] = (int32_t)lists[x].size();
     return affine;
 }
 
@@ -621,7 +625,7 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
                 }
                 std::vector<int32_t> lists[kXcds];
                 BatchMeta &bmw = d->batches[(size_t)b];
-                bmw.x_affine = plan_bands(hb, bm.cnnz, bm.rows, h_first, h_last, lists);
+                bmw.x_affine = plan_bands(hb, bm.cnnz, bm.rows, h_first, h_last, lists, bmw.xseg);
                 for (int x = 0; x < kXcds; ++x) {
                     bmw.xoff[x] = (int64_t)xlist_all.size();
                     bmw.xlen[x] = (int32_t)lists[x].size();
@@ -633,6 +637,7 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
             delete d;
             return rc;
         }
+        d->h_xlist.swap(xlist_all);
     }
     pt.lap("device transposes + metadata");
     // bitmap of the features whose gradient rows the fixup launch assembles (cut columns + hot block), per batch:

@@ -81,6 +81,7 @@ struct BatchMeta {
     // ranges of its own row bands first; xoff[x] = offset of list x in fmhip_dataset::xlist, -1 = no plan for this batch
     int64_t xoff[fmhip::kXcds] = {-1, -1, -1, -1, -1, -1, -1, -1};
     int32_t xlen[fmhip::kXcds] = {};
+    int32_t xseg[fmhip::kXcds][fmhip::kXSegs + 1] = {};   // list x = runs [xseg[x][s], xseg[x][s+1]) of ascending range ids (one per band, then the rest)
     int32_t x_affine = 0;   // ranges that were placed by their band (the rest fill the lists evenly)
 };
 
@@ -121,6 +122,7 @@ struct fmhip_dataset {
     DevBuf<uint32_t> own_bits;
     int64_t own_words = 0;       // words per batch
     DevBuf<int32_t> xlist;       // band-affine range lists of all batches (BatchMeta::xoff)
+    std::vector<int32_t> h_xlist;   // host copy (a feature-interval launch searches the runs for its range window)
     std::vector<int32_t> h_cfeat, h_cptr, h_split, h_split_short;   // host copies (feature-chunked backward needs them)
     int64_t rb_rows = 0;       // rows per row block of the transposes (0 = not row-blocked)
     int32_t max_pieces = 0;

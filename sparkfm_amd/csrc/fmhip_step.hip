@@ -238,14 +238,21 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
     if (whole || finish || d->hot_max_id >= feat_lo) hot_attach(m, d, bm, ba);
     if (d->rb_rows > 0 && !whole)
         return fail(FMHIP_ERR_UNSUPPORTED, "feature-interval backward is not available on a row-blocked dataset");
+    // band-affine placement (tuning key 4 = 2): XCD x walks the ranges of its own row bands first (BwdArgs::xlist); the same
+    // choice for every launch of a step — the partials of a cut column are written and read under one rule (no wave sums)
+    const bool banded = m->tv(kTuneXcd) == 2 && bm.xoff[0] >= 0 && d->rb_rows == 0;
+    if (banded) {
+        ba.xlist = d->xlist.p;
+        ba.no_wave_sum = 1;
+        ba.xcd_chunk = 0;
+    }
     if (whole) {   // the common case needs no host-side searches
-        if (m->tv(kTuneXcd) == 2 && bm.xoff[0] >= 0 && d->rb_rows == 0) {
-            // band-affine placement (tuning key 4 = 2): XCD x walks the ranges of its own row bands first (BwdArgs::xlist)
-            ba.xlist = d->xlist.p;
-            for (int x = 0; x < kXcds; ++x) { ba.xoff[x] = (int32_t)bm.xoff[x]; ba.xlen[x] = bm.xlen[x]; }
-            ba.no_wave_sum = 1;
-            ba.xcd_chunk = 0;
-        }
+        if (banded)
+            for (int x = 0; x < kXcds; ++x)
+                for (int sg = 0; sg < kXSegs; ++sg) {
+                    ba.xseg_off[x][sg] = (int32_t)bm.xoff[x] + bm.xseg[x][sg];
+                    ba.xseg_len[x][sg] = bm.xseg[x][sg + 1] - bm.xseg[x][sg];
+                }
         if (finish) {
             ba.red_bsum = m->bsum.p;
             ba.red_nblocks = m->fwd_parts;
@@ -302,6 +309,16 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
     const int32_t e_lo = hp[s_lo], e_hi = hp[s_hi];            // entry interval of the columns
     ba.rho_lo = e_lo / kRangeLen;
     ba.rho_hi = s_hi >= bm.n_cols ? bm.n_ranges : e_hi / kRangeLen;   // the straddling range goes to the next interval
+    if (banded) {
+        // every run of the plan holds ascending range ids: the part of it inside [rho_lo, rho_hi) is one sub-run
+        for (int x = 0; x < kXcds; ++x)
+            for (int sg = 0; sg < kXSegs; ++sg) {
+                const int32_t *r0 = d->h_xlist.data() + bm.xoff[x] + bm.xseg[x][sg], *r1 = d->h_xlist.data() + bm.xoff[x] + bm.xseg[x][sg + 1];
+                const int32_t *lo = std::lower_bound(r0, r1, ba.rho_lo), *hi = std::lower_bound(r0, r1, ba.rho_hi);
+                ba.xseg_off[x][sg] = (int32_t)(lo - d->h_xlist.data());
+                ba.xseg_len[x][sg] = (int32_t)(hi - lo);
+            }
+    }
     const int32_t sp_lo = (int32_t)(std::lower_bound(hs, hs + bm.n_split, s_lo) - hs);
     const int32_t sp_hi = (int32_t)(std::lower_bound(hs, hs + bm.n_split, s_hi) - hs);
     ba.split_seg += sp_lo;

@@ -465,6 +465,48 @@ def test_band_affine_placement_of_the_backward(fmhip, request, k, hot):
     fm.close()
 
 
+def test_band_affine_placement_with_feature_intervals(fmhip):
+    """The feature-interval launches of the data-parallel step take their ranges from the same per-XCD lists — each run
+    of a list cut down to the launch's range window: fmhip_step_forward + fmhip_step_backward over descending intervals
+    must fill the packed gradient exactly like the whole-batch backward (bit for bit: the same partials, the same order),
+    for cuts inside hot columns, at column starts, around empty intervals and with the dense hot block on."""
+    import ctypes as C
+    import torch
+    from sparkfm_amd import _ffi, synth
+    from sparkfm_amd.distributed import HipEngine
+    L = _ffi.load()
+    d = synth.make_zipf(4300, 40_000, 3000, 10, 30, zipf_s=1.05)
+    rng = np.random.default_rng(3)
+    a = dict(n1=3000, k=32, row_ptr=d["row_ptr"], col=d["col"], val=d["val"].astype(np.float64), y=d["y"].astype(np.float64),
+             w0=0.1, w=rng.normal(0, 0.05, 3000), v=rng.normal(0, 0.05, (32, 3000)))
+    ds, fm = make(fmhip, a, batch_rows=20_000, stream=torch_stream())
+    lay = ds.layout()
+    assert lay["planned_ranges"] == lay["ranges"] > 8192 and 0 < lay["band_affine_ranges"] < lay["ranges"]
+    eng = HipEngine(fm, ds)
+    eng.compute(1)
+    torch.cuda.synchronize()
+    want = eng.grad.clone()
+    ogv, ogw, og0, osse, _ = oracle.batch_grad(a["w0"], a["w"], a["v"], 20_000, 40_000, a["row_ptr"], a["col"], a["val"], a["y"], threads=8)
+    gv, gw, _, _ = fm.batchGradient(ds, 1)
+    check_grad(gv, gw, ogv, ogw, np.abs(a["v"]).max())
+    eng.grad.zero_()
+    torch.cuda.synchronize()
+    fm_h = fm.handle
+    _ffi.check(L.fmhip_grad_bind(fm_h, C.c_void_p(eng.grad.data_ptr())))
+    for cuts in ([0, 3000], [0, 70, 3000], [0, 3, 64, 65, 700, 2999, 3000], [0, 1500, 1500, 3000]):
+        eng.forward(1)
+        for i in range(len(cuts) - 1, 0, -1):
+            eng.backward(1, cuts[i - 1], cuts[i], finish=(i == 1))
+        torch.cuda.synchronize()
+        assert torch.equal(eng.grad, want), cuts
+        eng.grad.zero_()
+        torch.cuda.synchronize()
+        _ffi.check(L.fmhip_grad_bind(fm_h, C.c_void_p(eng.grad.data_ptr())))
+    eng.close()
+    ds.unpersist()
+    fm.close()
+
+
 def test_transpose_is_bit_exact(fmhip):
     """The device-resident per-batch transposes (S/DataSet.scala:31-38) against the oracle's:
     feature ids, row ids and values must match exactly (index gathers are bit-exact)."""
