@@ -239,9 +239,10 @@ def test_bench_without_a_launcher_fails_cleanly_when_ranks_cannot_start():
 
 def test_committed_bench_line_keeps_the_contract():
     """The bench line committed under profiles/ (a real MI355X run of `python bench.py`) carries every key of the
-    driver's contract plus the roofline / cpu_baseline objects, with a roofline that cannot exceed 1 against its ceiling."""
+    driver's contract plus the roofline / cpu_baseline objects; the roofline is an HBM-side fraction — counter bytes per
+    launch / launch time / 8 TB/s, measured in that run, <= 1 — with the algorithmic figure flagged beside it."""
     import json
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_c3_n1.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_c3_n1.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -251,14 +252,21 @@ def test_committed_bench_line_keeps_the_contract():
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
-    assert r["bound"] == "hbm" and r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0 < r["frac_of_ceiling"] <= 1.0
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["traffic_measured_in_this_run"] is True
+    assert r["achieved"] == pytest.approx(r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9) and r["frac"] == pytest.approx(r["achieved"] / r["peak"])
+    assert 0 < r["frac"] <= 1.0 and 0 < r["step"]["frac"] <= 1.0 and 0 < r["frac_of_ceiling"] <= 1.0 and r["algorithmic_frac"] > 0
     assert 0 < d["step_roofline"]["frac"] <= 1.0
     for k_ in d["kernels"].values():
         if "frac_of_ceiling" in k_:
             assert 0 < k_["frac_of_ceiling"] <= 1.0
+        if "traffic_frac_of_8TBps" in k_:
+            assert 0 < k_["traffic_frac_of_8TBps"] <= 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "nnz/s" and c["sample"]
-    assert d["sustained"]["seconds"] >= 2.0 and d["extra"]["hbm_resident"]["frac_of_8TBps"] <= 1.0
+    x = d["extra"]
+    assert d["sustained"]["seconds"] >= 2.0 and x["hbm_resident"]["frac_of_8TBps"] <= 1.0 and x["hbm_resident"]["distinct_batches"] >= 24
+    assert x["hbm_resident"]["ids_as_hashed"]["value"] > 0 and x["c4_one_gpu"]["value"] > 0 and len(x["als_long_columns"]) == 3
+    assert d["config"]["backward_band_plan"]["band_affine"] > 0
 
 
 def test_feature_order_utilities_are_host_arithmetic():
