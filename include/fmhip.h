@@ -100,7 +100,7 @@ int fmhip_device_count(int *count);
  *          entries sorted by (row block, feature) so a block's slice of P stays L2-resident in the
  *          backward; features occurring in several blocks are summed by an extra fixup pass
  *   key 4  placement of the backward's workgroups on the eight XCDs (each has its own 4 MiB L2): 2 = band-affine (default):
- *          fmhip_dataset_create plans, per batch of at least 4096 ranges, one range list per XCD that starts with the ranges of
+ *          fmhip_dataset_create plans, per batch of at least 1024 ranges, one range list per XCD that starts with the ranges of
  *          long columns whose rows fall into that XCD's own row bands (a column's entries ascend by row, so such a range
  *          gathers P rows from a 2 MB band that stays in that L2) — the whole-batch backward of feature-sorted transposes
  *          takes its ranges from those lists (C3: backward 164 -> 142 us, C5 width: 183 -> 151 us); 0 = ranges in stream

@@ -608,7 +608,7 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
             }
             finish_batch_meta(hb, bm.cnnz, cnt, base);
             // band-affine placement of the ranges (large batches of feature-sorted transposes only)
-            if (d->rb_rows == 0 && hb.range_seg.size() >= 4096) {
+            if (d->rb_rows == 0 && hb.range_seg.size() >= 1024) {
                 const int32_t nr = (int32_t)hb.range_seg.size();
                 if ((size_t)nr > rr_first.n && ((rc = rr_first.alloc((size_t)nr)) || (rc = rr_last.alloc((size_t)nr)))) {
                     delete d;

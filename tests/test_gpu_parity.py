@@ -428,7 +428,7 @@ def test_band_affine_placement_of_the_backward(fmhip, request, k, hot):
     that fall into an XCD's own row bands first (fmhip_dataset.hip: plan_bands) — and forms no wave sums.  Which slot walks a
     range changes nothing about what the range contributes: the gradient must agree with the default placement (to the
     summation order of the cut columns' partials) and with the oracle, run to run bit-identical, and training must track
-    the oracle.  Batches of ~400k transposed entries (6,000 ranges: the plan exists from 4,096 on), Zipf ids so that some
+    the oracle.  Batches of ~200k transposed entries (3,000 ranges: the plan exists from 1,024 on), Zipf ids so that some
     columns span hundreds of ranges, with and without the dense hot block."""
     from sparkfm_amd import _ffi, synth
     L = _ffi.load()
@@ -440,6 +440,8 @@ def test_band_affine_placement_of_the_backward(fmhip, request, k, hot):
              w0=0.1, w=rng.normal(0, 0.05, 3000), v=rng.normal(0, 0.05, (k, 3000)))
     br = 20_000
     ds, fm = make(fmhip, a, batch_rows=br)
+    lay = ds.layout()
+    assert lay["planned_ranges"] == lay["ranges"] > 2048 and 0 < lay["band_affine_ranges"] < lay["ranges"]
     grads = {}
     for mode in (0, 2, 2):
         _ffi.check(L.fmhip_model_tune(fm.handle, 4, mode))
@@ -481,7 +483,7 @@ def test_band_affine_placement_with_feature_intervals(fmhip):
              w0=0.1, w=rng.normal(0, 0.05, 3000), v=rng.normal(0, 0.05, (32, 3000)))
     ds, fm = make(fmhip, a, batch_rows=20_000, stream=torch_stream())
     lay = ds.layout()
-    assert lay["planned_ranges"] == lay["ranges"] > 8192 and 0 < lay["band_affine_ranges"] < lay["ranges"]
+    assert lay["planned_ranges"] == lay["ranges"] > 2048 and 0 < lay["band_affine_ranges"] < lay["ranges"]
     eng = HipEngine(fm, ds)
     eng.compute(1)
     torch.cuda.synchronize()
