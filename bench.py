@@ -216,7 +216,7 @@ def committed_pmc(config, k, batch_rows):
 STEP_KERNELS = ("k_forward", "k_backward", "k_fixup", "k_apply")
 
 
-def pmc_pass(counters, child_argv, skip=4, timeout_s=300):
+def pmc_pass(counters, child_argv, skip=4, timeout_s=150):
     """One `rocprofv3 --pmc <counters> -- python3 <child_argv>` run (counter collection only: no trace domain beside it) as
     a CHILD process; -> {kernel: {counter: mean per dispatch after the first `skip` dispatches of that kernel}} for the
     kernels of the SGD step, or None when rocprofv3 is not there / fails (the caller falls back to the committed profile).
@@ -657,7 +657,7 @@ def main():
             comm = HostStagedComm(fm, rank, world) if args.transport == "host" else RcclComm(fm, rank, world)
             fixed = None if args.upper_fractions == "auto" else (() if args.upper_fractions == "none" else
                                                                  tuple(float(x) for x in args.upper_fractions.split(",")))
-            dp_mode = args.dp_exchange if args.dp_exchange != "auto" else ("touched" if cfg.get("criteo") else "sharded")
+            dp_mode = args.dp_exchange if args.dp_exchange != "auto" else ("touched" if cfg.get("criteo") else "dense")
             dp = HipDataParallelSGD(comm, eta=args.eta, reg0=regs[0], regw=regs[1], regv=regs[2], exchange=dp_mode,
                                     upper_fractions=fixed if fixed is not None else (0.05, 0.15, 0.3, 0.55))
             dp.plan(fm, ds)
@@ -714,7 +714,7 @@ def main():
         # measure, don't guess: the best cut — and whether the sharded update pays — depends on the collectives' real
         # bandwidth on this node.  Candidates are timed for 4 steps each; the ranks agree through a max-reduce.
         tuning = []
-        modes = ("sharded", "dense") if args.dp_exchange == "auto" else (dp.exchange,)
+        modes = ("dense", "sharded") if args.dp_exchange == "auto" else (dp.exchange,)
         cands = ((0.3,), (0.2,), (0.12, 0.4), (0.08, 0.25, 0.5), (0.05, 0.15, 0.3, 0.55), (0.04, 0.1, 0.2, 0.35, 0.6), ())
         if args.transport == "host":
             cands = ((0.12, 0.4), ())        # a rehearsal of the flow: every step moves the whole gradient through the host
@@ -856,7 +856,7 @@ def main():
             _ffi.check(L.fmhip_dp_step(fm3.handle, ds3.handle, j % nb3, comm.handle, args.eta, regs[0], regs[1], regs[2]))
         keep, keep_mode = dp.upper_fractions, dp.exchange
         best3 = None
-        for mode3 in (("sharded", "dense") if args.dp_exchange == "auto" else (dp.exchange,)):
+        for mode3 in (("dense", "sharded") if args.dp_exchange == "auto" else (dp.exchange,)):
             dp.set_exchange(mode3)
             for cand in ((), (0.3,), (0.12, 0.4), (0.05, 0.15, 0.3, 0.55)):        # a 13.6 MB gradient wants fewer cuts than C4's 136 MB
                 dp.upper_fractions = cand
