@@ -3,6 +3,8 @@
 // and formulas: fm_device.h.
 #include "fm_device.h"
 
+#include <cstdlib>
+
 namespace fmhip {
 namespace {
 
@@ -454,13 +456,13 @@ struct RangeWalk {
 template <int LPN, int J, bool PACKED, bool HOT>
 __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
     constexpr int KP = 4 * LPN * J;
-    if (HOT && (int)blockIdx.x < a.hot_blocks) {
-        hot_backward_body<KP / 16>(a.hot, (int)blockIdx.x, a.hot_blocks);
+    if (HOT && (int)blockIdx.x >= a.hot_first && (int)blockIdx.x < a.hot_first + a.hot_blocks) {
+        hot_backward_body<KP / 16>(a.hot, (int)blockIdx.x - a.hot_first, a.hot_blocks);
         return;
     }
     constexpr int CH = (LPN * J > 16) ? (16 / J) : LPN;  // entries whose P rows are in flight together
     RangeWalk<LPN, J, PACKED> w;
-    if (!w.setup(a, HOT ? (int)blockIdx.x - a.hot_blocks : (int)blockIdx.x)) return;
+    if (!w.setup(a, (HOT && (int)blockIdx.x >= a.hot_first) ? (int)blockIdx.x - a.hot_blocks : (int)blockIdx.x)) return;
     const int l = w.l;
     for (int base = w.p0; base < w.stop; base += LPN) {
         const int p = base + l;
@@ -506,8 +508,8 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
 template <int LPN, int J, bool PACKED, bool HOT>
 __global__ __launch_bounds__(kBlock, (HOT && J == 1 ? FMHIP_BWD_WAVES : 1)) void k_backward_p(BwdArgs a) {
     constexpr int KP = 4 * LPN * J;
-    if (HOT && (int)blockIdx.x < a.hot_blocks) {
-        hot_backward_body<KP / 16>(a.hot, (int)blockIdx.x, a.hot_blocks);
+    if (HOT && (int)blockIdx.x >= a.hot_first && (int)blockIdx.x < a.hot_first + a.hot_blocks) {
+        hot_backward_body<KP / 16>(a.hot, (int)blockIdx.x - a.hot_first, a.hot_blocks);
         return;
     }
 #ifndef FMHIP_BWD_SG
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(kBlock, (HOT && J == 1 ? FMHIP_BWD_WAVES : 1)) void
     constexpr int CHB = (LPN * J > 8) ? ((8 / J) > 0 ? (8 / J) : 1) : LPN;   // entries per gather chunk
     constexpr int NCH = SG * LPN / CHB;                                       // chunks per super-group
     RangeWalk<LPN, J, PACKED> w;
-    if (!w.setup(a, HOT ? (int)blockIdx.x - a.hot_blocks : (int)blockIdx.x)) return;
+    if (!w.setup(a, (HOT && (int)blockIdx.x >= a.hot_first) ? (int)blockIdx.x - a.hot_blocks : (int)blockIdx.x)) return;
     const int l = w.l;
     const __amdgpu_buffer_rsrc_t prs = make_rsrc(a.P, a.p_bytes);
     for (int sbase = w.p0; sbase < w.stop; sbase += SG * LPN) {
@@ -785,6 +787,14 @@ hipError_t bwd_dispatch(const BwdArgs &a, hipStream_t s) {
         }
         nblk = kXcds * ((longest + SLOTS - 1) / SLOTS);
         a2.xcd_chunk = 0;
+    }
+    // Where the block product's workgroups sit in the launch: at the front by default; with the band-affine plan behind the
+    // band-affine part of the lists (FMHIP_HOT_AT = percent of the walkers in front of them; measurement knob) so that their
+    // 100 MB of streams do not pass through the L2s while the bands are meant to stay in them
+    a2.hot_first = 0;
+    if (a.xlist && a.hot_blocks > 0) {
+        static const int hot_at = getenv("FMHIP_HOT_AT") ? atoi(getenv("FMHIP_HOT_AT")) : 0;
+        a2.hot_first = (int)((int64_t)nblk * hot_at / 100) / kXcds * kXcds;
     }
     dim3 g((unsigned)((a2.xcd_chunk > 0 ? a2.xcd_chunk * 8 : nblk) + a.hot_blocks)), b(kBlock);
     // the pipelined kernel needs P to fit a 32-bit buffer view (< 4 GiB per batch); for k > 64 (J > 1)

@@ -176,6 +176,7 @@ struct BwdArgs {
     // partial sums while the others walk the sparse stream; pages * kHotT extra workgroups of k_fixup finish it
     HotArgs hot;
     int32_t hot_blocks;
+    int32_t hot_first;         // block index at which the hot workgroups start (0 = the front of the launch; set by the launcher)
     int32_t pipelined;         // host-side launch choice (the model's tuning key 1): 1 = k_backward_p where it applies
 };
 
