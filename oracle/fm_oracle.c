@@ -418,11 +418,18 @@ void fmo_als_epoch(int k, int64_t num_attribute, double *w0, double *w, double *
         double se = 0.0;
         if (n_rows > 0) { se = e[0]; for (int64_t r = 1; r < n_rows; ++r) se += e[r]; }
         double w0n = compute_theta(*w0, reg0, se, (double)n_rows);
-        if (is_updatable(w0n, *w0)) {                     /* :23-25 */
-            double d = w0n - *w0;
-            for (int64_t r = 0; r < n_rows; ++r) e[r] = e[r] + d;
-        }
+        /* :23-27 as Spark EVALUATES them.  `error` is a lazy RDD whose closures hold `fm` by reference: `error.map(e => e +
+         * (w0 - fm.w0))` (:24) is only built here, `fm.w0 = w0` (:27) runs next, and the job that materialises it (:31,
+         * transformAsMap) serialises the closures AFTER that assignment.  So precomputeTermE's `fm.predict` already adds
+         * the NEW bias, and the mapped term is (w0 - fm.w0) = w0n - w0n = 0: the residuals the sweeps start from are
+         * predict_{new w0}(x) - y + 0, not e_old + (w0n - w0_old) — equal in exact arithmetic, a last-bit difference in
+         * fp64. */
+        int upd = is_updatable(w0n, *w0);
         *w0 = w0n;                                        /* :27 */
+        if (upd) {
+            fmo_residual(k, *w0, w, v, n_rows, row_ptr, col, val, y, e, 1);
+            for (int64_t r = 0; r < n_rows; ++r) e[r] = e[r] + (w0n - *w0);   /* + 0.0: kept for the record */
+        }
     }
     /* :36-43 linear weights; `0 until num_attribute` skips slot n (quirk Q1) */
     for (int64_t id = 0; id < num_attribute; ++id) {

@@ -84,7 +84,10 @@ __device__ __forceinline__ void block_sum2(double &x, double &y, double (*sh)[kA
     y = ty;
 }
 
-// drawGlobalBias :152-154 = computeTheta(w0, reg0, sum e, size), then e += w0* - w0 (:19-28) — once per epoch, one workgroup
+// drawGlobalBias :152-154 = computeTheta(w0, reg0, sum e, size) and `fm.w0 = w0` (:19-27) — once per epoch, one workgroup.
+// The residuals are NOT shifted here: as Spark evaluates :23-31 the lazy `error` RDD is materialised after `fm.w0 = w0`, so
+// its `fm.predict` already carries the new bias and the mapped term `w0 - fm.w0` is zero (oracle/fm_oracle.c) — the
+// launcher simply runs k_als_residual again with the new bias.
 template <int kAlsBlock>
 __global__ __launch_bounds__(kAlsBlock) void k_als_w0(AlsArgs a) {
 #pragma clang fp contract(off)
@@ -95,11 +98,6 @@ __global__ __launch_bounds__(kAlsBlock) void k_als_w0(AlsArgs a) {
     block_sum2<kAlsBlock>(se, dummy, sh);
     const double w0 = *a.w0;
     const double w0n = compute_theta(w0, a.reg0, se, (double)a.n_rows);
-    if (is_updatable(w0n, w0)) {
-        const double d = w0n - w0;
-        for (int64_t r = tid; r < a.n_rows; r += kAlsBlock) a.e[r] = a.e[r] + d;
-    }
-    __syncthreads();
     if (tid == 0) *a.w0 = w0n;
 }
 
@@ -363,26 +361,12 @@ __device__ __forceinline__ void walk_columns(const AlsArgs &a, double *e, double
 __global__ __launch_bounds__(kLdsSweepThreads) void k_als_sweep_lds(AlsArgs a, const double *qall) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) double lds_eq[];
-    __shared__ double sh[2][kLdsSweepThreads / 64];
     double *e = lds_eq, *q = lds_eq + a.n_rows;
     const int tid = threadIdx.x, lane = tid & 63;
     const bool walker = tid < 64;                                  // wave 0 walks the columns
     for (int64_t r = tid; r < a.n_rows; r += kLdsSweepThreads) e[r] = a.e[r];
     __syncthreads();
-    // ---- global bias: drawGlobalBias :152-154 = computeTheta(w0, reg0, sum e, size)
-    {
-        double se = 0.0, dummy = 0.0;
-        for (int64_t r = tid; r < a.n_rows; r += kLdsSweepThreads) se += e[r];
-        block_sum2<kLdsSweepThreads>(se, dummy, sh);
-        const double w0 = *a.w0;
-        const double w0n = compute_theta(w0, a.reg0, se, (double)a.n_rows);
-        if (is_updatable(w0n, w0)) {
-            const double d = w0n - w0;
-            for (int64_t r = tid; r < a.n_rows; r += kLdsSweepThreads) e[r] = e[r] + d;
-        }
-        if (tid == 0) *a.w0 = w0n;
-        __syncthreads();
-    }
+    // (the global bias step ran before this launch: k_als_w0, then the residuals again with the new bias)
     // ---- linear weights (:36-43)
     if (walker) walk_columns<false>(a, e, q, 0, lane);
     // ---- factors (:50-68): q of the factor comes in from the up-front pass, every thread copies its share
@@ -429,6 +413,10 @@ hipError_t launch_als_epoch(const AlsArgs &a, const int32_t *h_cfeat, const int3
     int64_t blocks = (a.n_rows + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
+    // precomputeTermE (:17) with the old bias feeds the bias step (:19-27); the residuals the sweeps start from are
+    // evaluated after `fm.w0 = w0` (see k_als_w0)
+    hipLaunchKernelGGL(k_als_residual, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_als_w0<1024>, dim3(1), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(k_als_residual, dim3((unsigned)blocks), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -445,10 +433,8 @@ hipError_t launch_als_epoch(const AlsArgs &a, const int32_t *h_cfeat, const int3
         hipLaunchKernelGGL(k_als_sweep_lds, dim3(1), dim3(kLdsSweepThreads), (size_t)a.n_rows * 2 * sizeof(double), s, a, a.q);
         return hipGetLastError();
     }
-    // e and q in global memory: w0, then one pass per parameter group following the column lengths — a run of short
-    // columns is one launch of one workgroup, a long column two chip-wide launches
-    hipLaunchKernelGGL(k_als_w0<1024>, dim3(1), dim3(1024), 0, s, a);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    // e and q in global memory: one pass per parameter group following the column lengths — a run of short columns is one
+    // launch of one workgroup, a long column two chip-wide launches
     // the short columns' mean length decides their workgroup size (a barrier over 4 waves is ~3x cheaper than over 16)
     int64_t short_nnz = 0, n_short = 0;
     for (int c = 0; c < a.n_cols; ++c) {

@@ -330,11 +330,31 @@ __device__ __forceinline__ void forward_rows(const FwdArgs &a, const float *wt, 
     const int T = WT ? a.wt_rows : 0;
     const __amdgpu_buffer_rsrc_t vr = make_rsrc(a.V, a.v_bytes);
     float st1 = 0.f, st2 = 0.f, stbad = 0.f;   // this thread's share of {sum e, sum e^2, nonfinite}
+#ifdef FMHIP_FWD_PREFETCH
+    // The next row's offsets are requested while this row is walked: a row starts with a chain of dependent loads
+    // (order -> row_ptr -> col/val -> V rows) and a slot walks ~6 rows one after the other.
+    const int stride = gridDim.x * SLOTS;
+    int ri = blockIdx.x * SLOTS + slot;
+    int r_next = ri < a.n_rows ? (a.order ? a.order[ri] : ri) : 0;
+    int64_t n0 = a.row_ptr[a.row0 + r_next], n1 = a.row_ptr[a.row0 + r_next + 1];
+    for (; ri < a.n_rows; ri += stride) {
+        const int r = r_next;
+        const int64_t p0 = n0, p1 = n1;
+        float4 xh = f4zero();
+        if (HOT) xh = hot_load(a, r, l);
+        {
+            const int rn = ri + stride < a.n_rows ? ri + stride : ri;       // clamped: the last row re-reads its own offsets
+            r_next = a.order ? a.order[rn] : rn;
+            n0 = a.row_ptr[a.row0 + r_next];
+            n1 = a.row_ptr[a.row0 + r_next + 1];
+        }
+#else
     for (int ri = blockIdx.x * SLOTS + slot; ri < a.n_rows; ri += gridDim.x * SLOTS) {
         const int r = a.order ? a.order[ri] : ri;
         float4 xh = f4zero();
         if (HOT) xh = hot_load(a, r, l);
         const int64_t p0 = a.row_ptr[a.row0 + r], p1 = a.row_ptr[a.row0 + r + 1];
+#endif
         float4 q[J], s[J];
 #pragma unroll
         for (int jj = 0; jj < J; ++jj) { q[jj] = f4zero(); s[jj] = f4zero(); }
