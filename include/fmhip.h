@@ -285,7 +285,9 @@ int fmhip_step_stats(fmhip_model_t m, fmhip_stats *stats);
  * with |B| = the summed row count, so the replicas stay bit-identical.  `batch` < 0: this rank has run
  * out of rows and contributes zeros.  All ranks must call with the same (eta, reg*) and the same cuts
  * (fmhip_dp_plan).  The summed row count travels as one fp32 word: a global batch (rows x world) must stay
- * below 2^24 rows, larger ones are refused. */
+ * below 2^24 rows — fmhip_dp_plan agrees the largest batch of any rank and refuses on EVERY rank alike; a
+ * check that can only fail on one rank (a batch the plan has not seen) makes that rank contribute zeros to
+ * the step and return the error afterwards, so no peer is left waiting in a collective. */
 #define FMHIP_UNIQUE_ID_BYTES 128
 int fmhip_comm_unique_id(void *id /* FMHIP_UNIQUE_ID_BYTES out */);
 int fmhip_comm_create(fmhip_model_t m, const void *id, int rank, int world, fmhip_comm_t *out);
@@ -317,11 +319,16 @@ int fmhip_device_write(void *device_dst, const void *host_src, size_t bytes, voi
 /* What travels in a data-parallel step (set on every rank, before fmhip_dp_plan):
  *   FMHIP_EXCHANGE_DENSE    (default) the whole packed gradient, 4(n+1)(k+1) bytes, in slices overlapped with the backward —
  *                           north_star's dense all-reduce; right when a global batch touches most of the model (C4)
- *   FMHIP_EXCHANGE_TOUCHED  only the gradient rows some rank's mini-batch touched: every rank's touched ids are gathered,
- *                           their sorted union U (identical everywhere) is packed [scalars | G rows of U], summed, unpacked and
- *                           applied with the rows-only update (weight decay rides in the tables' scale: 0.5 <= 1 - eta*reg <= 1
- *                           required).  For models far wider than a global batch — C5's 2^25 x 64 table is 8.9 GB dense and
- *                           ~0.1 of that here.  No overlap with the backward; one 4-byte read-back per step.
+ *   FMHIP_EXCHANGE_TOUCHED  only the gradient rows some rank's mini-batch touched.  A dataset's mini-batches are fixed, so
+ *                           fmhip_dp_plan forms ONCE, for every step t of the lock-step schedule "step t = every rank's batch t",
+ *                           the sorted union U_t of the feature ids those batches touch (all-gather of the ids, sort, unique)
+ *                           and where this rank's columns lie in it; a step then writes its gradient straight into a COMPACT
+ *                           buffer [scalars | G_w | G_b | G_V rows of U_t], all-reduces that buffer (its size is known on the
+ *                           host: no read-back, no synchronisation) and applies the rows-only update (weight decay rides in
+ *                           the tables' scale: 0.5 <= 1 - eta*reg <= 1 required).  For models far wider than a global batch —
+ *                           C5's 2^25 x 64 gradient is 8.9 GB dense and ~0.1 GB here.  Steps must follow the planned schedule:
+ *                           fmhip_dp_epoch does; fmhip_dp_step takes batch t at step t (or -1 on a rank without it) and the
+ *                           schedule wraps around after the longest rank's batch count.  Not overlapped with the backward.
  *   FMHIP_EXCHANGE_SHARDED  the dense exchange with the UPDATE sharded too: each interval's G_V slice is reduce-scattered (rank r
  *                           receives the summed rows of its 1/world share of the interval), rank r updates just those rows of V and
  *                           zeroes them, the updated rows are all-gathered in place into every replica's V.  Same bytes on the wire as
@@ -330,7 +337,7 @@ int fmhip_device_write(void *device_dst, const void *host_src, size_t bytes, voi
  *                           by construction (one writer per row).  G_w / G_b (1/32 of the bytes) are still all-reduced and every rank
  *                           steps all of w.  Interval edges are rounded to multiples of `world`; needs the library's own gradient
  *                           buffer (fmhip_grad_bind: only if n+1 is a multiple of world) and world <= 64.
- * fmhip_dp_exchange_info: the mode, the id slots per rank agreed by the plan, the mean |U| of the steps so far. */
+ * fmhip_dp_exchange_info: the mode, the id slots per rank agreed by the plan, the mean |U_t| over the planned steps. */
 #define FMHIP_EXCHANGE_DENSE 0
 #define FMHIP_EXCHANGE_TOUCHED 1
 #define FMHIP_EXCHANGE_SHARDED 2
