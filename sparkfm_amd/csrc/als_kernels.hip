@@ -86,7 +86,7 @@ __device__ __forceinline__ void block_sum2(double &x, double &y, double (*sh)[kA
 
 // drawGlobalBias :152-154 = computeTheta(w0, reg0, sum e, size) and `fm.w0 = w0` (:19-27) — once per epoch, one workgroup.
 // The residuals are NOT shifted here: as Spark evaluates :23-31 the lazy `error` RDD is materialised after `fm.w0 = w0`, so
-// its `fm.predict` already carries the new bias and the mapped term `w0 - fm.w0` is zero (oracle/fm_oracle.c) — the
+// its `fm.predict` already carries the new bias and the mapped term `w0 - fm.w0` is zero — the
 // launcher simply runs k_als_residual again with the new bias.
 template <int kAlsBlock>
 __global__ __launch_bounds__(kAlsBlock) void k_als_w0(AlsArgs a) {
