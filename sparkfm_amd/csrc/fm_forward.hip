@@ -3,6 +3,10 @@
 // geometry that goes with them.  Lane geometry and formulas: fm_device.h.
 #include "fm_device.h"
 
+#ifndef FMHIP_FWD_LDS_SHARE
+#define FMHIP_FWD_LDS_SHARE 1
+#endif
+
 namespace fmhip {
 
 int g_tune[kTuneCount] = {60, 1, 0, 0, 2, 1, 0, 1, 0, 1, 0, 1, 4};   // forward: w-tile kernel; backward: pipelined; tile rows: auto; row blocks: off; backward placement: band-affine; hot block: on; row order: on; forced flat loads: off; lazy decay: on; fused update: off; merged finish: on; hot pages: 4 of up to kHotPages (pages 5-8 measured: no gain, profiles/r03_experiments.md)
@@ -117,8 +121,43 @@ __device__ __forceinline__ void hot_prologue(const float4 xq, const float *vh, c
     hot_group<LPN, J, WITH_LIN, MASKED, 3>(xq, vh, wh, l, q, s, lin);
 }
 
-// One step of a row walk: the slot's LPN entries (c, x: one per lane) are broadcast, their V rows
-// gathered CH at a time and accumulated in stored order (q_f: FMModel.scala:59, sum_sqr_f: :60).
+// The slot's LPN entries (c, x: one per lane) are handed to every lane of the slot through LDS: each lane writes its
+// entry into the slot's 2 x LPN words of the workgroup's staging area (slot_publish) and reads the others back four at a
+// time with ds_read_b128 (the lanes of a slot read the same address: a broadcast) — 1 + LPN/2 LDS instructions per step
+// instead of ~6 vector-ALU moves per entry (two DPP moves per broadcast value plus the copies DPP's tied operand
+// needs), on a kernel whose vector ALU is the busiest unit (profiles/r03_experiments.md §12).  LDS operations of one
+// wave complete in order and the lanes of a slot always run together, so no barrier is needed — only the compiler
+// kept from reordering the accesses.
+template <int LPN>
+__device__ __forceinline__ const int *slot_publish(int *stage, int c, float x, int l) {
+    if (!FMHIP_FWD_LDS_SHARE) return nullptr;
+    int *sc = stage + (threadIdx.x & ~(LPN - 1)) * 2;      // this slot's [LPN] ids, then its [LPN] values
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the previous step's reads come first
+    sc[l] = c;
+    sc[LPN + l] = __float_as_int(x);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return sc;
+}
+template <int LPN, int CH>
+__device__ __forceinline__ void slot_entries(const int *sc, int c, int c0, int (&out)[CH]) {
+    static_assert(CH % 4 == 0, "four staged words per LDS read");
+    if (FMHIP_FWD_LDS_SHARE) {
+#pragma unroll
+        for (int j = 0; j < CH; j += 4) {
+            const int4 t = *reinterpret_cast<const int4 *>(sc + c0 + j);
+            out[j] = t.x; out[j + 1] = t.y; out[j + 2] = t.z; out[j + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) out[j] = slot_bcast<LPN>(c, c0 + j);
+    }
+}
+
+// One step of a row walk: the V rows of the slot's LPN entries are gathered CH at a time and accumulated in stored
+// order (q_f: FMModel.scala:59, sum_sqr_f: :60).  The entries' values are fetched from the staging area only once the
+// gathers are on their way (their registers are not live while the addresses are).
 // MASKED = the row's last, partial step (entries >= cnt are dead); full steps carry no per-entry
 // compare/select — the vector ALU, not the memory path, is what the forward saturates
 // (profiles/r01_experiments.md, section 23).
@@ -126,33 +165,37 @@ __device__ __forceinline__ void hot_prologue(const float4 xq, const float *vh, c
 // descriptor lives in scalar registers) instead of a 64-bit multiply-add pair, and the dead entries of a
 // partial step fetch nothing (out-of-range offset).  Wider tables take flat 64-bit addresses.
 template <int LPN, int J, int CH, bool MASKED, bool BUF>
-__device__ __forceinline__ void fwd_step(const float *V, __amdgpu_buffer_rsrc_t vr, int c, float x, int cnt, int l, float4 (&q)[J],
+__device__ __forceinline__ void fwd_step(const float *V, __amdgpu_buffer_rsrc_t vr, const int *sc, int c, float x, int cnt, int l, float4 (&q)[J],
                                          float4 (&s)[J]) {
     constexpr int KP = 4 * LPN * J;
 #pragma unroll
     for (int c0 = 0; c0 < LPN; c0 += CH) {
         float4 t[CH][J];
-        float xs[CH];
+        {
+            int cj[CH];
+            slot_entries<LPN, CH>(sc, c, c0, cj);
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const int cj = slot_bcast<LPN>(c, c0 + j);
-            xs[j] = slot_bcast<LPN>(x, c0 + j);
-            if (BUF) {
-                const uint32_t off = (uint32_t)cj * (KP * 4u) + (uint32_t)l * 16u;
+            for (int j = 0; j < CH; ++j) {
+                if (BUF) {
+                    const uint32_t off = (uint32_t)cj[j] * (KP * 4u) + (uint32_t)l * 16u;
 #pragma unroll
-                for (int jj = 0; jj < J; ++jj) t[j][jj] = buf_load4(vr, (MASKED && c0 + j >= cnt) ? kOob : off + jj * LPN * 16u);
-            } else {
-                const float4 *vp = reinterpret_cast<const float4 *>(V + (size_t)(uint32_t)cj * KP) + l;
+                    for (int jj = 0; jj < J; ++jj) t[j][jj] = buf_load4(vr, (MASKED && c0 + j >= cnt) ? kOob : off + jj * LPN * 16u);
+                } else {
+                    const float4 *vp = reinterpret_cast<const float4 *>(V + (size_t)(uint32_t)cj[j] * KP) + l;
 #pragma unroll
-                for (int jj = 0; jj < J; ++jj) t[j][jj] = vp[jj * LPN];
+                    for (int jj = 0; jj < J; ++jj) t[j][jj] = vp[jj * LPN];
+                }
             }
         }
+        if (FMHIP_FWD_LDS_SHARE) __builtin_amdgcn_sched_barrier(0);
+        int xi[CH];
+        slot_entries<LPN, CH>(sc ? sc + LPN : nullptr, __float_as_int(x), c0, xi);
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const bool live = c0 + j < cnt;
 #pragma unroll
             for (int jj = 0; jj < J; ++jj) {
-                float4 tv = f4mul(t[j][jj], xs[j]);
+                float4 tv = f4mul(t[j][jj], __int_as_float(xi[j]));
                 if (MASKED && !live) tv = f4zero();
                 f4add(q[jj], tv);
                 f4sqacc(s[jj], tv);
@@ -322,6 +365,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_forward_lds(FwdArgs a) {
 // (profiles/r01_experiments.md §13); lanes whose id is in the tile drop out of the global gather.
 template <int LPN, int J, int MODE, bool PACKED, bool HOT, bool WT, bool BUF>
 __device__ __forceinline__ void forward_rows(const FwdArgs &a, const float *wt, const float *vh, const float *wh, bool hot_plain) {
+    __shared__ __attribute__((aligned(16))) int stage[FMHIP_FWD_LDS_SHARE ? 2 * kBlock : 4];   // slot_share
     constexpr int SLOTS = kBlock / LPN;
     constexpr int CH = (LPN * J > 16) ? (16 / J) : LPN;  // entries whose V rows are in flight together
     const int l = threadIdx.x & (LPN - 1);
@@ -329,6 +373,8 @@ __device__ __forceinline__ void forward_rows(const FwdArgs &a, const float *wt, 
     const float w0 = *a.w0;
     const int T = WT ? a.wt_rows : 0;
     const __amdgpu_buffer_rsrc_t vr = make_rsrc(a.V, a.v_bytes);
+    const int32_t *colb = a.col + a.nz0;
+    const float *valb = a.val + a.nz0;
     float st1 = 0.f, st2 = 0.f, stbad = 0.f;   // this thread's share of {sum e, sum e^2, nonfinite}
 #ifdef FMHIP_FWD_PREFETCH
     // The next row's offsets are requested while this row is walked: a row starts with a chain of dependent loads
@@ -339,7 +385,7 @@ __device__ __forceinline__ void forward_rows(const FwdArgs &a, const float *wt, 
     int64_t n0 = a.row_ptr[a.row0 + r_next], n1 = a.row_ptr[a.row0 + r_next + 1];
     for (; ri < a.n_rows; ri += stride) {
         const int r = r_next;
-        const int64_t p0 = n0, p1 = n1;
+        const uint32_t p0 = (uint32_t)(n0 - a.nz0), p1 = (uint32_t)(n1 - a.nz0);
         float4 xh = f4zero();
         if (HOT) xh = hot_load(a, r, l);
         {
@@ -353,7 +399,8 @@ __device__ __forceinline__ void forward_rows(const FwdArgs &a, const float *wt, 
         const int r = a.order ? a.order[ri] : ri;
         float4 xh = f4zero();
         if (HOT) xh = hot_load(a, r, l);
-        const int64_t p0 = a.row_ptr[a.row0 + r], p1 = a.row_ptr[a.row0 + r + 1];
+        // entry positions relative to the batch's first entry: 32-bit walk state (a batch holds < 2^31 entries)
+        const uint32_t p0 = (uint32_t)(a.row_ptr[a.row0 + r] - a.nz0), p1 = (uint32_t)(a.row_ptr[a.row0 + r + 1] - a.nz0);
 #endif
         float4 q[J], s[J];
 #pragma unroll
@@ -363,25 +410,25 @@ __device__ __forceinline__ void forward_rows(const FwdArgs &a, const float *wt, 
             if (hot_plain) hot_prologue<LPN, J, !PACKED, false>(xh, vh, wh, l, q, s, lin);
             else hot_prologue<LPN, J, !PACKED, true>(xh, vh, wh, l, q, s, lin);
         }
-        int64_t base = p0;
+        uint32_t base = p0;
         for (; base + LPN <= p1; base += LPN) {        // full steps
-            const int c = stream_load(a.col + base + l);
-            const float x = stream_load(a.val + base + l);
+            const int c = stream_load(colb + (base + l));
+            const float x = stream_load(valb + (base + l));
             float wv = 0.f;
             if (!PACKED) wv = (WT && c < T) ? wt[c] : a.w[c];
-            fwd_step<LPN, J, CH, false, BUF>(a.V, vr, c, x, LPN, l, q, s);
+            fwd_step<LPN, J, CH, false, BUF>(a.V, vr, slot_publish<LPN>(stage, c, x, l), c, x, LPN, l, q, s);
             if (!PACKED) lin = fmaf(wv, x, lin);       // consumed after the gathers are on their way
         }
         if (base < p1) {                               // the row's last, partial step
-            const int64_t p = base + l;
+            const uint32_t p = base + l;
             int c = 0;
             float x = 0.f, wv = 0.f;
             if (p < p1) {
-                c = stream_load(a.col + p);
-                x = stream_load(a.val + p);
+                c = stream_load(colb + p);
+                x = stream_load(valb + p);
                 if (!PACKED) wv = (WT && c < T) ? wt[c] : a.w[c];
             }
-            fwd_step<LPN, J, CH, true, BUF>(a.V, vr, c, x, (int)(p1 - base), l, q, s);
+            fwd_step<LPN, J, CH, true, BUF>(a.V, vr, slot_publish<LPN>(stage, c, x, l), c, x, (int)(p1 - base), l, q, s);
             if (!PACKED) lin = fmaf(wv, x, lin);
         }
         row_finish<LPN, J, MODE, PACKED>(a, r, l, q, s, lin, w0, st1, st2, stbad);

@@ -49,6 +49,7 @@ struct FwdArgs {
     const float *w;   // [n+1]
     const float *w0;  // [1]
     int64_t row0;
+    int64_t nz0;           // row_ptr[row0]: the batch's first entry (k_forward / k_forward_wt walk 32-bit positions relative to it)
     const int32_t *order;  // [n_rows] batch-local row ids, longest row first (NULL = 0, 1, 2, ..)
     int32_t n_rows;
     float *P;     // train: [rows][Kp] = e*q ; q-mode: [rows][Kp] = q

@@ -438,18 +438,26 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     // forward walk order of each batch: rows by (sparse) length, longest first, ties in row order
     {
         std::vector<int32_t> order((size_t)n_rows);
+        const char *ow = getenv("FMHIP_ORDER_WINDOW");
+        const int64_t order_window = ow ? atoll(ow) : 0;   // experiment: sort inside windows of this many rows (0 = the whole batch)
         parallel_chunks(nb, std::min<int>(T, (int)std::max<int64_t>(nb, 1)), [&](int, int64_t blo, int64_t bhi) {
             std::vector<int64_t> start;
             for (int64_t b = blo; b < bhi; ++b) {
                 const BatchMeta &bm = d->batches[(size_t)b];
-                int64_t maxlen = 0;
-                for (int64_t r = 0; r < bm.rows; ++r) maxlen = std::max(maxlen, row_ptr[bm.row0 + r + 1] - row_ptr[bm.row0 + r]);
-                start.assign((size_t)maxlen + 2, 0);
-                for (int64_t r = 0; r < bm.rows; ++r) ++start[(size_t)(maxlen - (row_ptr[bm.row0 + r + 1] - row_ptr[bm.row0 + r])) + 1];
-                for (size_t i = 1; i < start.size(); ++i) start[i] += start[i - 1];
-                for (int64_t r = 0; r < bm.rows; ++r) {
-                    const size_t key = (size_t)(maxlen - (row_ptr[bm.row0 + r + 1] - row_ptr[bm.row0 + r]));
-                    order[(size_t)(bm.row0 + start[key]++)] = (int32_t)r;
+                const int64_t win = order_window > 0 ? order_window : std::max<int64_t>(bm.rows, 1);
+                for (int64_t w0 = 0; w0 < bm.rows; w0 += win) {
+                    const int64_t w1 = std::min(bm.rows, w0 + win);
+                    int64_t maxlen = 0;
+                    for (int64_t r = w0; r < w1; ++r) maxlen = std::max(maxlen, row_ptr[bm.row0 + r + 1] - row_ptr[bm.row0 + r]);
+                    start.assign((size_t)maxlen + 2, 0);
+                    for (int64_t r = w0; r < w1; ++r) ++start[(size_t)(maxlen - (row_ptr[bm.row0 + r + 1] - row_ptr[bm.row0 + r])) + 1];
+                    for (size_t i = 1; i < start.size(); ++i) start[i] += start[i - 1];
+                    for (int64_t r = w0; r < w1; ++r) {
+                        const size_t key = (size_t)(maxlen - (row_ptr[bm.row0 + r + 1] - row_ptr[bm.row0 + r]));
+                        order[(size_t)(bm.row0 + w0 + start[key]++)] = (int32_t)r;
+                    }
+                    // windows alternate longest-first / shortest-first: a workgroup takes the same position of every window it visits
+                    if (order_window > 0 && ((w0 / win) & 1)) std::reverse(order.begin() + (bm.row0 + w0), order.begin() + (bm.row0 + w1));
                 }
             }
         });

@@ -106,9 +106,10 @@ FwdArgs fwd_args(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm) {
     a.w = m->w.p;
     a.w0 = m->w0.p;
     a.row0 = bm.row0;
+    a.nz0 = bm.nnz0;
     // longest-first row order: pays for wide rows only (k=64: -8 %); at Kp = 32 it changes nothing but the
     // locality of the per-row streams (forward FETCH_SIZE 184 -> 269 MB), so narrow models walk in stored order
-    a.order = (m->tv(kTuneRowOrder) && m->Kp >= 64) ? d->row_order.p + bm.row0 : nullptr;
+    a.order = (m->tv(kTuneRowOrder) && (m->Kp >= 64 || getenv("FMHIP_ORDER_ALL"))) ? d->row_order.p + bm.row0 : nullptr;
     a.n_rows = (int32_t)bm.rows;
     a.P = m->P.p;
     a.e = m->e.p;
