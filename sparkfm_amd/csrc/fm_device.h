@@ -85,6 +85,10 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t o
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
 // P rows are written once by the forward and read by OTHER compute units in the backward (never from
 // this XCD's L2, which is not coherent with theirs): optionally stored non-temporally so they do not
 // displace the gathered V rows from L2 on their way out.

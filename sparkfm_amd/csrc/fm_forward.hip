@@ -6,6 +6,28 @@
 #ifndef FMHIP_FWD_LDS_SHARE
 #define FMHIP_FWD_LDS_SHARE 1
 #endif
+// timing-only ablations (results wrong by construction; tools/build_variant.sh with EXTRA_FLAGS)
+#ifndef FMHIP_FWD_W_SPLIT
+#define FMHIP_FWD_W_SPLIT 1
+#endif
+#ifndef FMHIP_EXP_NO_STREAM
+#define FMHIP_EXP_NO_STREAM 0
+#endif
+#ifndef FMHIP_EXP_NO_MATH
+#define FMHIP_EXP_NO_MATH 0
+#endif
+#ifndef FMHIP_EXP_NO_W
+#define FMHIP_EXP_NO_W 0
+#endif
+#ifndef FMHIP_EXP_NO_GATHER
+#define FMHIP_EXP_NO_GATHER 0
+#endif
+#ifndef FMHIP_EXP_L1_GATHER
+#define FMHIP_EXP_L1_GATHER 0
+#endif
+#ifndef FMHIP_EXP_NO_HOT
+#define FMHIP_EXP_NO_HOT 0
+#endif
 
 namespace fmhip {
 
@@ -88,6 +110,24 @@ __device__ __forceinline__ float4 hot_load(const FwdArgs &a, int r, int l) {
     return reinterpret_cast<const float4 *>(a.xhot + (size_t)r * kHotT)[l & 3];
 }
 
+// q += v*x and s += (v*x)^2 for one float4 of one entry, spelled as the six packed-fp32 operations it should be
+// (v_pk_mul_f32 for the rounded product, v_pk_fma_f32 into q and into s): left to the vectoriser the same source comes out
+// packed or scalar depending on the surrounding register pressure.  A single-nonzero row still has q = round(v*x) and
+// s = round(q^2), so its interaction is exactly 0 (quirk Q6).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void acc_entry(float4 &q, float4 &s, const float4 t, const float x) {
+    const v2f xs = {x, x};
+    const v2f tlo = {t.x, t.y}, thi = {t.z, t.w};
+    v2f qlo = {q.x, q.y}, qhi = {q.z, q.w}, slo = {s.x, s.y}, shi = {s.z, s.w};
+    const v2f plo = tlo * xs, phi = thi * xs;
+    qlo = __builtin_elementwise_fma(tlo, xs, qlo);
+    qhi = __builtin_elementwise_fma(thi, xs, qhi);
+    slo = __builtin_elementwise_fma(plo, plo, slo);
+    shi = __builtin_elementwise_fma(phi, phi, shi);
+    q = make_float4(qlo.x, qlo.y, qhi.x, qhi.y);
+    s = make_float4(slo.x, slo.y, shi.x, shi.y);
+}
+
 template <int LPN, int J, bool WITH_LIN, bool MASKED, int G>
 __device__ __forceinline__ void hot_group(const float4 xq, const float *vh, const float *wh, int l, float4 (&q)[J],
                                           float4 (&s)[J], float &lin) {
@@ -100,10 +140,15 @@ __device__ __forceinline__ void hot_group(const float4 xq, const float *vh, cons
         const bool live = x != 0.f;
 #pragma unroll
         for (int jj = 0; jj < J; ++jj) {
-            float4 tv = f4mul(reinterpret_cast<const float4 *>(vh + h * KP)[jj * LPN + l], x);
-            if (MASKED && !live) tv = f4zero();
-            f4add(q[jj], tv);
-            f4sqacc(s[jj], tv);
+            const float4 vrow = reinterpret_cast<const float4 *>(vh + h * KP)[jj * LPN + l];
+            if (MASKED) {
+                float4 tv = f4mul(vrow, x);
+                if (!live) tv = f4zero();
+                f4add(q[jj], tv);
+                f4sqacc(s[jj], tv);
+            } else {
+                acc_entry(q[jj], s[jj], vrow, x);
+            }
         }
         if (WITH_LIN && (h & (LPN - 1)) == l && (!MASKED || live)) lin = fmaf(wh[h], x, lin);
     }
@@ -176,8 +221,11 @@ __device__ __forceinline__ void fwd_step(const float *V, __amdgpu_buffer_rsrc_t 
             slot_entries<LPN, CH>(sc, c, c0, cj);
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
-                if (BUF) {
-                    const uint32_t off = (uint32_t)cj[j] * (KP * 4u) + (uint32_t)l * 16u;
+                if (FMHIP_EXP_NO_GATHER) {
+#pragma unroll
+                    for (int jj = 0; jj < J; ++jj) t[j][jj] = make_float4(__int_as_float(cj[j]), 1.f, 2.f, (float)l);
+                } else if (BUF) {
+                    const uint32_t off = (uint32_t)(FMHIP_EXP_L1_GATHER ? (cj[j] & 63) : cj[j]) * (KP * 4u) + (uint32_t)l * 16u;
 #pragma unroll
                     for (int jj = 0; jj < J; ++jj) t[j][jj] = buf_load4(vr, (MASKED && c0 + j >= cnt) ? kOob : off + jj * LPN * 16u);
                 } else {
@@ -195,10 +243,16 @@ __device__ __forceinline__ void fwd_step(const float *V, __amdgpu_buffer_rsrc_t 
             const bool live = c0 + j < cnt;
 #pragma unroll
             for (int jj = 0; jj < J; ++jj) {
-                float4 tv = f4mul(t[j][jj], __int_as_float(xi[j]));
-                if (MASKED && !live) tv = f4zero();
-                f4add(q[jj], tv);
-                f4sqacc(s[jj], tv);
+                if (MASKED) {
+                    float4 tv = f4mul(t[j][jj], __int_as_float(xi[j]));
+                    if (!live) tv = f4zero();
+                    f4add(q[jj], tv);
+                    f4sqacc(s[jj], tv);
+                } else if (FMHIP_EXP_NO_MATH) {
+                    q[jj].x += t[j][jj].x * __int_as_float(xi[j]);
+                } else {
+                    acc_entry(q[jj], s[jj], t[j][jj], __int_as_float(xi[j]));
+                }
             }
         }
     }
@@ -357,6 +411,19 @@ __global__ __launch_bounds__(kLdsBlock) void k_forward_lds(FwdArgs a) {
     block_stats<kLdsBlock>(a.bsum, st1, st2, stbad);
 }
 
+// The linear weight of feature c: from the LDS tile when c < T, else from the table.  Written as one LDS read and one
+// buffer load whose tile lanes are out of range (they fetch nothing) rather than a select between two addresses, which
+// the compiler turns into a flat load that sends all 64 lanes through the texture addresser.
+template <bool WT, bool BUF>
+__device__ __forceinline__ float w_lookup(const FwdArgs &a, __amdgpu_buffer_rsrc_t wr, const float *wt, int T, int c) {
+    if (!WT) return a.w[c];
+    if (!BUF || !FMHIP_FWD_W_SPLIT) return c < T ? wt[c] : a.w[c];
+    const bool in_tile = c < T;
+    const float wl = wt[in_tile ? c : 0];
+    const float wg = buf_load1(wr, in_tile ? kOob : (uint32_t)c * 4u);
+    return in_tile ? wl : wg;
+}
+
 // The row walk of k_forward / k_forward_wt.  Rows are taken in the dataset's length-sorted order when one
 // is given (longest first): the slots of a wave then walk rows of (nearly) equal length, so no lane idles
 // while a neighbour finishes a longer row.  WT: the linear weights of the wt_rows lowest (= hottest, for
@@ -367,12 +434,14 @@ template <int LPN, int J, int MODE, bool PACKED, bool HOT, bool WT, bool BUF>
 __device__ __forceinline__ void forward_rows(const FwdArgs &a, const float *wt, const float *vh, const float *wh, bool hot_plain) {
     __shared__ __attribute__((aligned(16))) int stage[FMHIP_FWD_LDS_SHARE ? 2 * kBlock : 4];   // slot_share
     constexpr int SLOTS = kBlock / LPN;
+    constexpr int KPW = 4 * LPN * J;
     constexpr int CH = (LPN * J > 16) ? (16 / J) : LPN;  // entries whose V rows are in flight together
     const int l = threadIdx.x & (LPN - 1);
     const int slot = threadIdx.x / LPN;
     const float w0 = *a.w0;
     const int T = WT ? a.wt_rows : 0;
     const __amdgpu_buffer_rsrc_t vr = make_rsrc(a.V, a.v_bytes);
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.w, a.v_bytes / KPW);   // (n+1) floats, when V fits a buffer view
     const int32_t *colb = a.col + a.nz0;
     const float *valb = a.val + a.nz0;
     float st1 = 0.f, st2 = 0.f, stbad = 0.f;   // this thread's share of {sum e, sum e^2, nonfinite}
@@ -406,29 +475,32 @@ __device__ __forceinline__ void forward_rows(const FwdArgs &a, const float *wt, 
 #pragma unroll
         for (int jj = 0; jj < J; ++jj) { q[jj] = f4zero(); s[jj] = f4zero(); }
         float lin = 0.f;
-        if (HOT) {
+        if (HOT && !FMHIP_EXP_NO_HOT) {
             if (hot_plain) hot_prologue<LPN, J, !PACKED, false>(xh, vh, wh, l, q, s, lin);
             else hot_prologue<LPN, J, !PACKED, true>(xh, vh, wh, l, q, s, lin);
         }
         uint32_t base = p0;
         for (; base + LPN <= p1; base += LPN) {        // full steps
-            const int c = stream_load(colb + (base + l));
-            const float x = stream_load(valb + (base + l));
+            const int c = FMHIP_EXP_NO_STREAM ? (int)((base + l) & 1023u) : stream_load(colb + (base + l));
+            const float x = FMHIP_EXP_NO_STREAM ? 1.f : stream_load(valb + (base + l));
             float wv = 0.f;
-            if (!PACKED) wv = (WT && c < T) ? wt[c] : a.w[c];
+            if (!PACKED && !FMHIP_EXP_NO_W) wv = w_lookup<WT, BUF>(a, wr, wt, T, c);
             fwd_step<LPN, J, CH, false, BUF>(a.V, vr, slot_publish<LPN>(stage, c, x, l), c, x, LPN, l, q, s);
             if (!PACKED) lin = fmaf(wv, x, lin);       // consumed after the gathers are on their way
         }
         if (base < p1) {                               // the row's last, partial step
+            // Through a buffer view a dead entry is id -1 with value 0: its row offset lies past the end of V (a multiple
+            // of the row size below 2^32), so the gather fetches nothing and returns 0, and 0 * 0 adds exactly nothing —
+            // the step needs no per-entry mask.  Flat addresses keep the masked step (a dead entry reads row 0).
             const uint32_t p = base + l;
-            int c = 0;
+            int c = BUF ? -1 : 0;
             float x = 0.f, wv = 0.f;
             if (p < p1) {
                 c = stream_load(colb + p);
                 x = stream_load(valb + p);
-                if (!PACKED) wv = (WT && c < T) ? wt[c] : a.w[c];
+                if (!PACKED && !FMHIP_EXP_NO_W) wv = w_lookup<WT, BUF>(a, wr, wt, T, c);
             }
-            fwd_step<LPN, J, CH, true, BUF>(a.V, vr, slot_publish<LPN>(stage, c, x, l), c, x, (int)(p1 - base), l, q, s);
+            fwd_step<LPN, J, CH, !BUF, BUF>(a.V, vr, slot_publish<LPN>(stage, c, x, l), c, x, (int)(p1 - base), l, q, s);
             if (!PACKED) lin = fmaf(wv, x, lin);
         }
         row_finish<LPN, J, MODE, PACKED>(a, r, l, q, s, lin, w0, st1, st2, stbad);
