@@ -502,6 +502,9 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
 // chunks of CHB entries so chunk c+1 is in flight while chunk c is accumulated.
 // (HOT: the waves-per-SIMD bound keeps the MFMA accumulators of the hot body from costing the walkers
 // their third wave)
+#ifndef FMHIP_EXP_NO_XE_BCAST
+#define FMHIP_EXP_NO_XE_BCAST 0   // timing-only ablation: the value / residual broadcasts of the pipelined walk dropped (results wrong)
+#endif
 #ifndef FMHIP_BWD_WAVES
 #define FMHIP_BWD_WAVES 3
 #endif
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(kBlock, (HOT && J == 1 ? FMHIP_BWD_WAVES : 1)) void
                 for (int j = 0; j < CHB; ++j) {
                     const int ent = ch * CHB + j;
                     const int g = ent / LPN, jl = ent % LPN;
-                    w.add(pv[buf][j], slot_bcast<LPN>(x[g], jl), PACKED ? 0.f : slot_bcast<LPN>(ee[g], jl));
+                    w.add(pv[buf][j], FMHIP_EXP_NO_XE_BCAST ? x[g] : slot_bcast<LPN>(x[g], jl), PACKED ? 0.f : (FMHIP_EXP_NO_XE_BCAST ? ee[g] : slot_bcast<LPN>(ee[g], jl)));
                 }
                 continue;
             }
@@ -579,8 +582,8 @@ __global__ __launch_bounds__(kBlock, (HOT && J == 1 ? FMHIP_BWD_WAVES : 1)) void
             for (int j = 0; j < CHB; ++j) {
                 const int ent = ch * CHB + j;
                 const int g = ent / LPN, jl = ent % LPN;
-                const float xj = slot_bcast<LPN>(x[g], jl);
-                const float ej = PACKED ? 0.f : slot_bcast<LPN>(ee[g], jl);
+                const float xj = FMHIP_EXP_NO_XE_BCAST ? x[g] : slot_bcast<LPN>(x[g], jl);
+                const float ej = PACKED ? 0.f : (FMHIP_EXP_NO_XE_BCAST ? ee[g] : slot_bcast<LPN>(ee[g], jl));
                 if (sbase + ent < w.stop) w.entry(a, sbase + ent, rj[buf][j], pv[buf][j], xj, ej);
             }
         }

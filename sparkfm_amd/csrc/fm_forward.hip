@@ -7,6 +7,9 @@
 #define FMHIP_FWD_LDS_SHARE 1
 #endif
 // timing-only ablations (results wrong by construction; tools/build_variant.sh with EXTRA_FLAGS)
+#ifndef FMHIP_FWD_AHEAD
+#define FMHIP_FWD_AHEAD 1
+#endif
 #ifndef FMHIP_FWD_W_SPLIT
 #define FMHIP_FWD_W_SPLIT 1
 #endif
@@ -416,12 +419,17 @@ __global__ __launch_bounds__(kLdsBlock) void k_forward_lds(FwdArgs a) {
 // the compiler turns into a flat load that sends all 64 lanes through the texture addresser.
 template <bool WT, bool BUF>
 __device__ __forceinline__ float w_lookup(const FwdArgs &a, __amdgpu_buffer_rsrc_t wr, const float *wt, int T, int c) {
-    if (!WT) return a.w[c];
-    if (!BUF || !FMHIP_FWD_W_SPLIT) return c < T ? wt[c] : a.w[c];
-    const bool in_tile = c < T;
-    const float wl = wt[in_tile ? c : 0];
-    const float wg = buf_load1(wr, in_tile ? kOob : (uint32_t)c * 4u);
-    return in_tile ? wl : wg;
+    // c == -1 (the dead entry of a pipelined step) yields 0 without a branch: every load below is unconditional
+    if (BUF && FMHIP_FWD_W_SPLIT) {
+        const bool in_tile = WT && (uint32_t)c < (uint32_t)T;
+        const float wg = buf_load1(wr, in_tile ? kOob : (uint32_t)c * 4u);     // id -1: past the end of w, returns 0
+        if (!WT) return wg;
+        const float wl = wt[in_tile ? c : 0];
+        return in_tile ? wl : wg;
+    }
+    const int cc = c < 0 ? 0 : c;
+    const float v = (WT && cc < T) ? wt[cc] : a.w[cc];
+    return c < 0 ? 0.f : v;
 }
 
 // The row walk of k_forward / k_forward_wt.  Rows are taken in the dataset's length-sorted order when one
@@ -445,32 +453,65 @@ __device__ __forceinline__ void forward_rows(const FwdArgs &a, const float *wt, 
     const int32_t *colb = a.col + a.nz0;
     const float *valb = a.val + a.nz0;
     float st1 = 0.f, st2 = 0.f, stbad = 0.f;   // this thread's share of {sum e, sum e^2, nonfinite}
-#ifdef FMHIP_FWD_PREFETCH
-    // The next row's offsets are requested while this row is walked: a row starts with a chain of dependent loads
-    // (order -> row_ptr -> col/val -> V rows) and a slot walks ~6 rows one after the other.
-    const int stride = gridDim.x * SLOTS;
-    int ri = blockIdx.x * SLOTS + slot;
-    int r_next = ri < a.n_rows ? (a.order ? a.order[ri] : ri) : 0;
-    int64_t n0 = a.row_ptr[a.row0 + r_next], n1 = a.row_ptr[a.row0 + r_next + 1];
-    for (; ri < a.n_rows; ri += stride) {
-        const int r = r_next;
-        const uint32_t p0 = (uint32_t)(n0 - a.nz0), p1 = (uint32_t)(n1 - a.nz0);
-        float4 xh = f4zero();
-        if (HOT) xh = hot_load(a, r, l);
-        {
-            const int rn = ri + stride < a.n_rows ? ri + stride : ri;       // clamped: the last row re-reads its own offsets
-            r_next = a.order ? a.order[rn] : rn;
-            n0 = a.row_ptr[a.row0 + r_next];
-            n1 = a.row_ptr[a.row0 + r_next + 1];
+    if (BUF && FMHIP_FWD_AHEAD) {
+        // Through a buffer view one loop serves full and partial steps — a dead entry is id -1 with value 0: its row offset
+        // lies past the end of V (a multiple of the row size below 2^32), the gather fetches nothing and returns 0, and 0 * 0
+        // adds exactly nothing — and the entries of the row's NEXT step are requested before this step's gathers, so the
+        // stream's latency is not paid between steps.  What was measured around it (profiles/r03_experiments.md §12): looking
+        // further ahead (the next row's offsets, first entries, dense-block values) is slower at C3 (+5 us), and so is
+        // requesting the row's first entries before the dense-block prologue; packed rows (no w lookup) prefer the requests
+        // unconditional through opaque addresses (C2 forward 108 -> 97 us), rows with a w lookup the plain conditional form.
+        for (int ri = blockIdx.x * SLOTS + slot; ri < a.n_rows; ri += gridDim.x * SLOTS) {
+            const int r = a.order ? a.order[ri] : ri;
+            float4 xh = f4zero();
+            if (HOT) xh = hot_load(a, r, l);
+            const uint32_t p0 = (uint32_t)(a.row_ptr[a.row0 + r] - a.nz0), p1 = (uint32_t)(a.row_ptr[a.row0 + r + 1] - a.nz0);
+            float4 q[J], s[J];
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) { q[jj] = f4zero(); s[jj] = f4zero(); }
+            float lin = 0.f;
+            if (HOT && !FMHIP_EXP_NO_HOT) {
+                if (hot_plain) hot_prologue<LPN, J, !PACKED, false>(xh, vh, wh, l, q, s, lin);
+                else hot_prologue<LPN, J, !PACKED, true>(xh, vh, wh, l, q, s, lin);
+            }
+            int c_n = -1;
+            float x_n = 0.f;
+            bool live_n = p0 + l < p1;   // c_n / x_n hold a loaded entry (else a dead lane's filler)
+            if (live_n) { c_n = stream_load(colb + (p0 + l)); x_n = stream_load(valb + (p0 + l)); }
+            for (uint32_t base = p0; base < p1; base += LPN) {
+                const int c = live_n ? c_n : -1;
+                const float x = live_n ? x_n : 0.f;
+                const uint32_t pos = base + LPN + l;
+                if (PACKED) {
+                    // unconditional loads (a dead lane reads a harmless word), the dead-lane select left to the consumer
+                    live_n = pos < p1;
+                    typedef __attribute__((address_space(1))) const int32_t gint;
+                    typedef __attribute__((address_space(1))) const float gflt;
+                    gint *cp = (gint *)(live_n ? colb + pos : reinterpret_cast<const int32_t *>(a.w0));
+                    gflt *xp = (gflt *)(live_n ? valb + pos : a.w0);
+                    asm volatile("" : "+v"(cp), "+v"(xp));   // opaque: or the select + load is turned back into a branch
+                    c_n = *cp;
+                    x_n = *xp;
+                } else {
+                    live_n = true; c_n = -1; x_n = 0.f;
+                    if (pos < p1) { c_n = stream_load(colb + pos); x_n = stream_load(valb + pos); }
+                }
+                float wv = 0.f;
+                if (!PACKED && !FMHIP_EXP_NO_W && c >= 0) wv = w_lookup<WT, BUF>(a, wr, wt, T, c);
+                fwd_step<LPN, J, CH, false, BUF>(a.V, vr, slot_publish<LPN>(stage, c, x, l), c, x, LPN, l, q, s);
+                if (!PACKED) lin = fmaf(wv, x, lin);
+            }
+            row_finish<LPN, J, MODE, PACKED>(a, r, l, q, s, lin, w0, st1, st2, stbad);
         }
-#else
+        block_stats<kBlock>(a.bsum, st1, st2, stbad);
+        return;
+    }
     for (int ri = blockIdx.x * SLOTS + slot; ri < a.n_rows; ri += gridDim.x * SLOTS) {
         const int r = a.order ? a.order[ri] : ri;
         float4 xh = f4zero();
         if (HOT) xh = hot_load(a, r, l);
         // entry positions relative to the batch's first entry: 32-bit walk state (a batch holds < 2^31 entries)
         const uint32_t p0 = (uint32_t)(a.row_ptr[a.row0 + r] - a.nz0), p1 = (uint32_t)(a.row_ptr[a.row0 + r + 1] - a.nz0);
-#endif
         float4 q[J], s[J];
 #pragma unroll
         for (int jj = 0; jj < J; ++jj) { q[jj] = f4zero(); s[jj] = f4zero(); }

@@ -125,6 +125,27 @@ def test_forward_and_gradient_vs_oracle(fmhip, k):
     fm.close()
 
 
+@pytest.mark.parametrize("window", ["0", "64", "100"])
+def test_forward_walk_order_is_only_an_order(fmhip, monkeypatch, window):
+    """Wide rows (Kp >= 64) are walked longest-first; FMHIP_ORDER_WINDOW (an experiment knob read when the dataset is built)
+    sorts inside windows of rows instead.  Whatever the order, every row is visited once: predictions, residual
+    statistics and the gradient are the oracle's."""
+    monkeypatch.setenv("FMHIP_ORDER_WINDOW", window)
+    a = random_problem(777, 1500, 300, 64, 0, 60, empty_rows=(3, 1499))
+    ds, fm = make(fmhip, a, batch_rows=700)
+    sc = term_scale(a)
+    yh = fm.predict(ds)
+    oyh = oracle.predict(a["w0"], a["w"], a["v"], a["row_ptr"], a["col"], a["val"])
+    assert (np.abs(yh - oyh) <= TOL_Y * sc).all()
+    assert yh[3] == np.float32(a["w0"]) and yh[1499] == np.float32(a["w0"])
+    gv, gw, g0, st = fm.batchGradient(ds, 1)
+    ogv, ogw, og0, osse, oe = oracle.batch_grad(a["w0"], a["w"], a["v"], 700, 1400, a["row_ptr"], a["col"], a["val"], a["y"])
+    check_grad(gv, gw, ogv, ogw, np.abs(a["v"]).max())
+    assert st["sse"] == pytest.approx(osse, rel=1e-5) and st["rows"] == 700
+    ds.unpersist()
+    fm.close()
+
+
 @pytest.mark.parametrize("fwd,bwd,tile", [(20, 1, 0), (20, 1, 16), (0, 0, 0), (60, 1, 0), (60, 1, 50)])
 def test_kernel_variants_agree_with_the_oracle(fmhip, fwd, bwd, tile):
     """fmhip_tune: the LDS V-tile forward (ids < tile rows come from LDS, the rest from global
