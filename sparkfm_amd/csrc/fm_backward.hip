@@ -502,6 +502,9 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
 // chunks of CHB entries so chunk c+1 is in flight while chunk c is accumulated.
 // (HOT: the waves-per-SIMD bound keeps the MFMA accumulators of the hot body from costing the walkers
 // their third wave)
+#ifndef FMHIP_EXP_FIX_SKIP
+#define FMHIP_EXP_FIX_SKIP 0      // timing-only ablation of k_fixup's parts: 1 merged update, 2 hot rows, 4 short columns, 8 long columns
+#endif
 #ifndef FMHIP_EXP_NO_XE_BCAST
 #define FMHIP_EXP_NO_XE_BCAST 0   // timing-only ablation: the value / residual broadcasts of the pipelined walk dropped (results wrong)
 #endif
@@ -629,20 +632,28 @@ __global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
     constexpr int KP = 4 * LPN * J;
     constexpr int SLOTS = kBlock / LPN;
     constexpr int WS = 64 / LPN;
-    if (a.red_bsum && blockIdx.x == gridDim.x - 1) {
-        // the extra last block finishes the residual statistics of this step (saves a launch)
-        __shared__ double sh[3][kBlock / 64];
-        reduce_blocks_body(a.red_bsum, a.red_nblocks, a.red_rows, a.red_scal, a.red_acc, sh, a.red_w0, a.red_eta, a.red_reg0);
-        return;
+    // Block 0 (when asked for) finishes the residual statistics of this step (saves a launch).  It is one workgroup walking
+    // the forward's per-block partials — a serial chain of loads — so it goes out FIRST and runs beside everything else;
+    // as the last block it was the tail of the launch (k = 16, whose forward leaves 7,813 partials: +7 us).
+    int bx = (int)blockIdx.x;
+    const int nbx = (int)gridDim.x - (a.red_bsum ? 1 : 0);
+    if (a.red_bsum) {
+        if (bx == 0) {
+            __shared__ double sh[3][kBlock / 64];
+            reduce_blocks_body(a.red_bsum, a.red_nblocks, a.red_rows, a.red_scal, a.red_acc, sh, a.red_w0, a.red_eta, a.red_reg0);
+            return;
+        }
+        bx -= 1;
     }
-    // merged finish: fin_blocks workgroups in front of the statistics block update every parameter row the fixup part
+    // merged finish: the last fin_blocks workgroups update every parameter row the fixup part
     // does not own (those update themselves, straight from registers) — bandwidth-bound work beside latency-bound work
-    const int fin0 = (int)gridDim.x - (a.red_bsum ? 1 : 0) - a.fin_blocks;
-    if (a.fin_blocks > 0 && (int)blockIdx.x >= fin0) {
+    const int fin0 = nbx - a.fin_blocks;
+    if (a.fin_blocks > 0 && bx >= fin0) {
+        if (FMHIP_EXP_FIX_SKIP & 1) return;
         constexpr int LPR = KP / 4;
         const ApplyArgs &f = a.fin;
         const int64_t total = (f.row_hi - f.row_lo) * LPR;
-        for (int64_t idx = (int64_t)((int)blockIdx.x - fin0) * kBlock + threadIdx.x; idx < total; idx += (int64_t)a.fin_blocks * kBlock) {
+        for (int64_t idx = (int64_t)(bx - fin0) * kBlock + threadIdx.x; idx < total; idx += (int64_t)a.fin_blocks * kBlock) {
             const int64_t i = f.row_lo + idx / LPR;
             if (i < a.fin_own_bits && (a.fin_own[i >> 5] >> (i & 31) & 1u)) continue;
             apply_piece<KP, false>(f, i, (int)(idx % LPR), f.invb_val);
@@ -652,8 +663,9 @@ __global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
     if (HOT) {
         // one more workgroup per hot slot finishes the dense hot block's gradient rows
         const int hot0 = fin0 - a.hot.pages * kHotT;
-        if ((int)blockIdx.x >= hot0) {
-            hot_reduce_body(a.hot, (int)blockIdx.x - hot0, KP, a.fin, a.fin_blocks > 0);
+        if (bx >= hot0) {
+            if (FMHIP_EXP_FIX_SKIP & 2) return;
+            hot_reduce_body(a.hot, bx - hot0, KP, a.fin, a.fin_blocks > 0);
             return;
         }
     }
@@ -664,9 +676,10 @@ __global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
     for (int jj = 0; jj < J; ++jj) acc[jj] = f4zero();
     float sa = 0.f, sb = 0.f;
     const int blocks_short = (a.n_split_short + SLOTS - 1) / SLOTS;
-    if ((int)blockIdx.x < blocks_short) {
+    if (bx < blocks_short) {
         // ---- one slot per short column
-        const int idx = blockIdx.x * SLOTS + threadIdx.x / LPN;
+        if (FMHIP_EXP_FIX_SKIP & 4) return;
+        const int idx = bx * SLOTS + threadIdx.x / LPN;
         if (idx >= a.n_split_short) return;
         const int seg = a.split_short[idx];
         const ColumnUnits<LPN, J> cu(a.cptr[seg], a.cptr[seg + 1], a.no_wave_sum != 0);
@@ -685,8 +698,8 @@ __global__ __launch_bounds__(kBlock) void k_fixup(BwdArgs a) {
     // slot; slots tree-summed inside each wave, the 4 wave sums added in wave order through LDS
     const int ws = lane / LPN;
     const int wv = threadIdx.x >> 6;
-    const int idx = (int)blockIdx.x - blocks_short;
-    if (idx >= a.n_split) return;
+    const int idx = bx - blocks_short;
+    if (idx >= a.n_split || (FMHIP_EXP_FIX_SKIP & 8)) return;
     const int seg = a.split_seg[idx];
     const ColumnUnits<LPN, J> cu(a.cptr[seg], a.cptr[seg + 1], a.no_wave_sum != 0);
     constexpr int STRIDE = (kBlock / 64) * WS;

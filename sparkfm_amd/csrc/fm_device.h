@@ -216,8 +216,17 @@ __device__ __forceinline__ void reduce_blocks_body(const double *bsum, int32_t n
                                                    double *acc, double (*sh)[kBlock / 64], float *w0 = nullptr, float eta = 0.f,
                                                    float reg0 = 0.f) {
     double s1 = 0.0, s2 = 0.0, bad = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += kBlock) {
-        const double4 b = reinterpret_cast<const double4 *>(bsum)[i];
+    const double4 *b4 = reinterpret_cast<const double4 *>(bsum);
+    int i = threadIdx.x;
+    for (; i + 3 * kBlock < nblocks; i += 4 * kBlock) {   // four loads in flight; added in index order
+        const double4 b0 = b4[i], b1 = b4[i + kBlock], b2 = b4[i + 2 * kBlock], b3 = b4[i + 3 * kBlock];
+        s1 += b0.x; s2 += b0.y; bad += b0.z;
+        s1 += b1.x; s2 += b1.y; bad += b1.z;
+        s1 += b2.x; s2 += b2.y; bad += b2.z;
+        s1 += b3.x; s2 += b3.y; bad += b3.z;
+    }
+    for (; i < nblocks; i += kBlock) {
+        const double4 b = b4[i];
         s1 += b.x;
         s2 += b.y;
         bad += b.z;
