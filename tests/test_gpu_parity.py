@@ -564,6 +564,46 @@ def test_single_nonzero_rows_have_exactly_zero_interaction(fmhip):
     fm.close()
 
 
+@pytest.mark.parametrize("k,flat", [(16, 0), (32, 0), (32, 1), (64, 0), (100, 0)])
+def test_row_lengths_around_the_step_boundaries(fmhip, k, flat):
+    """The forward walks a row 8 (k <= 64) or 16 entries per step; through a buffer view the row's last, partial step is a
+    full step whose dead entries are id -1 with value 0, and the next step's entries are requested a step ahead; flat
+    addresses (forced here with tuning key 8) keep the masked last step.  Rows of every length 0..40 — each boundary from
+    both sides, several times over, in a persistent grid that gives a slot more than one row — predict like the oracle,
+    and the one-entry rows are exactly linear (quirk Q6)."""
+    rng = np.random.default_rng(40 + k)
+    n_rows, n1 = 41 * 60, 300
+    lens = np.tile(np.arange(41), 60)
+    rng.shuffle(lens)
+    row_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    col = np.concatenate([rng.choice(n1, size=n, replace=False) for n in lens]).astype(np.int32)
+    val = np.where(rng.random(len(col)) < 0.5, 1.0, rng.uniform(0.1, 1.0, len(col)))
+    a = dict(k=k, n1=n1, w0=0.3, w=rng.normal(0, 0.1, n1), v=rng.normal(0, 0.1, (k, n1)), row_ptr=row_ptr, col=col, val=val,
+             y=rng.normal(0, 1.0, n_rows))
+    from sparkfm_amd import _ffi
+    L = _ffi.load()
+    if flat:
+        L.fmhip_tune(8, 1)
+    try:
+        ds, fm = make(fmhip, a, batch_rows=1300)               # two batches: the dense hot block may form, too
+        yh = fm.predict(ds)
+        oyh = oracle.predict(a["w0"], a["w"], a["v"], row_ptr, col, val)
+        assert (np.abs(yh - oyh) <= TOL_Y * term_scale(a)).all()
+        assert (yh[lens == 0] == np.float32(0.3)).all()
+        one = np.flatnonzero(lens == 1)
+        lin = np.float32(0.3) + a["w"].astype(np.float32)[col[row_ptr[one]]] * val[row_ptr[one]].astype(np.float32)
+        np.testing.assert_array_equal(yh[one].astype(np.float32), lin.astype(np.float32))
+        gv, gw, g0, st = fm.batchGradient(ds, 1)
+        ogv, ogw, og0, osse, oe = oracle.batch_grad(a["w0"], a["w"], a["v"], 1300, n_rows, row_ptr, col, val, a["y"])
+        check_grad(gv, gw, ogv, ogw, np.abs(a["v"]).max())
+        assert st["sse"] == pytest.approx(osse, rel=1e-5) and st["rows"] == n_rows - 1300
+        ds.unpersist()
+        fm.close()
+    finally:
+        if flat:
+            L.fmhip_tune(8, 0)
+
+
 def test_hot_columns_split_over_many_ranges(fmhip):
     """Power-law columns: 3 features present in every row (columns of 4000 entries = 63 ranges
     each) next to a long tail of 1-2 entry columns."""
