@@ -816,8 +816,9 @@ hipError_t bwd_dispatch(const BwdArgs &a, hipStream_t s) {
     // the pipelined kernel needs P to fit a 32-bit buffer view (< 4 GiB per batch); for k > 64 (J > 1)
     // its register footprint spills, so those sizes take the plain walk
     const bool pipe = J == 1 && a.p_bytes && a.pipelined == 1;
+    static const size_t lds_pad = getenv("FMHIP_BWD_LDS_PAD") ? (size_t)atol(getenv("FMHIP_BWD_LDS_PAD")) : 0;   // experiment: fewer resident workgroups
 #define FMHIP_BW(PACKED_, HOT_)                                                               \
-    if (pipe) hipLaunchKernelGGL((k_backward_p<LPN, J, PACKED_, HOT_>), g, b, 0, s, a2);      \
+    if (pipe) hipLaunchKernelGGL((k_backward_p<LPN, J, PACKED_, HOT_>), g, b, lds_pad, s, a2); \
     else hipLaunchKernelGGL((k_backward<LPN, J, PACKED_, HOT_>), g, b, 0, s, a2)
     if (a.pack_k >= 0) {
         if (a.hot_blocks > 0) { FMHIP_BW(true, true); } else { FMHIP_BW(true, false); }
