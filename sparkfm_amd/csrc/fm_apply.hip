@@ -141,7 +141,7 @@ hipError_t launch_apply_shard(int Kp, const ApplyArgs &a, hipStream_t s) {
 }
 
 hipError_t launch_apply(int Kp, const ApplyArgs &a, hipStream_t s) {
-    const bool rows_only = a.feat != nullptr;
+    const bool rows_only = a.rows_only != 0;
     int64_t total = (rows_only ? (int64_t)a.n_feat + a.n_hot : a.row_hi - a.row_lo) * (Kp / 4);
     int64_t blocks = (total + kBlock - 1) / kBlock;
     if (blocks > 8192) blocks = 8192;

@@ -111,6 +111,8 @@ struct ApplyArgs {
     // uses eta_v = eta / that (eta_w likewise) as its step on the stored values
     float sv_in, sw_in, eta_v, eta_w;
     // rows-only variant (feat != NULL): just the listed distinct features and the hot block's ids
+    int32_t rows_only;       // 1: update only the rows in feat[] and hot_ids[] (k_apply_rows; decay rides in the tables' scale) — stated, not
+                             // inferred from feat: a batch whose features all sit in the dense hot block has n_feat = 0 and may have feat = NULL
     const int32_t *feat;     // [n_feat] distinct feature ids of the batch
     int32_t n_feat;
     const int32_t *hot_ids;  // [n_hot], -1 = unused

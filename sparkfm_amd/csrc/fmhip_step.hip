@@ -427,6 +427,7 @@ int step_apply(fmhip_model_t m, double eta, double reg0, double regw, double reg
         const BatchMeta &bm = d->batches[(size_t)b];
         const int64_t touched = (int64_t)bm.n_cols + d->hot_pages * kHotT;
         if (touched * 2 <= m->n1) {     // otherwise the dense, perfectly coalesced pass is as cheap
+            a.rows_only = 1;
             a.feat = d->cfeat.p + bm.col_off;
             a.n_feat = bm.n_cols;
             a.hot_ids = d->d_hot_ids.p;
@@ -558,6 +559,7 @@ int step_apply_rows(fmhip_model_t m, double eta, double reg0, double regw, doubl
     ApplyArgs a{};
     a.sv_in = (float)m->sv;
     a.sw_in = (float)m->sw;
+    a.rows_only = 1;
     a.feat = feat;
     a.n_feat = n_feat;
     a.hot_ids = nullptr;

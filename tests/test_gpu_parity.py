@@ -55,10 +55,11 @@ def term_scale(a):
     return out
 
 
-def check_grad(gv, gw, ogv, ogw, vmax=1.0):
+def check_grad(gv, gw, ogv, ogw, vmax=1.0, cancelled=0.0):
     # the V gradient is a difference of two sums (sum e*x*q  -  v * sum e*x^2) that can cancel
-    # exactly (single-nonzero rows): the floor is set by the size of the cancelled terms
-    scale = max(np.abs(ogv).max(), np.abs(ogw).max() * vmax, 1e-6)
+    # exactly (single-nonzero rows): the floor is set by the size of the cancelled terms — `cancelled` = max over the
+    # features of sum |e*x| (when the caller has the residuals), else the signed sums in ogw stand in for it
+    scale = max(np.abs(ogv).max(), np.abs(ogw).max() * vmax, cancelled * vmax, 1e-6)
     rowmax = np.maximum(np.abs(ogv).max(axis=0), 1e-3 * scale)
     assert (np.abs(gv - ogv) <= TOL_G * rowmax[None, :]).all(), float((np.abs(gv - ogv) / rowmax[None, :]).max())
     np.testing.assert_allclose(gw, ogw, rtol=TOL_G, atol=TOL_G * max(np.abs(ogw).max(), 1e-6))
@@ -720,6 +721,34 @@ def test_rows_only_apply_for_wide_models(fmhip, k):
     fm2.close()
 
 
+@pytest.mark.parametrize("k", [2, 8, 32])
+def test_rows_only_update_when_every_feature_sits_in_the_hot_block(fmhip, k):
+    """A dataset whose every feature is dense enough for the hot block has NO sparse columns (n_cols = 0 in every batch, an
+    empty feature list) under a model far wider than the batch touches: the update must still be the rows-only one — the
+    decay of the untouched rows rides in the tables' scale exactly once.  (Found by tools/soak_random_shapes.py: the update
+    kernel was chosen by `feat != NULL`, an empty list was NULL, the dense pass applied the decay and the host scaled the
+    tables as well — every parameter decayed twice, then three times, ...)"""
+    rng = np.random.default_rng(5)
+    n_rows, n1, feats = 40, 700, rng.choice(700, size=30, replace=False).astype(np.int32)
+    row_ptr = np.arange(n_rows + 1, dtype=np.int64) * 30
+    col = np.concatenate([rng.permutation(feats) for _ in range(n_rows)]).astype(np.int32)
+    val = rng.uniform(0.1, 1.0, len(col))
+    a = dict(k=k, n1=n1, w0=0.1, w=rng.normal(0, 0.1, n1), v=rng.normal(0, 0.1, (k, n1)), row_ptr=row_ptr, col=col, val=val,
+             y=rng.normal(0, 1.0, n_rows))
+    ds, fm = make(fmhip, a, batch_rows=10)
+    lay = ds.layout()
+    assert len([i for i in lay["hot_ids_all"] if i >= 0]) == 30 and lay["nnz_sparse_backward"] == 0   # all thirty features are in the block: no transposes left
+    eta, regs = 0.01, (0.01, 0.01, 0.01)
+    fmhip.HipSGD(eta=eta, reg0=regs[0], regw=regs[1], regv=regs[2]).learn(fm, ds)
+    w0, w, v, sse = oracle.sgd_epoch(a["w0"], a["w"], a["v"], 10, row_ptr, col, val, a["y"], eta, *regs)
+    untouched = np.setdiff1d(np.arange(n1), feats)
+    np.testing.assert_allclose(fm.v[:, untouched], a["v"][:, untouched] * (1 - eta * regs[2]) ** 4, rtol=2e-6)   # four steps of decay, once each
+    assert np.linalg.norm(fm.v - v) <= 1e-5 * np.linalg.norm(v)
+    assert np.linalg.norm(fm.w - w) <= 1e-5 * max(np.linalg.norm(w), 1e-9)
+    ds.unpersist()
+    fm.close()
+
+
 def test_batch_order_and_determinism(fmhip):
     a = random_problem(61, 1500, 300, 16, 1, 20)
     outs = []
@@ -1049,16 +1078,16 @@ def test_random_shapes_property(fmhip, flat):
         L.fmhip_tune(8, 0)
 
 
-def _random_shapes(fmhip, L):
-    rng = np.random.default_rng(20261003)
-    for case in range(40):
+def _random_shapes(fmhip, L, seed=20261003, cases=40):
+    rng = np.random.default_rng(seed)
+    for case in range(cases):
         k = int(rng.choice([1, 2, 5, 8, 13, 16, 32, 40, 64]))
         n_rows = int(rng.integers(1, 1200))
         n1 = int(rng.integers(2, 400)) if case < 24 else int(rng.integers(400, 6000))   # wide models: rows-only update
         hi = int(rng.integers(1, min(n1, 70) + 1))
         lo = int(rng.integers(0, hi + 1))
         batch_rows = int(rng.choice([0, 1, 7, 64, 300, 5000]))
-        a = random_problem(1000 + case, n_rows, n1, k, lo, hi, empty_rows=tuple(rng.integers(0, n_rows, 2).tolist()))
+        a = random_problem(1000 + case + (seed - 20261003) * 1000, n_rows, n1, k, lo, hi, empty_rows=tuple(rng.integers(0, n_rows, 2).tolist()))
         if case % 3 == 0 and len(a["col"]):                          # a few dominating features
             hot = rng.integers(0, n1, 2)
             for r in range(n_rows):
@@ -1078,8 +1107,14 @@ def _random_shapes(fmhip, L):
         r0, r1 = bi["row0"], bi["row0"] + bi["rows"]
         assert bi["nnz"] == a["row_ptr"][r1] - a["row_ptr"][r0], case
         gv, gw, g0, st = fm.batchGradient(ds, b)
-        ogv, ogw, og0, osse, _ = oracle.batch_grad(a["w0"], a["w"], a["v"], r0, r1, a["row_ptr"], a["col"], a["val"], a["y"])
-        check_grad(gv, gw, ogv, ogw, np.abs(a["v"]).max())
+        ogv, ogw, og0, osse, oe = oracle.batch_grad(a["w0"], a["w"], a["v"], r0, r1, a["row_ptr"], a["col"], a["val"], a["y"])
+        p0, p1 = int(a["row_ptr"][r0]), int(a["row_ptr"][r1])
+        absw = np.zeros(n1)
+        np.add.at(absw, a["col"][p0:p1], np.abs(np.repeat(np.asarray(oe), np.diff(a["row_ptr"][r0:r1 + 1])) * a["val"][p0:p1]))
+        try:
+            check_grad(gv, gw, ogv, ogw, np.abs(a["v"]).max(), cancelled=float(absw.max()) if len(absw) else 0.0)
+        except AssertionError as e:
+            raise AssertionError("case %d seed %d: k=%d rows=%d n1=%d nnz/row %d..%d batch_rows=%d batch %d: %s" % (case, seed, k, n_rows, n1, lo, hi, batch_rows, b, e))
         # sse = sum e^2 with |de| <= TOL_Y * O(1) per row  =>  |d sse| <= 2 * TOL_Y * sqrt(rows * sse)  (a single row
         # whose prediction nearly equals its label has a tiny e and a large RELATIVE error in e^2)
         assert st["rows"] == r1 - r0, case

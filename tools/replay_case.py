@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Replays one case of the random-shapes property test (tests/test_gpu_parity.py: _random_shapes) and prints where the GPU's
+SGD epoch leaves the oracle's.   python3 tools/replay_case.py SEED CASE [flat]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle  # noqa: E402
+import sparkfm_amd as fmhip  # noqa: E402
+from helpers import random_problem  # noqa: E402
+from sparkfm_amd import _ffi  # noqa: E402
+from test_gpu_parity import make  # noqa: E402
+
+seed, want = int(sys.argv[1]), int(sys.argv[2])
+L = _ffi.load()
+L.fmhip_tune(8, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
+rng = np.random.default_rng(seed)
+for case in range(want + 1):
+    k = int(rng.choice([1, 2, 5, 8, 13, 16, 32, 40, 64]))
+    n_rows = int(rng.integers(1, 1200))
+    n1 = int(rng.integers(2, 400)) if case < 24 else int(rng.integers(400, 6000))
+    hi = int(rng.integers(1, min(n1, 70) + 1))
+    lo = int(rng.integers(0, hi + 1))
+    batch_rows = int(rng.choice([0, 1, 7, 64, 300, 5000]))
+    empty = tuple(rng.integers(0, n_rows, 2).tolist())
+    a = random_problem(1000 + case + (seed - 20261003) * 1000, n_rows, n1, k, lo, hi, empty_rows=empty) if case == want else None
+    if case % 3 == 0:
+        hot = rng.integers(0, n1, 2)
+    # (the remaining draws of a case — the batch index — follow dataset creation; they do not matter for the last case)
+    if case < want:
+        # replay the draw of b: needs nb
+        br = batch_rows if batch_rows > 0 else n_rows
+        nb = (n_rows + br - 1) // br
+        rng.integers(0, nb)
+print("case", want, dict(k=k, n_rows=n_rows, n1=n1, lo=lo, hi=hi, batch_rows=batch_rows, empty=empty), "row lengths", np.diff(a["row_ptr"]))
+regs = (0.01, 0.01, 0.01) if want % 4 else (0.0, 0.0, 0.0)
+ds, fm = make(fmhip, a, batch_rows=batch_rows)
+br = ds.info()["batch_rows"]
+eta = 0.02 if br >= 64 else 0.001
+sgd = fmhip.HipSGD(eta=eta, reg0=regs[0], regw=regs[1], regv=regs[2])
+sgd.learn(fm, ds)
+w0, w, v, sse = oracle.sgd_epoch(a["w0"], a["w"], a["v"], br, a["row_ptr"], a["col"], a["val"], a["y"], eta, *regs)
+dv = np.abs(fm.v - v)
+print("regs", regs, "eta", eta, "|dv| max", dv.max(), "norm", np.linalg.norm(fm.v - v), "of", np.linalg.norm(v), "w0", fm.w0, w0)
+bad = np.argwhere(dv > 1e-6)
+print("entries off by > 1e-6:", len(bad), bad[:10].tolist(), "features in the data:", sorted(set(a["col"].tolist()))[:20])
+for f_, i in bad[:6]:
+    print("  v[%d,%d]: gpu %.9g oracle %.9g initial %.9g" % (f_, i, fm.v[f_, i], v[f_, i], a["v"][f_, i]))
