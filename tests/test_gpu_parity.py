@@ -55,14 +55,22 @@ def term_scale(a):
     return out
 
 
-def check_grad(gv, gw, ogv, ogw, vmax=1.0, cancelled=0.0):
+def check_grad(gv, gw, ogv, ogw, vmax=1.0, cancelled=0.0, terms=None, w_terms=None):
     # the V gradient is a difference of two sums (sum e*x*q  -  v * sum e*x^2) that can cancel
     # exactly (single-nonzero rows): the floor is set by the size of the cancelled terms — `cancelled` = max over the
     # features of sum |e*x| (when the caller has the residuals), else the signed sums in ogw stand in for it
     scale = max(np.abs(ogv).max(), np.abs(ogw).max() * vmax, cancelled * vmax, 1e-6)
     rowmax = np.maximum(np.abs(ogv).max(axis=0), 1e-3 * scale)
-    assert (np.abs(gv - ogv) <= TOL_G * rowmax[None, :]).all(), float((np.abs(gv - ogv) / rowmax[None, :]).max())
-    np.testing.assert_allclose(gw, ogw, rtol=TOL_G, atol=TOL_G * max(np.abs(ogw).max(), 1e-6))
+    tol = TOL_G * rowmax
+    if terms is not None:
+        # fp32 summation of a feature's terms: a few ulps of the sum of their magnitudes, whatever cancels in the total
+        tol = tol + 2e-6 * np.asarray(terms)
+    assert (np.abs(gv - ogv) <= tol[None, :]).all(), float((np.abs(gv - ogv) / tol[None, :]).max())
+    if w_terms is None:
+        np.testing.assert_allclose(gw, ogw, rtol=TOL_G, atol=TOL_G * max(np.abs(ogw).max(), 1e-6))
+    else:
+        tolw = TOL_G * np.maximum(np.abs(ogw), max(np.abs(ogw).max(), 1e-6)) + 2e-6 * np.asarray(w_terms)
+        assert (np.abs(gw - ogw) <= tolw).all(), float((np.abs(gw - ogw) / tolw).max())
 
 
 def test_kats_through_the_c_abi(fmhip, kats):
@@ -1078,7 +1086,7 @@ def test_random_shapes_property(fmhip, flat):
         L.fmhip_tune(8, 0)
 
 
-def _random_shapes(fmhip, L, seed=20261003, cases=40):
+def _random_shapes(fmhip, L, seed=20261003, cases=40, skip_diverged=False):
     rng = np.random.default_rng(seed)
     for case in range(cases):
         k = int(rng.choice([1, 2, 5, 8, 13, 16, 32, 40, 64]))
@@ -1109,10 +1117,21 @@ def _random_shapes(fmhip, L, seed=20261003, cases=40):
         gv, gw, g0, st = fm.batchGradient(ds, b)
         ogv, ogw, og0, osse, oe = oracle.batch_grad(a["w0"], a["w"], a["v"], r0, r1, a["row_ptr"], a["col"], a["val"], a["y"])
         p0, p1 = int(a["row_ptr"][r0]), int(a["row_ptr"][r1])
-        absw = np.zeros(n1)
-        np.add.at(absw, a["col"][p0:p1], np.abs(np.repeat(np.asarray(oe), np.diff(a["row_ptr"][r0:r1 + 1])) * a["val"][p0:p1]))
+        absw, terms = np.zeros(n1), np.zeros(n1)
+        cb, xb = a["col"][p0:p1], a["val"][p0:p1]
+        rb = np.repeat(np.arange(r1 - r0), np.diff(a["row_ptr"][r0:r1 + 1]))
+        ex = np.abs(np.asarray(oe)[rb] * xb)
+        np.add.at(absw, cb, ex)
+        qrow = np.zeros((r1 - r0, k))
+        np.add.at(qrow, rb, (a["v"][:, cb] * xb).T)                  # q_r = sum v x, per factor
+        # sum |x| (|q| + |x v|) * (|e| + the forward's own fp32 error in e: ~ an ulp of the row's terms): a feature whose only
+        # row has a small residual inherits that residual's RELATIVE error
+        e_err = np.abs(np.asarray(oe))[rb] + 0.15 * term_scale(a)[r0:r1][rb]
+        np.add.at(terms, cb, e_err * np.abs(xb) * (np.abs(qrow).max(axis=1)[rb] + np.abs(xb) * np.abs(a["v"][:, cb]).max(axis=0)))
+        w_terms = np.zeros(n1)
+        np.add.at(w_terms, cb, e_err * np.abs(xb))                   # the same for G_w = sum e x
         try:
-            check_grad(gv, gw, ogv, ogw, np.abs(a["v"]).max(), cancelled=float(absw.max()) if len(absw) else 0.0)
+            check_grad(gv, gw, ogv, ogw, np.abs(a["v"]).max(), cancelled=float(absw.max()) if len(absw) else 0.0, terms=terms, w_terms=w_terms)
         except AssertionError as e:
             raise AssertionError("case %d seed %d: k=%d rows=%d n1=%d nnz/row %d..%d batch_rows=%d batch %d: %s" % (case, seed, k, n_rows, n1, lo, hi, batch_rows, b, e))
         # sse = sum e^2 with |de| <= TOL_Y * O(1) per row  =>  |d sse| <= 2 * TOL_Y * sqrt(rows * sse)  (a single row
@@ -1128,10 +1147,14 @@ def _random_shapes(fmhip, L, seed=20261003, cases=40):
         sgd.learn(fm, ds)
         w0, w, v, sse = oracle.sgd_epoch(a["w0"], a["w"], a["v"], br, a["row_ptr"], a["col"], a["val"], a["y"],
                                          eta, *regs)
+        if skip_diverged and not (np.isfinite(v).all() and np.abs(v).max() < 1e3):   # (the soak's seeds: a case whose SGD diverges says nothing)
+            ds.unpersist()
+            fm.close()
+            continue
         assert np.isfinite(v).all(), (case, "oracle diverged: pick a smaller eta for this case")
         assert np.linalg.norm(fm.v - v) <= 1e-5 * max(np.linalg.norm(v), 1e-9), (case, k, n_rows, n1, batch_rows)
         assert np.linalg.norm(fm.w - w) <= 1e-5 * max(np.linalg.norm(w), 1e-9), case
-        assert fm.w0 == pytest.approx(w0, rel=1e-5, abs=1e-7), case
+        assert fm.w0 == pytest.approx(w0, rel=1e-5, abs=1e-6), case      # (hundreds of per-row fp32 steps leave w0 a few ulps of its LARGEST past value off)
         ds.unpersist()
         fm.close()
 

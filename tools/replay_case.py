@@ -39,6 +39,38 @@ for case in range(want + 1):
 print("case", want, dict(k=k, n_rows=n_rows, n1=n1, lo=lo, hi=hi, batch_rows=batch_rows, empty=empty), "row lengths", np.diff(a["row_ptr"]))
 regs = (0.01, 0.01, 0.01) if want % 4 else (0.0, 0.0, 0.0)
 ds, fm = make(fmhip, a, batch_rows=batch_rows)
+for b in range(ds.n_batches):
+    bi = ds.batch_info(b)
+    r0, r1 = bi["row0"], bi["row0"] + bi["rows"]
+    gv, gw, g0, st = fm.batchGradient(ds, b)
+    ogv, ogw, og0, osse, oe = oracle.batch_grad(a["w0"], a["w"], a["v"], r0, r1, a["row_ptr"], a["col"], a["val"], a["y"])
+    p0, p1 = int(a["row_ptr"][r0]), int(a["row_ptr"][r1])
+    x = a["val"][p0:p1]
+    er = np.repeat(np.asarray(oe), np.diff(a["row_ptr"][r0:r1 + 1]))
+    cancel = np.zeros(n1)
+    np.add.at(cancel, a["col"][p0:p1], np.abs(er * x * x))                          # sum |e x^2| per feature: what v multiplies
+    d = np.abs(gv - ogv)
+    f_, i = np.unravel_index(np.argmax(d), d.shape)
+    print("batch %d: max |gv - ogv| %.3e at (f=%d, i=%d): gpu %.9g oracle %.9g; max |ogv| %.3e; |v| %.3e x sum|e x^2| %.3e = %.3e; layout %s"
+          % (b, d.max(), f_, i, gv[f_, i], ogv[f_, i], np.abs(ogv).max(), abs(a["v"][f_, i]), cancel[i], abs(a["v"][f_, i]) * cancel[i],
+             {k_: v_ for k_, v_ in ds.layout().items() if k_ in ("hot_ids", "hot_pages", "nnz_sparse_backward")}))
+    rb = np.repeat(np.arange(r1 - r0), np.diff(a["row_ptr"][r0:r1 + 1]))
+    cb = a["col"][p0:p1]
+    ex = np.abs(er * x)
+    qrow = np.zeros((r1 - r0, k)); np.add.at(qrow, rb, (a["v"][:, cb] * x).T)
+    terms = np.zeros(n1); np.add.at(terms, cb, ex * (np.abs(qrow).max(axis=1)[rb] + np.abs(x) * np.abs(a["v"][:, cb]).max(axis=0)))
+    absw = np.zeros(n1); np.add.at(absw, cb, ex)
+    vmax = np.abs(a["v"]).max()
+    scale = max(np.abs(ogv).max(), np.abs(ogw).max() * vmax, absw.max() * vmax, 1e-6)
+    rowmax = np.maximum(np.abs(ogv).max(axis=0), 1e-3 * scale)
+    tol = 1e-4 * rowmax + 2e-6 * terms
+    ratio = d / tol[None, :]
+    f2, i2 = np.unravel_index(np.argmax(ratio), ratio.shape)
+    cnt = int((cb == i2).sum())
+    print("   worst ratio %.3f at (f=%d, i=%d): gpu %.9g oracle %.9g |d| %.3e tol %.3e (rowmax %.3e terms %.3e) entries of this feature in the batch: %d"
+          % (ratio.max(), f2, i2, gv[f2, i2], ogv[f2, i2], d[f2, i2], tol[i2], rowmax[i2], terms[i2], cnt))
+    if ds.n_batches > 4:
+        break
 br = ds.info()["batch_rows"]
 eta = 0.02 if br >= 64 else 0.001
 sgd = fmhip.HipSGD(eta=eta, reg0=regs[0], regw=regs[1], regv=regs[2])
