@@ -1086,10 +1086,10 @@ def test_random_shapes_property(fmhip, flat):
         L.fmhip_tune(8, 0)
 
 
-def _random_shapes(fmhip, L, seed=20261003, cases=40, skip_diverged=False):
+def _random_shapes(fmhip, L, seed=20261003, cases=40, skip_diverged=False, ks=(1, 2, 5, 8, 13, 16, 32, 40, 64)):
     rng = np.random.default_rng(seed)
     for case in range(cases):
-        k = int(rng.choice([1, 2, 5, 8, 13, 16, 32, 40, 64]))
+        k = int(rng.choice(list(ks)))
         n_rows = int(rng.integers(1, 1200))
         n1 = int(rng.integers(2, 400)) if case < 24 else int(rng.integers(400, 6000))   # wide models: rows-only update
         hi = int(rng.integers(1, min(n1, 70) + 1))
@@ -1152,9 +1152,17 @@ def _random_shapes(fmhip, L, seed=20261003, cases=40, skip_diverged=False):
             fm.close()
             continue
         assert np.isfinite(v).all(), (case, "oracle diverged: pick a smaller eta for this case")
-        assert np.linalg.norm(fm.v - v) <= 1e-5 * max(np.linalg.norm(v), 1e-9), (case, k, n_rows, n1, batch_rows)
-        assert np.linalg.norm(fm.w - w) <= 1e-5 * max(np.linalg.norm(w), 1e-9), case
-        assert fm.w0 == pytest.approx(w0, rel=1e-5, abs=1e-6), case      # (hundreds of per-row fp32 steps leave w0 a few ulps of its LARGEST past value off)
+        slack = 0.0
+        if skip_diverged:
+            # the soak's seeds include nearly divergent trainings that amplify ANY rounding a thousandfold (k = 100, 60 entries
+            # per row, eta 0.02: an initial perturbation of 1e-8 is 3e-5 after 15 steps): measure the case's own sensitivity —
+            # the same fp64 epoch on the inputs rounded to fp32, which is what the GPU is given — and allow a multiple of it
+            r32 = lambda x: np.asarray(x, np.float64).astype(np.float32).astype(np.float64)
+            _, _, v32, _ = oracle.sgd_epoch(float(r32(a["w0"])), r32(a["w"]), r32(a["v"]), br, a["row_ptr"], a["col"], r32(a["val"]), r32(a["y"]), eta, *regs)
+            slack = 30.0 * float(np.linalg.norm(v32 - v)) if np.isfinite(v32).all() else float("inf")
+        assert np.linalg.norm(fm.v - v) <= 1e-5 * max(np.linalg.norm(v), 1e-9) + slack, (case, k, n_rows, n1, batch_rows)
+        assert np.linalg.norm(fm.w - w) <= 1e-5 * max(np.linalg.norm(w), 1e-9) + slack, case
+        assert fm.w0 == pytest.approx(w0, rel=1e-5, abs=1e-6 + slack), case      # (hundreds of per-row fp32 steps leave w0 a few ulps of its LARGEST past value off)
         ds.unpersist()
         fm.close()
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Replays one case of the random-shapes property test (tests/test_gpu_parity.py: _random_shapes) and prints where the GPU's
-SGD epoch leaves the oracle's.   python3 tools/replay_case.py SEED CASE [flat]"""
+SGD epoch leaves the oracle's.   python3 tools/replay_case.py SEED CASE [flat] [k values]"""
 import os
 import sys
 
@@ -16,11 +16,12 @@ from sparkfm_amd import _ffi  # noqa: E402
 from test_gpu_parity import make  # noqa: E402
 
 seed, want = int(sys.argv[1]), int(sys.argv[2])
+ks = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [1, 2, 5, 8, 13, 16, 32, 40, 64]
 L = _ffi.load()
 L.fmhip_tune(8, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
 rng = np.random.default_rng(seed)
 for case in range(want + 1):
-    k = int(rng.choice([1, 2, 5, 8, 13, 16, 32, 40, 64]))
+    k = int(rng.choice(ks))
     n_rows = int(rng.integers(1, 1200))
     n1 = int(rng.integers(2, 400)) if case < 24 else int(rng.integers(400, 6000))
     hi = int(rng.integers(1, min(n1, 70) + 1))
@@ -30,6 +31,11 @@ for case in range(want + 1):
     a = random_problem(1000 + case + (seed - 20261003) * 1000, n_rows, n1, k, lo, hi, empty_rows=empty) if case == want else None
     if case % 3 == 0:
         hot = rng.integers(0, n1, 2)
+        if case == want and len(a["col"]):                           # a few dominating features, as the test makes them
+            for r in range(n_rows):
+                s_ = slice(a["row_ptr"][r], a["row_ptr"][r + 1])
+                if s_.stop - s_.start >= 2 and not np.isin(hot, a["col"][s_]).any():
+                    a["col"][s_.start] = hot[0]
     # (the remaining draws of a case — the batch index — follow dataset creation; they do not matter for the last case)
     if case < want:
         # replay the draw of b: needs nb
@@ -38,7 +44,13 @@ for case in range(want + 1):
         rng.integers(0, nb)
 print("case", want, dict(k=k, n_rows=n_rows, n1=n1, lo=lo, hi=hi, batch_rows=batch_rows, empty=empty), "row lengths", np.diff(a["row_ptr"]))
 regs = (0.01, 0.01, 0.01) if want % 4 else (0.0, 0.0, 0.0)
+for extra in sys.argv[5:]:                                           # regs:r0,rw,rv   tune:KEY=VALUE (per model, after creation)
+    if extra.startswith("regs:"):
+        regs = tuple(float(x) for x in extra[5:].split(","))
 ds, fm = make(fmhip, a, batch_rows=batch_rows)
+for extra in sys.argv[5:]:
+    if extra.startswith("tune:"):
+        _ffi.check(L.fmhip_model_tune(fm.handle, int(extra[5:].split("=")[0]), int(extra.split("=")[1])))
 for b in range(ds.n_batches):
     bi = ds.batch_info(b)
     r0, r1 = bi["row0"], bi["row0"] + bi["rows"]
@@ -82,3 +94,53 @@ bad = np.argwhere(dv > 1e-6)
 print("entries off by > 1e-6:", len(bad), bad[:10].tolist(), "features in the data:", sorted(set(a["col"].tolist()))[:20])
 for f_, i in bad[:6]:
     print("  v[%d,%d]: gpu %.9g oracle %.9g initial %.9g" % (f_, i, fm.v[f_, i], v[f_, i], a["v"][f_, i]))
+
+# is a deviation from the oracle an error or the amplification of fp32 rounding by the training dynamics?  The same epoch with
+# the dense hot block off (another summation order, same arithmetic otherwise): if two GPU runs differ from each other as much
+# as each differs from the oracle, it is the dynamics.
+gpu_v, gpu_w0 = fm.v.copy(), fm.w0
+ds.unpersist(); fm.close()
+L.fmhip_tune(5, 0)
+ds, fm = make(fmhip, a, batch_rows=batch_rows)
+L.fmhip_tune(5, 1)
+fmhip.HipSGD(eta=eta, reg0=regs[0], regw=regs[1], regv=regs[2]).learn(fm, ds)
+print("hot block off: |v - oracle| %.3e, |v - v(hot on)| %.3e (hot on vs oracle: %.3e); w0 %.9g vs %.9g (hot on) vs %.9g (oracle)"
+      % (np.linalg.norm(fm.v - v), np.linalg.norm(fm.v - gpu_v), np.linalg.norm(gpu_v - v), fm.w0, gpu_w0, w0))
+# and the oracle itself in another summation order: rows of each batch reversed (fp64: the difference shows the conditioning)
+
+# where does a hot-block deviation enter: predictions and the first batch's gradient at the INITIAL parameters, block on / off
+for hot_on in (1, 0):
+    ds.unpersist(); fm.close()
+    L.fmhip_tune(5, hot_on)
+    ds, fm = make(fmhip, a, batch_rows=batch_rows)
+    L.fmhip_tune(5, 1)
+    yh = fm.predict(ds)
+    oy = oracle.predict(a["w0"], a["w"], a["v"], a["row_ptr"], a["col"], a["val"])
+    bi = ds.batch_info(0)
+    gv, gw, g0, st = fm.batchGradient(ds, 0)
+    ogv, ogw, og0, osse, oe = oracle.batch_grad(a["w0"], a["w"], a["v"], 0, bi["rows"], a["row_ptr"], a["col"], a["val"], a["y"])
+    print("hot %d: yhat rel-L2 err %.2e (max abs %.2e of |y|max %.2e); G_V rel-L2 %.2e, G_w rel-L2 %.2e, G_w0 %.9g vs %.9g, sse %.9g vs %.9g; dense ids %d"
+          % (hot_on, np.linalg.norm(yh - oy) / np.linalg.norm(oy), np.abs(yh - oy).max(), np.abs(oy).max(), np.linalg.norm(gv - ogv) / np.linalg.norm(ogv),
+             np.linalg.norm(gw - ogw) / np.linalg.norm(ogw), g0, og0, st["sse"], osse, len([i for i in ds.layout()["hot_ids_all"] if i >= 0])))
+
+# ... and batch by batch (a ragged last batch, batches the hot features are absent from)
+ds.unpersist(); fm.close()
+ds, fm = make(fmhip, a, batch_rows=batch_rows)
+errs = []
+for b in range(ds.n_batches):
+    bi = ds.batch_info(b)
+    r0, r1 = bi["row0"], bi["row0"] + bi["rows"]
+    gv, gw, g0, st = fm.batchGradient(ds, b)
+    ogv, ogw, og0, osse, oe = oracle.batch_grad(a["w0"], a["w"], a["v"], r0, r1, a["row_ptr"], a["col"], a["val"], a["y"])
+    errs.append((b, bi["rows"], float(np.linalg.norm(gv - ogv) / max(np.linalg.norm(ogv), 1e-30)), float(np.linalg.norm(gw - ogw) / max(np.linalg.norm(ogw), 1e-30)), abs(g0 - og0)))
+print("per batch (rows, G_V rel err, G_w rel err, |dG_w0|):", [(b, r, "%.1e" % e1, "%.1e" % e2, "%.1e" % e3) for b, r, e1, e2, e3 in errs])
+# one step at a time from the same start: after which step does the model leave the oracle?
+ds.unpersist(); fm.close()
+ds, fm = make(fmhip, a, batch_rows=batch_rows)
+w0o, wo, vo = a["w0"], a["w"], a["v"]
+for b in range(ds.n_batches):
+    bi = ds.batch_info(b)
+    _ffi.check(L.fmhip_sgd_step(fm.handle, ds.handle, b, eta, regs[0], regs[1], regs[2], None))
+    fm._device_updated()
+    w0o, wo, vo, _ = oracle.sgd_step(w0o, wo, vo, bi["row0"], bi["row0"] + bi["rows"], a["row_ptr"], a["col"], a["val"], a["y"], eta, *regs)
+    print("after step %d (%d rows): |v - oracle| %.2e  |w - oracle| %.2e  w0 %.9g vs %.9g" % (b, bi["rows"], np.linalg.norm(fm.v - vo), np.linalg.norm(fm.w - wo), fm.w0, w0o))
