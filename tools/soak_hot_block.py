@@ -24,7 +24,7 @@ for seed in range(first, first + n_cases):
     rng = np.random.default_rng(seed)
     k = int(rng.choice([4, 16, 32, 64, 100]))
     n_hot = int(rng.choice([1, 5, 16, 17, 40, 64, 90, 128]))
-    n1 = int(n_hot + rng.choice([10, 300, 5000]))
+    n1 = int(n_hot + rng.choice([5, 10, 300, 5000]))
     n_rows = int(rng.choice([200, 1500, 4000]))
     n_low = int(rng.integers(0, n_hot)) if rng.random() < 0.4 else 0
     dup = int(rng.integers(0, n_hot)) if rng.random() < 0.3 else None
@@ -33,8 +33,14 @@ for seed in range(first, first + n_cases):
     br = int(rng.choice([64, 300, 700]))
     regs = (0.0, float(rng.choice([0.0, 1e-3])), float(rng.choice([0.0, 1e-3])))
     tag = "case %d k=%d hot=%d (low %d, dup %s, zero %s) n1=%d rows=%d batch %d pages %d flat %d regs %s" % (seed, k, n_hot, n_low, dup, zero, n1, n_rows, br, pages, flat, regs)
+    regs = (regs[0], regs[1], float(rng.choice([regs[2], 1e-2])))
     a, hot_ids = hot_problem(9000 + seed, n_rows, n1, k, n_hot, dup, zero, n_low)
     a["val"] = a["val"].astype(np.float32).astype(np.float64)
+    pad = int(rng.choice([0, 0, 600, 6000]))                     # features the data never touch: a model far wider than the batch
+    if pad:                                                      # (with few or no sparse columns left beside the block: the rows-only update's edge)
+        a["n1"] = n1 + pad
+        a["w"] = np.concatenate([a["w"], rng.normal(0, 0.1, pad)])
+        a["v"] = np.concatenate([a["v"], rng.normal(0, 0.1, (k, pad))], axis=1)
     try:
         L.fmhip_tune(8, flat), L.fmhip_tune(5, 1), L.fmhip_tune(12, pages)
         ds, fm = make(fmhip, a, batch_rows=br)
