@@ -33,7 +33,19 @@
  *    a collective of the caller's instead of RCCL.  The packed gradient is also exposed
  *    (fmhip_grad_*) for a host that orchestrates the step itself
  *    (fmhip_step_compute -> host all-reduce -> fmhip_step_apply).
- *  - a handle must not be used from two threads at once.
+ *  - threads.  Different handles are independent: any number of host threads may work on their own models / datasets /
+ *    communicators at once, on one GPU or several (the reference's `local[*]` runs its tasks as threads of one JVM,
+ *    S/driver.scala:14).  ONE model is guarded by a reader-writer lock inside the library: the scoring calls
+ *    (fmhip_predict, fmhip_predict_rows, fmhip_rmse, fmhip_residual, fmhip_term_q) and the parameter reads
+ *    (fmhip_model_get_params*, fmhip_model_get_rows, fmhip_model_info) are RE-ENTRANT — each call works on a stream and in
+ *    a workspace of its own, so executor threads score through one frozen model side by side (S/Model.scala:14) and each
+ *    gets the bits a lone caller would get; every call that changes the model (set_params, init, training, the split and
+ *    the data-parallel step, tuning, gradient binding, profiling) takes the lock exclusively and so runs alone, after the
+ *    readers before it and before those behind it.  A dataset is immutable once created and may be shared by any number of
+ *    threads.  A communicator belongs to the thread that drives its model.  fmhip_tune is atomic per key.  Destroying a
+ *    handle while another thread still uses it is the caller's bug.  A transport callback (fmhip_comm_create_external)
+ *    runs inside a data-parallel call, i.e. under that model's lock: it must not call back into the same model
+ *    (fmhip_stream_wait / fmhip_device_read / fmhip_device_write take a stream, not a model, and are what it needs).
  */
 #ifndef FMHIP_H
 #define FMHIP_H
@@ -44,7 +56,7 @@
 extern "C" {
 #endif
 
-#define FMHIP_VERSION 300 /* 0.3.0 */
+#define FMHIP_VERSION 400 /* 0.4.0 */
 
 enum {
     FMHIP_OK = 0,
@@ -89,7 +101,8 @@ const char *fmhip_last_error(void);
 int fmhip_device_count(int *count);
 /* tuning knobs — fmhip_tune sets the PROCESS-WIDE DEFAULT of a key, fmhip_model_tune overrides it for one model (value < 0:
  * back to the default); a launch reads the model's value if it has one, else the default as it stands then.  Results are
- * identical across variants up to fp32 rounding.  Not synchronised: set the knobs before the threads that use them start.
+ * identical across variants up to fp32 rounding.  Each key is an atomic word: any thread may set or read one at any time (a launch
+ * that is being prepared sees the old or the new value, never a torn one).
  *   key 0  forward kernel : 60 = LDS w-tile (default: the linear weights of the 6144 lowest feature ids
  *                           are staged in LDS), 0 = plain global-memory gathers, 20 = LDS V-tile (rows of
  *                           the lowest-id features of V staged in LDS); the tiles only help when ids are
@@ -326,9 +339,12 @@ int fmhip_device_write(void *device_dst, const void *host_src, size_t bytes, voi
  *                           buffer [scalars | G_w | G_b | G_V rows of U_t], all-reduces that buffer (its size is known on the
  *                           host: no read-back, no synchronisation) and applies the rows-only update (weight decay rides in
  *                           the tables' scale: 0.5 <= 1 - eta*reg <= 1 required).  For models far wider than a global batch —
- *                           C5's 2^25 x 64 gradient is 8.9 GB dense and ~0.1 GB here.  Steps must follow the planned schedule:
- *                           fmhip_dp_epoch does; fmhip_dp_step takes batch t at step t (or -1 on a rank without it) and the
- *                           schedule wraps around after the longest rank's batch count.  Not overlapped with the backward.
+ *                           C5's 2^25 x 64 gradient is 8.9 GB dense and ~0.1 GB here.  The compact rows are sorted by feature id,
+ *                           so the plan's cuts apply here too: the all-reduce of an interval's slice of rows runs beside the
+ *                           backward of the next interval and the interval is updated when its slice has arrived, as in the dense
+ *                           mode.  The plan is per POSITION of the lock-step schedule (position t = every rank's batch t):
+ *                           fmhip_dp_epoch walks the positions in order, fmhip_dp_epoch_order / fmhip_dp_step_at in any order every
+ *                           rank names alike; fmhip_dp_step takes batch t at step t (or -1 on a rank without it), in order.
  *   FMHIP_EXCHANGE_SHARDED  the dense exchange with the UPDATE sharded too: each interval's G_V slice is reduce-scattered (rank r
  *                           receives the summed rows of its 1/world share of the interval), rank r updates just those rows of V and
  *                           zeroes them, the updated rows are all-gathered in place into every replica's V.  Same bytes on the wire as
@@ -358,6 +374,19 @@ int fmhip_dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_
  * sums over all ranks of the last step {sse, sum_e, rows, nonfinite} and steps taken */
 int fmhip_dp_epoch(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double eta, double reg0, double regw,
                    double regv, fmhip_stats *stats);
+/* One step at a POSITION of the lock-step schedule that every rank names alike: this rank's batch `position` if it has that
+ * many, a zero contribution otherwise.  What a permuted epoch calls (HipSGD.shuffle_seed, S/fm/lib/ALS.scala has no
+ * counterpart): unlike fmhip_dp_step, a rank without rows still says WHICH position the step is, so the touched-rows exchange
+ * can pick that position's union. */
+int fmhip_dp_step_at(fmhip_model_t m, fmhip_dataset_t d, int64_t position, fmhip_comm_t c, double eta, double reg0,
+                     double regw, double regv);
+/* fmhip_dp_epoch with the positions visited in the caller's order: order[n_order] = a permutation of [0, steps), steps = the
+ * largest batch count of any rank (fmhip_dp_plan_info), the SAME array on every rank.  order = NULL: ascending. */
+int fmhip_dp_epoch_order(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double eta, double reg0, double regw,
+                         double regv, const int64_t *order, int64_t n_order, fmhip_stats *stats);
+/* what the last fmhip_dp_plan agreed over all ranks: the lock-step steps of an epoch (the largest batch count of any rank)
+ * and the largest mini-batch (rows) */
+int fmhip_dp_plan_info(fmhip_comm_t c, int64_t *steps, int64_t *max_batch_rows);
 /* device time of the exchange as the compute stream saw it (HIP events, summed over the steps since
  * _begin): exposed_ms = time the update waited for the last collective after the backward had finished;
  * comm_ms = busy time of the collectives on their own stream; bytes = payload all-reduced per rank */

@@ -34,7 +34,7 @@
 
 namespace fmhip {
 
-int g_tune[kTuneCount] = {60, 1, 0, 0, 2, 1, 0, 1, 0, 1, 0, 1, 4};   // forward: w-tile kernel; backward: pipelined; tile rows: auto; row blocks: off; backward placement: band-affine; hot block: on; row order: on; forced flat loads: off; lazy decay: on; fused update: off; merged finish: on; hot pages: 4 of up to kHotPages (pages 5-8 measured: no gain, profiles/r03_experiments.md)
+std::atomic<int> g_tune[kTuneCount] = {60, 1, 0, 0, 2, 1, 0, 1, 0, 1, 0, 1, 4};   // forward: w-tile kernel; backward: pipelined; tile rows: auto; row blocks: off; backward placement: band-affine; hot block: on; row order: on; forced flat loads: off; lazy decay: on; fused update: off; merged finish: on; hot pages: 4 of up to kHotPages (pages 5-8 measured: no gain, profiles/r03_experiments.md)
 
 int padded_factors(int k) {
     int kp = 32;   // a row is at least one 128-B line: the cost of a gather is per line, not per byte
@@ -678,7 +678,7 @@ static int wt_occupancy() {
 }
 
 int forward_wt_occupancy(int Kp) {
-    static int cache[4] = {0, 0, 0, 0};
+    static std::atomic<int> cache[4] = {0, 0, 0, 0};      // filled on first use; two threads racing compute the same value
     const int idx = Kp == 32 ? 0 : Kp == 64 ? 1 : Kp == 128 ? 2 : 3;
     if (!cache[idx]) {
         switch (Kp) {

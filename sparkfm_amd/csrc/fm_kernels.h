@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace fmhip {
 
 constexpr int kRangeLen = 64;      // == FMHIP_RANGE_LEN
@@ -27,7 +29,8 @@ constexpr int kHotPages = 8;
 // pages the gradient-side block product carries through ONE pass over P (its accumulators: pages x Kp/16 x 4 VGPRs: 64 at
 // 8 pages x Kp = 32 and at 4 pages x Kp = 64); a dataset with more pages than that takes several passes
 constexpr int hot_pages_max(int Kp) { return Kp <= 32 ? 8 : (Kp <= 64 ? 4 : 1); }
-extern int g_tune[kTuneCount];     // process-wide DEFAULTS (fmhip_tune); a model may override a key (fmhip_model_tune)
+extern std::atomic<int> g_tune[kTuneCount];     // process-wide DEFAULTS (fmhip_tune; atomic: any thread may set or read one); a model may override a key (fmhip_model_tune)
+inline int tune_default(int key) { return g_tune[key].load(std::memory_order_relaxed); }
 
 // padded factor count: 4 * LPN * J with LPN = lanes per row-slot (<= 16), J float4 per lane
 int padded_factors(int k);

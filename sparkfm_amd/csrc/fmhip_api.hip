@@ -121,6 +121,7 @@ int fmhip_tune(int key, int value) {
 }
 
 int fmhip_model_tune(fmhip_model_t m, int key, int value) {
+    WriteLock lock(m);
     if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
     if (key < 0 || key >= kTuneCount) return fail(FMHIP_ERR_INVALID, "unknown tuning key %d", key);
     if (key == kTuneRowBlock || key == kTuneHot || key == kTuneHotPages)
@@ -201,6 +202,7 @@ int fmhip_model_destroy(fmhip_model_t m) {
 }
 
 int fmhip_model_info(fmhip_model_t m, int64_t *num_attribute, int32_t *num_factor, int32_t *padded) {
+    ReadLock lock(m);
     if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
     if (num_attribute) *num_attribute = m->n;
     if (num_factor) *num_factor = m->k;
@@ -209,6 +211,7 @@ int fmhip_model_info(fmhip_model_t m, int64_t *num_attribute, int32_t *num_facto
 }
 
 int fmhip_model_init_normal(fmhip_model_t m, uint64_t seed, double mean, double stdev) {
+    WriteLock lock(m);
     if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
     TRY(set_device(m->device));
     HIP_TRY(launch_init_normal(m->Kp, m->V.p, m->w.p, m->w0.p, m->n1, m->n1p, m->k, seed, (float)mean, (float)stdev, m->stream));
@@ -221,6 +224,7 @@ int fmhip_model_init_normal(fmhip_model_t m, uint64_t seed, double mean, double 
 }
 
 int fmhip_model_get_rows(fmhip_model_t m, int64_t n, const int32_t *ids, double *w, double *v) {
+    ReadLock lock(m);
     if (!m || n < 0 || (n > 0 && !ids)) return fail(FMHIP_ERR_INVALID, "NULL argument or negative count");
     for (int64_t j = 0; j < n; ++j)
         if (ids[j] < 0 || ids[j] > m->n) return fail(FMHIP_ERR_SHAPE, "feature id %d outside [0, %lld]", ids[j], (long long)m->n);
@@ -253,12 +257,25 @@ int fmhip_model_get_rows(fmhip_model_t m, int64_t n, const int32_t *ids, double 
     return FMHIP_OK;
 }
 
-int fmhip_model_set_params(fmhip_model_t m, double w0, const double *w, const double *v) { return set_params_impl<double>(m, w0, w, v); }
-int fmhip_model_get_params(fmhip_model_t m, double *w0, double *w, double *v) { return get_params_impl<double>(m, w0, w, v); }
-int fmhip_model_set_params_f32(fmhip_model_t m, float w0, const float *w, const float *v) { return set_params_impl<float>(m, w0, w, v); }
-int fmhip_model_get_params_f32(fmhip_model_t m, float *w0, float *w, float *v) { return get_params_impl<float>(m, w0, w, v); }
+int fmhip_model_set_params(fmhip_model_t m, double w0, const double *w, const double *v) {
+    WriteLock lock(m);
+    return set_params_impl<double>(m, w0, w, v);
+}
+int fmhip_model_get_params(fmhip_model_t m, double *w0, double *w, double *v) {
+    ReadLock lock(m);
+    return get_params_impl<double>(m, w0, w, v);
+}
+int fmhip_model_set_params_f32(fmhip_model_t m, float w0, const float *w, const float *v) {
+    WriteLock lock(m);
+    return set_params_impl<float>(m, w0, w, v);
+}
+int fmhip_model_get_params_f32(fmhip_model_t m, float *w0, float *w, float *v) {
+    ReadLock lock(m);
+    return get_params_impl<float>(m, w0, w, v);
+}
 
 int fmhip_synchronize(fmhip_model_t m) {
+    ReadLock lock(m);
     if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
     TRY(set_device(m->device));
     HIP_TRY(hipStreamSynchronize(m->stream));
@@ -267,56 +284,111 @@ int fmhip_synchronize(fmhip_model_t m) {
 
 // ---- scoring
 
+// A scoring call's workspace: taken from the model's pool (or made), given back when the call returns.
+namespace {
+struct ScoreLease {
+    fmhip_model_t m;
+    ScoreCtx *cx = nullptr;
+    explicit ScoreLease(fmhip_model_t m_) : m(m_) {}
+    int take() {
+        {
+            std::lock_guard<std::mutex> g(m->pool_mu);
+            if (!m->ctx_free.empty()) {
+                cx = m->ctx_free.back();
+                m->ctx_free.pop_back();
+                return FMHIP_OK;
+            }
+        }
+        std::unique_ptr<ScoreCtx> fresh(new (std::nothrow) ScoreCtx());
+        if (!fresh) return fail(FMHIP_ERR_NOMEM, "out of host memory");
+        HIP_TRY(hipStreamCreateWithFlags(&fresh->s, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&fresh->ev, hipEventDisableTiming));
+        std::lock_guard<std::mutex> g(m->pool_mu);
+        cx = fresh.get();
+        m->ctx_all.push_back(std::move(fresh));
+        return FMHIP_OK;
+    }
+    ~ScoreLease() {
+        if (!cx) return;
+        (void)hipStreamSynchronize(cx->s);       // an early error return must not hand a busy workspace to the next call
+        std::lock_guard<std::mutex> g(m->pool_mu);
+        m->ctx_free.push_back(cx);
+    }
+};
+}  // namespace
+
+// One pass of FMModel.predict over a dataset's rows.  Re-entrant: the caller holds the model's lock SHARED, every call
+// works on a stream and in buffers of its own (ScoreCtx) and touches nothing of the model but its parameters.
 static int score_pass(fmhip_model_t m, fmhip_dataset_t d, double *yhat, double *e_out, double *q_out, fmhip_stats *st) {
     TRY(check_pair(m, d));
-    TRY(ensure_workspace(m, d));
-    HIP_TRY(hipMemsetAsync(m->acc.p, 0, 4 * sizeof(double), m->stream));
-    DevBuf<float> dy;
-    if (yhat) TRY(dy.alloc((size_t)std::max<int64_t>(d->max_rows, 1)));
+    ScoreLease lease(m);
+    TRY(lease.take());
+    ScoreCtx &cx = *lease.cx;
+    const size_t rows_max = (size_t)std::max<int64_t>(d->max_rows, 1);
+    TRY(cx.e.ensure(rows_max));
+    TRY(cx.bsum.ensure((size_t)kMaxFwdBlocks * 4));
+    TRY(cx.acc.ensure(4));
+    if (yhat) TRY(cx.yhat.ensure(rows_max));
+    if (q_out) TRY(cx.P.ensure(rows_max * m->Kp));
+    // behind whatever the model's own stream still has queued (a training step returns before it has run)
+    HIP_TRY(hipEventRecord(cx.ev, m->stream));
+    HIP_TRY(hipStreamWaitEvent(cx.s, cx.ev, 0));
+    HIP_TRY(hipMemsetAsync(cx.acc.p, 0, 4 * sizeof(double), cx.s));
     std::vector<float> hbuf;
     for (size_t b = 0; b < d->batches.size(); ++b) {
         const BatchMeta &bm = d->batches[b];
         FwdArgs a = fwd_args(m, d, bm);
-        a.yhat = dy.p;
+        a.P = q_out ? cx.P.p : nullptr;          // the scoring modes write P only to hand q back
+        a.e = cx.e.p;
+        a.bsum = cx.bsum.p;
+        a.yhat = yhat ? cx.yhat.p : nullptr;
         int parts = 0;
-        HIP_TRY(launch_forward(m->Kp, q_out ? kFwdQ : kFwdResidual, a, m->stream, &parts));
-        HIP_TRY(launch_reduce_blocks(m->bsum.p, parts, (int32_t)bm.rows, nullptr, m->acc.p, m->stream));
+        HIP_TRY(launch_forward(m->Kp, q_out ? kFwdQ : kFwdResidual, a, cx.s, &parts));
+        HIP_TRY(launch_reduce_blocks(cx.bsum.p, parts, (int32_t)bm.rows, nullptr, cx.acc.p, cx.s));
         if (yhat || e_out) {
             hbuf.resize((size_t)bm.rows);
             if (yhat) {
-                HIP_TRY(hipMemcpyAsync(hbuf.data(), dy.p, (size_t)bm.rows * sizeof(float), hipMemcpyDeviceToHost, m->stream));
-                HIP_TRY(hipStreamSynchronize(m->stream));
+                HIP_TRY(hipMemcpyAsync(hbuf.data(), cx.yhat.p, (size_t)bm.rows * sizeof(float), hipMemcpyDeviceToHost, cx.s));
+                HIP_TRY(hipStreamSynchronize(cx.s));
                 for (int64_t r = 0; r < bm.rows; ++r) yhat[bm.row0 + r] = hbuf[(size_t)r];
             }
             if (e_out) {
-                HIP_TRY(hipMemcpyAsync(hbuf.data(), m->e.p, (size_t)bm.rows * sizeof(float), hipMemcpyDeviceToHost, m->stream));
-                HIP_TRY(hipStreamSynchronize(m->stream));
+                HIP_TRY(hipMemcpyAsync(hbuf.data(), cx.e.p, (size_t)bm.rows * sizeof(float), hipMemcpyDeviceToHost, cx.s));
+                HIP_TRY(hipStreamSynchronize(cx.s));
                 for (int64_t r = 0; r < bm.rows; ++r) e_out[bm.row0 + r] = hbuf[(size_t)r];
             }
         }
         if (q_out) {
             hbuf.resize((size_t)bm.rows * m->Kp);
-            HIP_TRY(hipMemcpyAsync(hbuf.data(), m->P.p, hbuf.size() * sizeof(float), hipMemcpyDeviceToHost, m->stream));
-            HIP_TRY(hipStreamSynchronize(m->stream));
+            HIP_TRY(hipMemcpyAsync(hbuf.data(), cx.P.p, hbuf.size() * sizeof(float), hipMemcpyDeviceToHost, cx.s));
+            HIP_TRY(hipStreamSynchronize(cx.s));
             for (int64_t r = 0; r < bm.rows; ++r)
                 for (int f = 0; f < m->k; ++f) q_out[(bm.row0 + r) * m->k + f] = hbuf[(size_t)r * m->Kp + f];
         }
     }
     if (st) {
         memset(st, 0, sizeof *st);
-        TRY(read_acc(m, st));
+        double h[4];
+        HIP_TRY(hipMemcpyAsync(h, cx.acc.p, sizeof h, hipMemcpyDeviceToHost, cx.s));
+        HIP_TRY(hipStreamSynchronize(cx.s));
+        st->sum_e = h[0];
+        st->sse = h[1];
+        st->rows = (int64_t)llround(h[2]);
+        st->nonfinite = (int64_t)llround(h[3]);
         st->nnz = d->nnz;
     }
     return FMHIP_OK;
 }
 
 int fmhip_predict(fmhip_model_t m, fmhip_dataset_t d, double *yhat) {
+    ReadLock lock(m);
     if (!yhat) return fail(FMHIP_ERR_INVALID, "yhat is NULL");
     return score_pass(m, d, yhat, nullptr, nullptr, nullptr);
 }
 
 int fmhip_predict_rows(fmhip_model_t m, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const double *val,
                        double *yhat) {
+    ReadLock lock(m);
     if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
     if (n_rows > 0 && !yhat) return fail(FMHIP_ERR_INVALID, "yhat is NULL");
     fmhip_dataset_t d = nullptr;
@@ -327,16 +399,19 @@ int fmhip_predict_rows(fmhip_model_t m, int64_t n_rows, const int64_t *row_ptr, 
 }
 
 int fmhip_residual(fmhip_model_t m, fmhip_dataset_t d, double *e) {
+    ReadLock lock(m);
     if (!e) return fail(FMHIP_ERR_INVALID, "e is NULL");
     return score_pass(m, d, nullptr, e, nullptr, nullptr);
 }
 
 int fmhip_term_q(fmhip_model_t m, fmhip_dataset_t d, double *q) {
+    ReadLock lock(m);
     if (!q) return fail(FMHIP_ERR_INVALID, "q is NULL");
     return score_pass(m, d, nullptr, nullptr, q, nullptr);
 }
 
 int fmhip_rmse(fmhip_model_t m, fmhip_dataset_t d, double *rmse, fmhip_stats *stats) {
+    ReadLock lock(m);
     if (!rmse) return fail(FMHIP_ERR_INVALID, "rmse is NULL");
     fmhip_stats st;
     TRY(score_pass(m, d, nullptr, nullptr, nullptr, &st));
@@ -350,6 +425,7 @@ int fmhip_rmse(fmhip_model_t m, fmhip_dataset_t d, double *rmse, fmhip_stats *st
 
 int fmhip_sgd_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double eta, double reg0, double regw,
                    double regv, fmhip_stats *stats) {
+    WriteLock lock(m);
     TRY(check_train(m, d));
     TRY(check_batch(d, batch));
     FusedPlan fp{};
@@ -366,6 +442,7 @@ int fmhip_sgd_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double eta
 
 int fmhip_sgd_epoch(fmhip_model_t m, fmhip_dataset_t d, double eta, double reg0, double regw, double regv,
                     const int64_t *order, fmhip_stats *stats) {
+    WriteLock lock(m);
     TRY(check_train(m, d));
     const int64_t nb = (int64_t)d->batches.size();
     if (order)
@@ -389,6 +466,7 @@ int fmhip_sgd_epoch(fmhip_model_t m, fmhip_dataset_t d, double eta, double reg0,
 
 int fmhip_batch_grad(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double *gv, double *gw, double *gw0,
                      fmhip_stats *stats) {
+    WriteLock lock(m);
     TRY(check_train(m, d));
     TRY(check_batch(d, batch));
     TRY(step_compute(m, d, batch, nullptr));
@@ -420,6 +498,7 @@ int fmhip_batch_grad(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double *
 // ---- ALS (the reference's own learner), fp64
 
 int fmhip_als_epoch(fmhip_model_t m, fmhip_dataset_t d, double reg0, double regw, double regv) {
+    WriteLock lock(m);
     TRY(check_train(m, d));
     if (d->batches.size() > 1 || (d->nnz > 0 && !d->val64.p))
         return fail(FMHIP_ERR_UNSUPPORTED, "ALS walks the whole-dataset transpose: create the dataset with batch_rows <= 0 "
@@ -488,12 +567,14 @@ int fmhip_als_epoch(fmhip_model_t m, fmhip_dataset_t d, double reg0, double regw
 // ---- data-parallel split step
 
 int fmhip_grad_floats(fmhip_model_t m, int64_t *n_floats) {
+    ReadLock lock(m);
     if (!m || !n_floats) return fail(FMHIP_ERR_INVALID, "NULL argument");
     *n_floats = (int64_t)m->grad_floats();
     return FMHIP_OK;
 }
 
 int fmhip_grad_bind(fmhip_model_t m, void *device_ptr) {
+    WriteLock lock(m);
     if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
     if (device_ptr && (reinterpret_cast<uintptr_t>(device_ptr) & 15u))
         return fail(FMHIP_ERR_INVALID, "gradient buffer must be 16-byte aligned");
@@ -503,24 +584,28 @@ int fmhip_grad_bind(fmhip_model_t m, void *device_ptr) {
 }
 
 int fmhip_grad_ptr(fmhip_model_t m, void **device_ptr) {
+    ReadLock lock(m);
     if (!m || !device_ptr) return fail(FMHIP_ERR_INVALID, "NULL argument");
     *device_ptr = m->grad;
     return FMHIP_OK;
 }
 
 int fmhip_step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t batch) {
+    WriteLock lock(m);
     TRY(check_train(m, d));
     TRY(check_batch(d, batch));
     return step_compute(m, d, batch, nullptr);
 }
 
 int fmhip_step_forward(fmhip_model_t m, fmhip_dataset_t d, int64_t batch) {
+    WriteLock lock(m);
     TRY(check_train(m, d));
     TRY(check_batch(d, batch));
     return step_forward(m, d, batch);
 }
 
 int fmhip_step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, int64_t feat_lo, int64_t feat_hi, int finish) {
+    WriteLock lock(m);
     TRY(check_train(m, d));
     TRY(check_batch(d, batch));
     if (feat_lo < 0 || feat_hi < feat_lo) return fail(FMHIP_ERR_INVALID, "bad feature interval [%lld, %lld)", (long long)feat_lo, (long long)feat_hi);
@@ -537,6 +622,7 @@ int fmhip_step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, int64
 }
 
 int fmhip_grad_layout(fmhip_model_t m, int64_t *row_floats, int64_t *gv_offset) {
+    ReadLock lock(m);
     if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
     if (row_floats) *row_floats = m->Kp;
     if (gv_offset) *gv_offset = (int64_t)m->head_floats();
@@ -544,12 +630,14 @@ int fmhip_grad_layout(fmhip_model_t m, int64_t *row_floats, int64_t *gv_offset) 
 }
 
 int fmhip_step_apply(fmhip_model_t m, double eta, double reg0, double regw, double regv) {
+    WriteLock lock(m);
     if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
     TRY(set_device(m->device));
     return step_apply(m, eta, reg0, regw, regv);
 }
 
 int fmhip_step_stats(fmhip_model_t m, fmhip_stats *stats) {
+    WriteLock lock(m);
     if (!m || !stats) return fail(FMHIP_ERR_INVALID, "NULL argument");
     TRY(set_device(m->device));
     memset(stats, 0, sizeof *stats);
@@ -561,33 +649,28 @@ int fmhip_step_stats(fmhip_model_t m, fmhip_stats *stats) {
 
 // ---- measurement
 
-int fmhip_profile_begin(fmhip_model_t m) {
+static int profile_begin(fmhip_model_t m, bool rotate, int period) {
     if (!m) return fail(FMHIP_ERR_INVALID, "model is NULL");
+    if (period < 1) return fail(FMHIP_ERR_INVALID, "period must be >= 1");
+    WriteLock lock(m);
     for (auto &r : m->prof) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }
     m->prof.clear();
     m->profiling = true;
-    m->prof_rotate = false;
-    m->prof_period = 1;
+    m->prof_rotate = rotate;
+    m->prof_period = period;
     m->prof_step = 0;
     return FMHIP_OK;
 }
 
-int fmhip_profile_begin_rotating(fmhip_model_t m) { return fmhip_profile_begin_sampled(m, 1); }
-
-int fmhip_profile_begin_sampled(fmhip_model_t m, int period) {
-    if (period < 1) return fail(FMHIP_ERR_INVALID, "period must be >= 1");
-    int rc = fmhip_profile_begin(m);
-    if (rc == FMHIP_OK) {
-        m->prof_rotate = true;
-        m->prof_period = period;
-    }
-    return rc;
-}
+int fmhip_profile_begin(fmhip_model_t m) { return profile_begin(m, false, 1); }
+int fmhip_profile_begin_rotating(fmhip_model_t m) { return profile_begin(m, true, 1); }
+int fmhip_profile_begin_sampled(fmhip_model_t m, int period) { return profile_begin(m, true, period); }
 
 int fmhip_profile_end(fmhip_model_t m, fmhip_profile *p) {
+    WriteLock lock(m);
     if (!m || !p) return fail(FMHIP_ERR_INVALID, "NULL argument");
     TRY(set_device(m->device));
     m->profiling = false;

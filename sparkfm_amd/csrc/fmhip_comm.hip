@@ -153,6 +153,19 @@ __global__ __launch_bounds__(256) void k_positions(const int32_t *ids, int32_t n
     pos[i] = lo;
 }
 
+// pos[i] = lower bound of cuts[i] in u[0..*n_u): where the feature interval that starts at cuts[i] begins in the compact gradient
+__global__ void k_cut_positions(const int32_t *cuts, int32_t n, const int32_t *u, const int32_t *n_u, int32_t *pos) {
+    const int32_t i = (int32_t)threadIdx.x;
+    if (i >= n) return;
+    int32_t lo = 0, hi = *n_u;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (u[mid] < cuts[i]) lo = mid + 1;
+        else hi = mid;
+    }
+    pos[i] = lo;
+}
+
 // The event set of ONE profiled step.  Sets are created in fmhip_comm_profile_begin (a pool), never inside a step: an
 // event creation costs the host tens of microseconds, and the pass that uses them is the one that measures what the
 // exchange leaves exposed.
@@ -185,6 +198,7 @@ struct fmhip_comm {
         int32_t n_u = 0;
         int32_t *cdst = nullptr;              // device: per compressed column of this rank's batch t, its row in the compact buffer
         int32_t *hot_pos = nullptr;           // device: the same for the slots of the dense hot block (-1 = unused)
+        int32_t cut_pos[kMaxCuts + 1] = {};   // where the plan's cuts (c->cuts, ascending) fall in the union: an interval of ids = a slice of rows
     };
     std::vector<TStep> tsteps;                // one per lock-step step of an epoch
     int64_t t_cursor = 0;                     // the next step of the planned schedule
@@ -211,6 +225,7 @@ struct fmhip_comm {
     // agreed by fmhip_dp_plan over all ranks: the largest mini-batch of any rank (rows), so that every size check of a
     // step passes or fails on every rank alike
     int64_t plan_max_rows = -1;
+    int64_t plan_steps = 0;                   // ... and the largest batch count: the lock-step steps of an epoch
 };
 
 namespace {
@@ -345,27 +360,58 @@ struct CompactLayout {
     }
 };
 
-// The plan of the touched-rows exchange (collective): for every lock-step step t < steps, the union of the rows the ranks'
-// batches t touch, and where this rank's columns lie in it.  Plan-time work: one all-gather, one sort and one 4-byte
-// read-back per step — what every STEP used to pay.
+// small control collectives (a count, a cut) through a device scratch word
+int control_i64(fmhip_model_t m, fmhip_comm_t c, int64_t *value, int count, bool broadcast_from_0) {
+    HIP_TRY(hipMemcpyAsync(c->scratch, value, count * sizeof(int64_t), hipMemcpyHostToDevice, m->stream));
+    TRY(collective(c, c->scratch, (size_t)count, broadcast_from_0 ? FMHIP_COLL_BCAST0_I64 : FMHIP_COLL_MAX_I64, m->stream));
+    HIP_TRY(hipMemcpyAsync(value, c->scratch, count * sizeof(int64_t), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return FMHIP_OK;
+}
+
+// The plan of the touched-rows exchange (collective): for every position t < steps of the lock-step schedule, the union of the
+// rows the ranks' batches t touch, where this rank's columns lie in it, and where the plan's cuts fall in it.  Plan-time
+// work: one all-gather, one sort and one small read-back per position — what every STEP used to pay.
+// A failure that only THIS rank sees (an allocation, a sort) must not leave the peers inside the next all-gather: the rank
+// keeps taking part in the collectives, skips its own work, and all ranks agree on the outcome at the end.
 int plan_touched(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, int64_t cap, int64_t steps) {
     free_touched(c);
     c->cap = cap;
     c->msg_kp = m->Kp;
     const size_t n = (size_t)c->world * (size_t)cap;
+    // sized alike on every rank (cap, world and steps are agreed values): passes or fails everywhere
     if (n > (size_t)INT32_MAX) return fail(FMHIP_ERR_UNSUPPORTED, "%zu id slots exceed the touched-rows exchange's 2^31 limit", n);
-    size_t ta = 0, tb = 0;
-    int32_t *kq = nullptr;
-    HIP_TRY(rocprim::radix_sort_keys(nullptr, ta, kq, kq, n, 0, 32, m->stream));
-    HIP_TRY(rocprim::unique(nullptr, tb, kq, kq, kq, n, rocprim::equal_to<int32_t>(), m->stream));
-    const size_t tmp_bytes = std::max(ta, tb);
-    DevBuf<int32_t> ids, sorted, uniq, n_uniq;
+    DevBuf<int32_t> ids, sorted, uniq, n_uniq, dcuts, dpos;
     DevBuf<uint8_t> tmp;
-    TRY(ids.alloc(std::max<size_t>(n, 1)));
-    TRY(sorted.alloc(std::max<size_t>(n, 1)));
-    TRY(uniq.alloc(std::max<size_t>(n, 1)));
-    TRY(n_uniq.alloc(1));
-    TRY(tmp.alloc(tmp_bytes + 16));
+    size_t tmp_bytes = 0;
+    const int n_cuts = (int)c->cuts.size();
+    auto scratch = [&]() -> int {
+        size_t ta = 0, tb = 0;
+        int32_t *kq = nullptr;
+        HIP_TRY(rocprim::radix_sort_keys(nullptr, ta, kq, kq, n, 0, 32, m->stream));
+        HIP_TRY(rocprim::unique(nullptr, tb, kq, kq, kq, n, rocprim::equal_to<int32_t>(), m->stream));
+        tmp_bytes = std::max(ta, tb);
+        TRY(ids.alloc(std::max<size_t>(n, 1)));
+        TRY(sorted.alloc(std::max<size_t>(n, 1)));
+        TRY(uniq.alloc(std::max<size_t>(n, 1)));
+        TRY(n_uniq.alloc(1));
+        TRY(tmp.alloc(tmp_bytes + 16));
+        TRY(dcuts.alloc(kMaxCuts + 1));
+        TRY(dpos.alloc(kMaxCuts + 1));
+        int32_t hc[kMaxCuts + 1] = {};
+        for (int i = 0; i < n_cuts; ++i) hc[i] = (int32_t)c->cuts[(size_t)i];
+        HIP_TRY(hipMemcpyAsync(dcuts.p, hc, sizeof hc, hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        return FMHIP_OK;
+    };
+    int64_t bad = scratch() != FMHIP_OK;
+    std::string why = bad ? fmhip_last_error() : "";
+    {
+        // without the id table there is nothing to all-gather into: agreed BEFORE the first collective that needs it
+        int64_t flag = bad;
+        TRY(control_i64(m, c, &flag, 1, false));
+        if (flag) return fail(FMHIP_ERR_NOMEM, "%s", why.empty() ? "another rank could not allocate the touched-rows plan's scratch" : why.c_str());
+    }
     const int64_t nb = (int64_t)d->batches.size();
     const int32_t n_hot = d->hot_pages * kHotT;
     int32_t max_nu = 0;
@@ -377,69 +423,100 @@ int plan_touched(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, int64_t cap
         const int32_t n_feat = live ? d->batches[(size_t)t].n_cols : 0;
         hipLaunchKernelGGL(k_fill_ids, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, m->stream, ids.p + (size_t)c->rank * cap, feat, n_feat,
                            live ? d->d_hot_ids.p : nullptr, live ? n_hot : 0, cap);
-        HIP_TRY(hipGetLastError());
+        // the collective itself: every rank, every position, whatever happened locally (a transport error IS collective)
         TRY(collective(c, ids.p, (size_t)cap, FMHIP_COLL_ALLGATHER_I32, m->stream));
-        size_t tbytes = tmp_bytes;
-        HIP_TRY(rocprim::radix_sort_keys(tmp.p, tbytes, ids.p, sorted.p, n, 0, 32, m->stream));
-        tbytes = tmp_bytes;
-        HIP_TRY(rocprim::unique(tmp.p, tbytes, sorted.p, uniq.p, n_uniq.p, n, rocprim::equal_to<int32_t>(), m->stream));
-        HIP_TRY(hipMemcpyAsync(&ts.n_u, n_uniq.p, sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
-        HIP_TRY(hipStreamSynchronize(m->stream));
-        max_nu = std::max(max_nu, ts.n_u);
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ts.uni), std::max<size_t>((size_t)ts.n_u, 1) * sizeof(int32_t)));
-        HIP_TRY(hipMemcpyAsync(ts.uni, uniq.p, (size_t)ts.n_u * sizeof(int32_t), hipMemcpyDeviceToDevice, m->stream));
-        if (live) {
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ts.cdst), std::max<size_t>((size_t)n_feat, 1) * sizeof(int32_t)));
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ts.hot_pos), std::max<size_t>((size_t)n_hot, 1) * sizeof(int32_t)));
-            if (n_feat) {
-                hipLaunchKernelGGL(k_positions, dim3((unsigned)((n_feat + 255) / 256)), dim3(256), 0, m->stream, feat, n_feat, ts.uni, ts.n_u, ts.cdst);
+        if (bad) continue;
+        auto local = [&]() -> int {
+            HIP_TRY(hipGetLastError());
+            size_t tbytes = tmp_bytes;
+            HIP_TRY(rocprim::radix_sort_keys(tmp.p, tbytes, ids.p, sorted.p, n, 0, 32, m->stream));
+            tbytes = tmp_bytes;
+            HIP_TRY(rocprim::unique(tmp.p, tbytes, sorted.p, uniq.p, n_uniq.p, n, rocprim::equal_to<int32_t>(), m->stream));
+            if (n_cuts) {
+                hipLaunchKernelGGL(k_cut_positions, dim3(1), dim3(64), 0, m->stream, dcuts.p, n_cuts, uniq.p, n_uniq.p, dpos.p);
                 HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(ts.cut_pos, dpos.p, (size_t)n_cuts * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
             }
-            if (n_hot) {
-                hipLaunchKernelGGL(k_positions, dim3((unsigned)((n_hot + 255) / 256)), dim3(256), 0, m->stream, d->d_hot_ids.p, n_hot, ts.uni, ts.n_u,
-                                   ts.hot_pos);
-                HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(&ts.n_u, n_uniq.p, sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            max_nu = std::max(max_nu, ts.n_u);
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ts.uni), std::max<size_t>((size_t)ts.n_u, 1) * sizeof(int32_t)));
+            HIP_TRY(hipMemcpyAsync(ts.uni, uniq.p, (size_t)ts.n_u * sizeof(int32_t), hipMemcpyDeviceToDevice, m->stream));
+            if (live) {
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ts.cdst), std::max<size_t>((size_t)n_feat, 1) * sizeof(int32_t)));
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ts.hot_pos), std::max<size_t>((size_t)n_hot, 1) * sizeof(int32_t)));
+                if (n_feat) {
+                    hipLaunchKernelGGL(k_positions, dim3((unsigned)((n_feat + 255) / 256)), dim3(256), 0, m->stream, feat, n_feat, ts.uni, ts.n_u, ts.cdst);
+                    HIP_TRY(hipGetLastError());
+                }
+                if (n_hot) {
+                    hipLaunchKernelGGL(k_positions, dim3((unsigned)((n_hot + 255) / 256)), dim3(256), 0, m->stream, d->d_hot_ids.p, n_hot, ts.uni, ts.n_u,
+                                       ts.hot_pos);
+                    HIP_TRY(hipGetLastError());
+                }
             }
+            return FMHIP_OK;
+        };
+        if (local() != FMHIP_OK) {
+            bad = 1;
+            why = fmhip_last_error();
         }
     }
-    c->cg_floats = CompactLayout(max_nu, m->Kp).total;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->cg), c->cg_floats * sizeof(float)));
-    HIP_TRY(hipMemsetAsync(c->cg, 0, c->cg_floats * sizeof(float), m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (!bad) {
+        auto finish = [&]() -> int {
+            c->cg_floats = CompactLayout(max_nu, m->Kp).total;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->cg), c->cg_floats * sizeof(float)));
+            HIP_TRY(hipMemsetAsync(c->cg, 0, c->cg_floats * sizeof(float), m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            return FMHIP_OK;
+        };
+        if (finish() != FMHIP_OK) {
+            bad = 1;
+            why = fmhip_last_error();
+        }
+    }
+    TRY(control_i64(m, c, &bad, 1, false));       // every rank leaves with the same verdict
+    if (bad) {
+        free_touched(c);
+        return fail(FMHIP_ERR_HIP, "%s", why.empty() ? "the touched-rows plan failed on another rank" : why.c_str());
+    }
     c->planned_data = d;
     return FMHIP_OK;
 }
 
 // One data-parallel step that exchanges only the gradient rows some rank touched (models far wider than a global batch:
-// C5's 2^25 x 64 table moves 8.9 GB per dense all-reduce and ~0.1 of that here).  Step t of the planned schedule:
-//   |B| -> forward -> backward straight into the compact buffer (row j = feature U_t[j]) -> all-reduce of the buffer ->
-//   rows-only update of U_t with lazy weight decay (which zeroes the buffer's rows again).
-// Nothing is sized on the device: no read-back, no host synchronisation.  Replicas stay bit-identical: same U, same sums,
-// same update.
-int dp_step_touched(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0, double regw, double regv) {
+// C5's 2^25 x 64 table moves 8.9 GB per dense all-reduce and a few percent of that here).  Position t of the planned schedule:
+//   compute stream  forward | backward(cold ids) -> compact rows | backward(next) ... + statistics | wait 1 | update(slice 1) | ...
+//   comm stream     |B|     |                                    | all-reduce(slice 1)            | all-reduce(slice 2) ...
+// — the dense step's schedule with a COMPACT gradient: row j of the buffer belongs to feature U_t[j], U_t ascending, so the
+// feature interval [cut_i, cut_i+1) is the contiguous slice of rows [cut_pos_i, cut_pos_i+1) and its all-reduce runs beside
+// the backward of the next interval; an interval gets the rows-only update (lazy weight decay: the tables' scale moves with
+// the last slice) as soon as its slice has arrived.  Nothing is sized on the device: no read-back, no host synchronisation.
+// Replicas stay bit-identical: same U, same sums, same update.
+int dp_step_touched(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0, double regw, double regv,
+                    int64_t position) {
     const bool live = batch >= 0;
     if (c->tsteps.empty() || !c->cg || c->msg_kp != m->Kp)
         return fail(FMHIP_ERR_INVALID, "the touched-rows exchange is not planned for this model: call fmhip_dp_plan (every rank)");
     if (!lazy_decay_ok(m, eta, regw, regv))
         return fail(FMHIP_ERR_UNSUPPORTED, "the touched-rows exchange needs weight decay that fits the tables' scale (0.5 <= 1 - eta*reg <= 1)");
     const bool packed_dirty = m->grad_dirty;      // this step neither writes nor cleans the model's packed gradient
-    const int64_t t = c->t_cursor;
+    const int64_t t = position >= 0 ? position : c->t_cursor;
+    if (t >= (int64_t)c->tsteps.size())
+        return fail(FMHIP_ERR_INVALID, "position %lld outside the planned schedule of %zu steps", (long long)t, c->tsteps.size());
     const auto &ts = c->tsteps[(size_t)t];
     const CompactLayout L(ts.n_u, m->Kp);
     const GradView view{c->cg, c->cg + L.gw, c->cg + L.gb, c->cg + L.gv, ts.cdst, ts.hot_pos};
     const float my_rows = live ? (float)d->batches[(size_t)batch].rows : 0.f;
     hipLaunchKernelGGL(k_set_float, dim3(1), dim3(1), 0, m->stream, c->rows_dev, my_rows);
     HIP_TRY(hipGetLastError());
-    TRY(collective(c, c->rows_dev, 1, FMHIP_COLL_SUM_F32, m->stream));
+    HIP_TRY(hipEventRecord(c->ev_rows, m->stream));
+    HIP_TRY(hipStreamWaitEvent(c->cs, c->ev_rows, 0));
+    TRY(collective(c, c->rows_dev, 1, FMHIP_COLL_SUM_F32, c->cs));
     if (live) {
         // the packed gradient is not written by this step: a pending memset of it (8.9 GB at C5's width) would be wasted
         m->grad_dirty = false;
-        int rc = step_forward(m, d, batch);
-        if (rc == FMHIP_OK) {
-            m->view = &view;
-            rc = step_backward(m, d, batch, 0, INT64_MAX, true, nullptr);
-            m->view = nullptr;
-        }
+        const int rc = step_forward(m, d, batch);
         m->grad_dirty = packed_dirty;
         TRY(rc);
     } else {
@@ -448,24 +525,61 @@ int dp_step_touched(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_com
         HIP_TRY(hipMemsetAsync(c->cg, 0, (size_t)kGradHead * sizeof(float), m->stream));
         m->last_nnz = m->last_rows = 0;
     }
-    m->bw_next_hi = -1;
     CommProf *pr = next_prof(c);
-    if (pr) {
-        HIP_TRY(hipEventRecord(pr->wait_a, m->stream));
-        HIP_TRY(hipEventRecord(pr->c0[pr->n_coll], m->stream));
+    // intervals of feature ids [edge[i], edge[i+1]) = rows [pe[i], pe[i+1]) of the compact buffer, from the top down
+    std::vector<int64_t> edge{0};
+    std::vector<int64_t> pe{0};
+    for (size_t i = 0; i < c->cuts.size(); ++i) {
+        const int64_t x = c->cuts[i];
+        if (x > edge.back() && x < m->n1) {
+            edge.push_back(x);
+            pe.push_back(ts.cut_pos[i]);
+        }
     }
-    TRY(collective(c, c->cg, L.total, FMHIP_COLL_SUM_F32, m->stream));
-    TRY(emu_delay(c, (double)L.total * sizeof(float), m->stream));
-    if (pr) {
-        HIP_TRY(hipEventRecord(pr->c1[pr->n_coll++], m->stream));
-        HIP_TRY(hipEventRecord(pr->wait_b, m->stream));        // nothing overlaps: the whole exchange is exposed
+    edge.push_back(m->n1);
+    pe.push_back(ts.n_u);
+    const int n_int = (int)edge.size() - 1;
+    for (int i = n_int - 1; i >= 0; --i) {
+        const bool last = i == 0;
+        if (live) {
+            m->view = &view;
+            m->grad_dirty = false;
+            const int rc = step_backward(m, d, batch, edge[(size_t)i], n_int == 1 ? INT64_MAX : edge[(size_t)i + 1], last, nullptr);
+            m->view = nullptr;
+            m->grad_dirty = packed_dirty;
+            TRY(rc);
+        }
+        const size_t plo = (size_t)pe[(size_t)i], phi = (size_t)pe[(size_t)i + 1];
+        if (n_int == 1) {
+            const Region whole[1] = {{c->cg, L.total}};
+            TRY(reduce_regions(m, c, whole, 1, c->ev_ready[i], c->ev_done[i], pr));
+        } else {
+            // the interval's G_V rows, G_w and G_b entries; the lowest interval's G_w region starts at the scalars in front of it
+            const Region reg[3] = {{view.GV + plo * m->Kp, (phi - plo) * m->Kp},
+                                   {last ? c->cg : view.Gw + plo, (phi - plo) + (last ? (size_t)kGradHead : 0)},
+                                   {view.Gb + plo, phi - plo}};
+            TRY(reduce_regions(m, c, reg, 3, c->ev_ready[i], c->ev_done[i], pr));
+        }
     }
-    // the step's global sums where fmhip_step_stats / fmhip_dp_epoch read them
-    HIP_TRY(hipMemcpyAsync(m->scal(), c->cg, (size_t)kScalars * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
-    TRY(step_apply_rows(m, eta, reg0, regw, regv, ts.uni, ts.n_u, c->rows_dev, &view));
+    m->bw_next_hi = -1;
+    if (pr) HIP_TRY(hipEventRecord(pr->wait_a, m->stream));
+    int64_t pend_hi = -1;
+    for (int i = n_int - 1; i >= 0; --i) {
+        const int64_t plo = pe[(size_t)i], phi = pe[(size_t)i + 1];
+        if (pend_hi < 0) pend_hi = phi;
+        const bool last = i == 0;
+        HIP_TRY(hipStreamWaitEvent(m->stream, c->ev_done[i], 0));
+        if (!last && (pend_hi - plo) * 8 < ts.n_u) continue;      // small slices share the next one's launch
+        if (last)       // the step's global sums where fmhip_step_stats / fmhip_dp_epoch read them
+            HIP_TRY(hipMemcpyAsync(m->scal(), c->cg, (size_t)kScalars * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
+        if (pr) HIP_TRY(hipEventRecord(pr->a0[pr->n_apply++], m->stream));
+        TRY(step_apply_rows(m, eta, reg0, regw, regv, ts.uni, (int32_t)(pend_hi - plo), c->rows_dev, &view, plo, last));
+        if (pr) HIP_TRY(hipEventRecord(pr->a1[pr->n_apply - 1], m->stream));
+        pend_hi = -1;
+    }
+    if (pr) HIP_TRY(hipEventRecord(pr->wait_b, m->stream));
     m->grad_dirty = packed_dirty;
     c->t_cursor = (t + 1) % (int64_t)c->tsteps.size();
-    if (c->profiling) c->prof_bytes += (int64_t)(L.total * sizeof(float));
     return FMHIP_OK;
 }
 
@@ -640,40 +754,38 @@ int local_checks(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t
                                        "rows): call fmhip_dp_plan with this dataset (every rank)",
                     (long long)batch, (long long)bm.rows, (long long)c->plan_max_rows);
     if (c->exchange == FMHIP_EXCHANGE_TOUCHED) {
-        // the unions were formed for the lock-step schedule "step t = every rank's batch t" of ONE dataset
+        // the unions were formed for the lock-step schedule "position t = every rank's batch t" of ONE dataset
         if (c->planned_data != d)
             return fail(FMHIP_ERR_INVALID, "the touched-rows exchange was planned for another dataset: call fmhip_dp_plan with this one (every rank)");
+        // fmhip_dp_step: a rank without rows follows the cursor, so the ranks with rows must too; any other order goes
+        // through fmhip_dp_step_at, where EVERY rank names the position
         if (in_schedule && batch != c->t_cursor)
-            return fail(FMHIP_ERR_INVALID, "the touched-rows exchange steps through the planned schedule in order: step %lld takes batch %lld "
-                                           "(or -1 on a rank without it), not batch %lld", (long long)c->t_cursor, (long long)c->t_cursor, (long long)batch);
+            return fail(FMHIP_ERR_INVALID, "fmhip_dp_step walks the touched-rows plan in order: step %lld takes batch %lld (or -1 on a rank "
+                                           "without it), not batch %lld; another order: fmhip_dp_step_at / fmhip_dp_epoch_order (every rank)",
+                        (long long)c->t_cursor, (long long)c->t_cursor, (long long)batch);
     }
     return FMHIP_OK;
 }
 
-int dp_step_mode(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0, double regw, double regv) {
+int dp_step_mode(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0, double regw, double regv,
+                 int64_t position) {
     switch (c->exchange) {
-        case FMHIP_EXCHANGE_TOUCHED: return dp_step_touched(m, d, batch, c, eta, reg0, regw, regv);
+        case FMHIP_EXCHANGE_TOUCHED: return dp_step_touched(m, d, batch, c, eta, reg0, regw, regv, position);
         case FMHIP_EXCHANGE_SHARDED: return dp_step_sharded(m, d, batch, c, eta, reg0, regw, regv);
         default: return dp_step_dense(m, d, batch, c, eta, reg0, regw, regv);
     }
 }
 
-int dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0, double regw, double regv) {
-    const int pre = local_checks(m, d, batch, c);
-    if (pre == FMHIP_OK) return dp_step_mode(m, d, batch, c, eta, reg0, regw, regv);
+// position >= 0: the step's place in the lock-step schedule, named by every rank alike (fmhip_dp_step_at; the touched-rows
+// exchange picks that position's union); -1: the next one in order (fmhip_dp_step)
+int dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0, double regw, double regv,
+            int64_t position = -1) {
+    const int pre = local_checks(m, d, batch, c, position < 0);
+    if (pre == FMHIP_OK) return dp_step_mode(m, d, batch, c, eta, reg0, regw, regv, position);
     const std::string why = fmhip_last_error();
-    const int rc = dp_step_mode(m, d, -1, c, eta, reg0, regw, regv);     // keep in step with the peers: contribute zeros
+    const int rc = dp_step_mode(m, d, -1, c, eta, reg0, regw, regv, position);     // keep in step with the peers: contribute zeros
     if (rc != FMHIP_OK) return rc;
     return fail(pre, "%s (this rank contributed zeros to the step)", why.c_str());
-}
-
-// small control collectives (a count, a cut) through a device scratch word
-int control_i64(fmhip_model_t m, fmhip_comm_t c, int64_t *value, int count, bool broadcast_from_0) {
-    HIP_TRY(hipMemcpyAsync(c->scratch, value, count * sizeof(int64_t), hipMemcpyHostToDevice, m->stream));
-    TRY(collective(c, c->scratch, (size_t)count, broadcast_from_0 ? FMHIP_COLL_BCAST0_I64 : FMHIP_COLL_MAX_I64, m->stream));
-    HIP_TRY(hipMemcpyAsync(value, c->scratch, count * sizeof(int64_t), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
-    return FMHIP_OK;
 }
 
 }  // namespace
@@ -838,6 +950,7 @@ int fmhip_comm_info(fmhip_comm_t c, int *rank, int *world) {
 }
 
 int fmhip_dp_plan(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, int n_fractions, const double *upper_fractions, int64_t *cuts_out) {
+    WriteLock lock(m);       // the step changes the model; the communicator is used by the thread that owns its model
     TRY(check_comm(m, c));
     TRY(check_train(m, d));
     if (n_fractions < 0 || n_fractions > kMaxCuts || (n_fractions > 0 && !upper_fractions))
@@ -883,13 +996,10 @@ int fmhip_dp_plan(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, int n_frac
         return fail(FMHIP_ERR_UNSUPPORTED, "the sharded exchange cannot cut %lld rows into %d equal shares on some rank (a caller-owned "
                                            "gradient buffer, fmhip_grad_bind, needs n+1 to be a multiple of world)", (long long)m->n1, W);
     c->plan_max_rows = agree[0];
+    c->plan_steps = agree[4];
     const int64_t blocked = agree[1];
-    if (c->exchange == FMHIP_EXCHANGE_TOUCHED) {
-        if (blocked)
-            return fail(FMHIP_ERR_UNSUPPORTED, "the touched-rows exchange needs transposes without row blocks (some rank's dataset has them)");
-        // id slots per rank = the largest number of rows any batch of any rank touches; steps = the largest batch count
-        TRY(plan_touched(m, d, c, agree[2], agree[4]));
-    }
+    if (c->exchange == FMHIP_EXCHANGE_TOUCHED && blocked)
+        return fail(FMHIP_ERR_UNSUPPORTED, "the touched-rows exchange needs transposes without row blocks (some rank's dataset has them)");
     TRY(control_i64(m, c, cuts, kMaxCuts + 1, true));
     c->cuts.clear();
     for (int i = 0; i < n_fractions && !blocked; ++i) {
@@ -898,6 +1008,9 @@ int fmhip_dp_plan(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, int n_frac
     }
     std::sort(c->cuts.begin(), c->cuts.end());
     c->cuts.erase(std::unique(c->cuts.begin(), c->cuts.end()), c->cuts.end());
+    // the touched-rows plan: id slots per rank = the largest number of rows any batch of any rank touches; positions = the
+    // largest batch count; it places the cuts chosen above in every position's union
+    if (c->exchange == FMHIP_EXCHANGE_TOUCHED) TRY(plan_touched(m, d, c, agree[2], agree[4]));
     if (cuts_out)
         for (int i = 0; i < n_fractions; ++i) cuts_out[i] = i < (int)c->cuts.size() ? c->cuts[c->cuts.size() - 1 - (size_t)i] : 0;
     return FMHIP_OK;
@@ -905,40 +1018,89 @@ int fmhip_dp_plan(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, int n_frac
 
 int fmhip_dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0, double regw,
                   double regv) {
+    WriteLock lock(m);       // the step changes the model; the communicator is used by the thread that owns its model
     TRY(check_comm(m, c));
     TRY(check_train(m, d));
     if (batch >= 0) TRY(check_batch(d, batch));
     return dp_step(m, d, batch, c, eta, reg0, regw, regv);
 }
 
-int fmhip_dp_epoch(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double eta, double reg0, double regw, double regv,
-                   fmhip_stats *stats) {
+int fmhip_dp_step_at(fmhip_model_t m, fmhip_dataset_t d, int64_t position, fmhip_comm_t c, double eta, double reg0, double regw,
+                     double regv) {
+    WriteLock lock(m);       // the step changes the model; the communicator is used by the thread that owns its model
+    TRY(check_comm(m, c));
+    TRY(check_train(m, d));
+    if (position < 0) return fail(FMHIP_ERR_INVALID, "position must be >= 0");
+    return dp_step(m, d, position < (int64_t)d->batches.size() ? position : -1, c, eta, reg0, regw, regv, position);
+}
+
+static int dp_epoch(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double eta, double reg0, double regw, double regv,
+                    const int64_t *order, int64_t n_order, fmhip_stats *stats) {
     TRY(check_comm(m, c));
     TRY(check_train(m, d));
     const int64_t nb = (int64_t)d->batches.size();
     // every rank takes the same number of steps — the largest local batch count — and every rank learns whether SOME
-    // rank's dataset does not fit the plan (then all of them stop here, none inside a collective)
-    int64_t agree[2] = {nb, 0};
+    // rank's dataset does not fit the plan, or whether the ranks disagree about taking an order at all (then all of them stop
+    // here, none inside a collective)
+    int64_t agree[4] = {nb, 0, order ? n_order : -1, order ? -n_order : 1};
     for (int64_t j = 0; j < nb && !agree[1]; ++j) agree[1] = local_checks(m, d, j, c, false) != FMHIP_OK;
     const std::string why = agree[1] ? fmhip_last_error() : "";
-    TRY(control_i64(m, c, agree, 2, false));
+    TRY(control_i64(m, c, agree, 4, false));
     if (agree[1])
         return fail(FMHIP_ERR_INVALID, "%s", why.empty() ? "another rank's dataset does not fit the communicator's plan: call fmhip_dp_plan "
                                                            "with the datasets of this epoch (every rank)" : why.c_str());
     const int64_t steps = agree[0];
+    if (agree[2] != -agree[3] || (order && n_order != steps))
+        return fail(FMHIP_ERR_INVALID, "fmhip_dp_epoch_order: every rank passes the same order of the epoch's %lld positions (this rank: %lld "
+                                       "entries; the ranks' counts range from %lld to %lld)", (long long)steps, (long long)(order ? n_order : -1),
+                    (long long)-agree[3], (long long)agree[2]);
+    if (order) {
+        // a permutation of [0, steps): checked locally — the arrays are the same on every rank by contract, and a rank whose
+        // copy is bad would otherwise walk other positions than its peers
+        std::vector<char> seen((size_t)steps, 0);
+        for (int64_t j = 0; j < steps; ++j) {
+            if (order[j] < 0 || order[j] >= steps || seen[(size_t)order[j]])
+                return fail(FMHIP_ERR_INVALID, "order[%lld] = %lld: the order must be a permutation of [0, %lld)", (long long)j, (long long)order[j], (long long)steps);
+            seen[(size_t)order[j]] = 1;
+        }
+    }
     if (c->exchange == FMHIP_EXCHANGE_TOUCHED) {
         if (steps != (int64_t)c->tsteps.size())
             return fail(FMHIP_ERR_INVALID, "the touched-rows plan covers %zu steps, this epoch has %lld: call fmhip_dp_plan with this dataset (every rank)",
                         c->tsteps.size(), (long long)steps);
         c->t_cursor = 0;
     }
-    for (int64_t j = 0; j < steps; ++j) TRY(dp_step(m, d, j < nb ? j : -1, c, eta, reg0, regw, regv));
+    for (int64_t j = 0; j < steps; ++j) {
+        const int64_t p = order ? order[j] : j;
+        TRY(dp_step(m, d, p < nb ? p : -1, c, eta, reg0, regw, regv, p));
+    }
     if (stats) {
         memset(stats, 0, sizeof *stats);
         TRY(read_scal(m, stats));      // all-reduced: the global batch's sums
         stats->nnz = m->last_nnz;
         stats->steps = steps;
     }
+    return FMHIP_OK;
+}
+
+int fmhip_dp_epoch(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double eta, double reg0, double regw, double regv,
+                   fmhip_stats *stats) {
+    WriteLock lock(m);       // the step changes the model; the communicator is used by the thread that owns its model
+    return dp_epoch(m, d, c, eta, reg0, regw, regv, nullptr, 0, stats);
+}
+
+int fmhip_dp_epoch_order(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double eta, double reg0, double regw, double regv,
+                         const int64_t *order, int64_t n_order, fmhip_stats *stats) {
+    WriteLock lock(m);
+    if (!order || n_order < 0) return dp_epoch(m, d, c, eta, reg0, regw, regv, nullptr, 0, stats);
+    return dp_epoch(m, d, c, eta, reg0, regw, regv, order, n_order, stats);
+}
+
+int fmhip_dp_plan_info(fmhip_comm_t c, int64_t *steps, int64_t *max_batch_rows) {
+    if (!c) return fail(FMHIP_ERR_INVALID, "communicator is NULL");
+    if (c->plan_max_rows < 0) return fail(FMHIP_ERR_INVALID, "no plan yet: call fmhip_dp_plan (every rank)");
+    if (steps) *steps = c->plan_steps;
+    if (max_batch_rows) *max_batch_rows = c->plan_max_rows;
     return FMHIP_OK;
 }
 

@@ -200,9 +200,9 @@ template <typename FT>
 int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const FT *val,
                         const FT *y, int64_t batch_rows, bool scoring, fmhip_dataset_t *out, int hot_opt = -1,
                         int64_t rb_opt = -1) {
-    const bool want_hot = hot_opt < 0 ? g_tune[kTuneHot] > 0 : hot_opt > 0;
-    const int max_hot_pages = std::max(1, std::min(kHotPages, hot_opt > 0 ? hot_opt : g_tune[kTuneHotPages]));
-    const int64_t want_rb = rb_opt < 0 ? (g_tune[kTuneRowBlock] > 0 ? g_tune[kTuneRowBlock] : 0) : rb_opt;
+    const bool want_hot = hot_opt < 0 ? tune_default(kTuneHot) > 0 : hot_opt > 0;
+    const int max_hot_pages = std::max(1, std::min(kHotPages, hot_opt > 0 ? hot_opt : tune_default(kTuneHotPages)));
+    const int64_t want_rb = rb_opt < 0 ? std::max(tune_default(kTuneRowBlock), 0) : rb_opt;
     if (!out) return fail(FMHIP_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (n_rows < 0) return fail(FMHIP_ERR_INVALID, "n_rows < 0");

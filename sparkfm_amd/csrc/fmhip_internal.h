@@ -8,6 +8,9 @@
 
 #include <cstdarg>
 #include <cstdint>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -99,6 +102,21 @@ struct ProfRec {
     int64_t nnz, rows;
 };
 
+// What ONE scoring call (predict / rmse / residual / term_q) works in: its own stream and workspace, so that any number of
+// host threads may score through one frozen model at once (the reference's `predict` runs on executor task threads over a
+// read-only model, S/Model.scala:14 under `local[*]`, S/driver.scala:14).  Pooled per model; a call takes a free one or
+// makes one (fmhip_api.hip: ScoreLease).
+struct ScoreCtx {
+    hipStream_t s = nullptr;
+    hipEvent_t ev = nullptr;        // orders the call behind what the model's own stream has queued (an asynchronous step)
+    DevBuf<float> P, e, yhat;
+    DevBuf<double> bsum, acc;
+    ~ScoreCtx() {
+        if (ev) (void)hipEventDestroy(ev);
+        if (s) (void)hipStreamDestroy(s);
+    }
+};
+
 }  // namespace host
 }  // namespace fmhip
 
@@ -155,6 +173,13 @@ struct fmhip_model {
     // rows allocated (and kept zero) behind row n1p of V and of the library's own packed gradient: the sharded exchange
     // (fmhip_comm.hip) cuts [0, n+1) into `world` equal shares, so its last share may reach up to world - 1 rows past n1p
     static constexpr int kSlackRows = 64;
+    // Threading rule of the C ABI (include/fmhip.h): calls that CHANGE a model (parameters, training, tuning, gradient
+    // buffer, profiling, the data-parallel step) hold `mu` exclusively; the scoring calls and the parameter reads hold it
+    // shared and work in a ScoreCtx of their own — they run side by side and never beside a writer.
+    std::shared_mutex mu;
+    std::mutex pool_mu;                                             // guards the two lists below
+    std::vector<std::unique_ptr<fmhip::host::ScoreCtx>> ctx_all;
+    std::vector<fmhip::host::ScoreCtx *> ctx_free;
     int device = 0;
     int64_t n = 0, n1 = 0, n1p = 0;
     int32_t k = 0, Kp = 0;
@@ -185,7 +210,7 @@ struct fmhip_model {
     // per-model overrides of the tuning keys (fmhip_model_tune); -1 = the process-wide default (fmhip_tune) as it stands
     // at the time of the launch
     int tune[fmhip::kTuneCount];
-    int tv(int key) const { return tune[key] >= 0 ? tune[key] : fmhip::g_tune[key]; }
+    int tv(int key) const { return tune[key] >= 0 ? tune[key] : fmhip::tune_default(key); }
     bool profiling = false;
     bool prof_rotate = false;     // time one kernel kind per step, rotating
     int prof_period = 1;          // ... and only on every prof_period-th step
@@ -210,6 +235,15 @@ namespace host {
 
 extern thread_local std::string g_err;    // the calling thread's last error message (fmhip_api.hip)
 int set_device(int device);
+// the model's lock for the length of a C-ABI call (a NULL model is left to the call's own argument check)
+struct WriteLock {
+    std::unique_lock<std::shared_mutex> lk;
+    explicit WriteLock(fmhip_model_t m) { if (m) lk = std::unique_lock<std::shared_mutex>(m->mu); }
+};
+struct ReadLock {
+    std::shared_lock<std::shared_mutex> lk;
+    explicit ReadLock(fmhip_model_t m) { if (m) lk = std::shared_lock<std::shared_mutex>(m->mu); }
+};
 // ---- fmhip_step.hip
 int ensure_workspace(fmhip_model_t m, fmhip_dataset_t d);
 FwdArgs fwd_args(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm);
@@ -246,8 +280,10 @@ int step_apply_shard(fmhip_model_t m, double eta, double reg0, double regw, doub
 // the rows-only (lazy-decay) update of the feature rows listed on the device (ids < 0 are skipped), |B| from `rows`
 // (device float): the touched-rows exchange of the data-parallel step applies the union of all ranks' rows with it
 // view given: the gradient rows are read from (and zeroed in) its compact arrays, row j belonging to feature feat[j]
+// off / last: the rows [off, off + n_feat) of the list (and of a compact view) only — the touched-rows exchange updates a
+// feature interval as soon as its slice has arrived; the step's bookkeeping (w0, the tables' scale) moves with the LAST slice
 int step_apply_rows(fmhip_model_t m, double eta, double reg0, double regw, double regv, const int32_t *feat, int32_t n_feat,
-                    const float *rows, const GradView *view = nullptr);
+                    const float *rows, const GradView *view = nullptr, int64_t off = 0, bool last = true);
 bool lazy_decay_ok(fmhip_model_t m, double eta, double regw, double regv);
 int read_scal(fmhip_model_t m, fmhip_stats *st);
 

@@ -236,9 +236,9 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
     // the block product rides in the first call whose interval reaches down to the highest hot id (callers that cut the
     // backward go from the top down: every hot row is complete before the interval holding it is exchanged, and the
     // cold intervals in front — whose exchange the rest of the backward hides — are not held up by it)
-    if (whole || finish || d->hot_max_id >= feat_lo) hot_attach(m, d, bm, ba);
-    if (d->rb_rows > 0 && !whole)
+    if (d->rb_rows > 0 && !whole)      // refused before anything of the step's state (hot_pending) is consumed
         return fail(FMHIP_ERR_UNSUPPORTED, "feature-interval backward is not available on a row-blocked dataset");
+    if (whole || finish || d->hot_max_id >= feat_lo) hot_attach(m, d, bm, ba);
     // band-affine placement (tuning key 4 = 2): XCD x walks the ranges of its own row bands first (BwdArgs::xlist); the same
     // choice for every launch of a step — the partials of a cut column are written and read under one rule (no wave sums)
     const bool banded = m->tv(kTuneXcd) == 2 && bm.xoff[0] >= 0 && d->rb_rows == 0;
@@ -552,15 +552,16 @@ bool lazy_decay_ok(fmhip_model_t m, double eta, double regw, double regv) {
 }
 
 int step_apply_rows(fmhip_model_t m, double eta, double reg0, double regw, double regv, const int32_t *feat, int32_t n_feat,
-                    const float *rows, const GradView *view) {
+                    const float *rows, const GradView *view, int64_t off, bool last) {
     if (!lazy_decay_ok(m, eta, regw, regv))
         return fail(FMHIP_ERR_UNSUPPORTED, "a rows-only update needs weight decay that fits the tables' scale (0.5 <= 1 - eta*reg <= 1)");
+    // every slice of a step starts from the scale the step began with (m->sv / m->sw move with the LAST slice only)
     const double sv_out = m->sv * (1.0 - eta * regv), sw_out = m->sw * (1.0 - eta * regw);
     ApplyArgs a{};
     a.sv_in = (float)m->sv;
     a.sw_in = (float)m->sw;
     a.rows_only = 1;
-    a.feat = feat;
+    a.feat = feat + off;
     a.n_feat = n_feat;
     a.hot_ids = nullptr;
     a.n_hot = 0;
@@ -569,25 +570,26 @@ int step_apply_rows(fmhip_model_t m, double eta, double reg0, double regw, doubl
     a.V = m->V.p;
     a.w = m->w.p;
     a.w0 = m->w0.p;
-    a.GV = view ? view->GV : m->GV();
-    a.Gw = view ? view->Gw : m->Gw();
-    a.Gb = view ? view->Gb : m->Gb();
+    a.GV = (view ? view->GV : m->GV()) + (view ? (size_t)off * m->Kp : 0);
+    a.Gw = (view ? view->Gw : m->Gw()) + (view ? off : 0);
+    a.Gb = (view ? view->Gb : m->Gb()) + (view ? off : 0);
     a.scal = view ? view->scal : m->scal();
     a.g_compact = view ? 1 : 0;
     a.rows = rows;
     a.n1 = m->n1;
     a.row_lo = 0;
     a.row_hi = m->n1;
-    a.do_w0 = 1;
+    a.do_w0 = last ? 1 : 0;
     a.pack_k = m->pack_k();
     a.eta = (float)eta;
     a.reg0 = (float)reg0;
     a.regw = (float)regw;
     a.regv = (float)regv;
-    {
+    if (n_feat > 0 || last) {
         ProfScope ps(m, FMHIP_K_APPLY, m->last_nnz, m->last_rows);
         HIP_TRY(launch_apply(m->Kp, a, m->stream));
     }
+    if (!last) return FMHIP_OK;
     m->sv = sv_out;
     m->sw = sw_out;
     if (m->sv < 0x1p-24 || m->sw < 0x1p-24) TRY(fold_scales(m));

@@ -312,6 +312,140 @@ class HostStagedComm(RcclComm):
         _ffi.check(L.fmhip_comm_create_external(fm.handle, rank, world, self._fn, None, C.byref(self._h)))
 
 
+class ThreadGroup:
+    """What N ranks that are THREADS of one process share (ThreadStagedComm): a barrier, one slot per rank and the
+    buffer a reduced result is assembled in — plus the little control plane a caller of thread-ranks needs beside the
+    library's own collectives (barrier, all-reduce of a few host numbers)."""
+
+    def __init__(self, world, timeout=600.0):
+        import threading
+        self.world = int(world)
+        self.timeout = timeout
+        self._barrier = threading.Barrier(self.world)
+        self.slots = [None] * self.world
+        self.out = None
+
+    def barrier(self):
+        self._barrier.wait(self.timeout)
+
+    def abort(self):
+        self._barrier.abort()
+
+    def exchange(self, rank, value):
+        """-> every rank's `value`, in rank order (a host-side all-gather of Python objects)."""
+        self.slots[rank] = value
+        self.barrier()
+        got = list(self.slots)
+        self.barrier()
+        return got
+
+    def allreduce(self, rank, values, op="max"):
+        """Element-wise max / sum over the ranks of a short list of numbers."""
+        got = self.exchange(rank, [float(v) for v in values])
+        f = max if op == "max" else sum
+        return [f(col) for col in zip(*got)]
+
+
+class ThreadStagedComm(RcclComm):
+    """The library's data-parallel step with every rank a THREAD of this process (fmhip_comm_create_external): each
+    collective is staged through the host and reduced between the threads — segment r of a sum by rank r, every element in
+    rank order, so all replicas receive the same bits.  This is the `local[*]` shape of the reference (executor tasks are
+    threads of one JVM, S/driver.scala:14); with one GPU per thread a real deployment takes RcclComm — this transport
+    exists to run a world of 8 on a box with ONE GPU, where RCCL refuses a second rank per device and the test pool admits
+    at most 6 processes on the card.  Not a measurement of anything: every byte crosses PCIe twice."""
+
+    def __init__(self, fm, rank, group):   # noqa: D107 — does not call RcclComm.__init__ (no unique id)
+        import numpy as np
+        L = _ffi.load()
+        world = group.world
+        self.rank, self.world, self.group = rank, world, group
+        self.calls = []                        # (kind, count) of every collective: what the ranks must agree on
+
+        def read(dev, n, dt, stream):
+            host = np.empty(n, dt)
+            _ffi.check(L.fmhip_device_read(_ffi.ptr(host), dev, host.nbytes, stream))
+            return host
+
+        def collective(_ctx, dev, count, kind, stream):
+            try:
+                self.calls.append((kind, count))
+                g = group
+                if kind in (_ffi.COLL_ALLGATHER_I32, _ffi.COLL_ALLGATHER_F32):
+                    dt = np.int32 if kind == _ffi.COLL_ALLGATHER_I32 else np.float32
+                    g.slots[rank] = read(dev + rank * count * 4, count, dt, stream)
+                    g.barrier()
+                    host = np.concatenate(g.slots)
+                    g.barrier()
+                    _ffi.check(L.fmhip_device_write(dev, _ffi.ptr(host), host.nbytes, stream))
+                    return 0
+                if kind == _ffi.COLL_REDUCE_SCATTER_F32:
+                    g.slots[rank] = read(dev, world * count, np.float32, stream)
+                    g.barrier()
+                    mine = g.slots[0][rank * count:(rank + 1) * count].copy()
+                    for r in range(1, world):
+                        mine += g.slots[r][rank * count:(rank + 1) * count]
+                    g.barrier()
+                    _ffi.check(L.fmhip_device_write(dev + rank * count * 4, _ffi.ptr(mine), mine.nbytes, stream))
+                    return 0
+                if kind == _ffi.COLL_SUM_F32:
+                    g.slots[rank] = read(dev, count, np.float32, stream)
+                    if rank == 0:
+                        g.out = np.empty(count, np.float32)
+                    g.barrier()
+                    lo, hi = count * rank // world, count * (rank + 1) // world      # this rank sums its segment, in rank order
+                    seg = g.out[lo:hi]
+                    np.copyto(seg, g.slots[0][lo:hi])
+                    for r in range(1, world):
+                        seg += g.slots[r][lo:hi]
+                    g.barrier()
+                    _ffi.check(L.fmhip_device_write(dev, _ffi.ptr(g.out), g.out.nbytes, stream))
+                    g.barrier()                                                    # nobody reuses `out` before everyone has copied it
+                    return 0
+                g.slots[rank] = read(dev, count, np.int64, stream)
+                g.barrier()
+                host = np.maximum.reduce(g.slots) if kind == _ffi.COLL_MAX_I64 else g.slots[0].copy()
+                g.barrier()
+                _ffi.check(L.fmhip_device_write(dev, _ffi.ptr(host), host.nbytes, stream))
+                return 0
+            except Exception:   # noqa: BLE001 — an exception must not cross the C ABI
+                import traceback
+                traceback.print_exc()
+                group.abort()                      # the peers' barriers break instead of waiting for this rank
+                return 1
+
+        self._fn = _ffi.CollectiveFn(collective)     # kept alive as long as the communicator
+        self._h = C.c_void_p()
+        _ffi.check(L.fmhip_comm_create_external(fm.handle, rank, world, self._fn, None, C.byref(self._h)))
+
+
+def run_thread_ranks(world, fn, timeout=600.0):
+    """Runs fn(rank, group) on `world` threads of this process (one rank each, a shared ThreadGroup) and returns their
+    results in rank order; the first exception of any rank is raised after all threads have ended."""
+    import threading
+    group = ThreadGroup(world, timeout)
+    out, err = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            out[r] = fn(r, group)
+        except BaseException as ex:   # noqa: BLE001
+            err[r] = ex
+            group.abort()
+
+    threads = [threading.Thread(target=body, args=(r,), name="rank%d" % r) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for ex in err:
+        if ex is not None and not isinstance(ex, __import__("threading").BrokenBarrierError):
+            raise ex
+    for ex in err:
+        if ex is not None:
+            raise ex
+    return out
+
+
 class HipDataParallelSGD(FMLearn):
     """FMLearn whose `learn` runs one data-parallel epoch over this rank's row shard INSIDE the library:
     forward -> feature-chunked backward overlapped with the RCCL all-reduce -> identical update
@@ -355,20 +489,43 @@ class HipDataParallelSGD(FMLearn):
         return dict(mode={v: k for k, v in _ffi.EXCHANGE_MODES.items()}[mode.value], id_slots_per_rank=int(cap.value),
                     mean_union_rows=float(mean.value))
 
+    def plan_steps(self):
+        """The lock-step steps of an epoch the plan agreed on (the largest batch count of any rank)."""
+        n = C.c_int64()
+        _ffi.check(_ffi.load().fmhip_dp_plan_info(self.comm.handle, C.byref(n), None))
+        return int(n.value)
+
     def step(self, fm, dataset, batch):
-        """One global step; batch < 0: this rank contributes zeros."""
+        """One global step, the next of the schedule; batch < 0: this rank contributes zeros."""
         if self._planned_for != id(dataset):
             self.plan(fm, dataset)
         _ffi.check(_ffi.load().fmhip_dp_step(fm.handle, dataset.handle, batch, self.comm.handle, self.eta, self.reg0,
                                              self.regw, self.regv))
         fm._device_updated()
 
-    def learn(self, fm, dataset):
+    def step_at(self, fm, dataset, position):
+        """One global step at a position of the lock-step schedule that EVERY rank names alike (this rank's batch
+        `position`, or zeros if it has fewer): the call of a permuted epoch."""
+        if self._planned_for != id(dataset):
+            self.plan(fm, dataset)
+        _ffi.check(_ffi.load().fmhip_dp_step_at(fm.handle, dataset.handle, position, self.comm.handle, self.eta, self.reg0,
+                                                self.regw, self.regv))
+        fm._device_updated()
+
+    def learn(self, fm, dataset, order=None):
+        """One data-parallel epoch; `order`: a permutation of range(plan_steps()), the same on every rank
+        (e.g. numpy's default_rng(shuffle_seed + epoch).permutation(steps)); None = ascending."""
+        import numpy as np
         if self._planned_for != id(dataset):
             self.plan(fm, dataset)
         st = _ffi.Stats()
-        _ffi.check(_ffi.load().fmhip_dp_epoch(fm.handle, dataset.handle, self.comm.handle, self.eta, self.reg0, self.regw,
-                                              self.regv, C.byref(st)))
+        L = _ffi.load()
+        if order is None:
+            _ffi.check(L.fmhip_dp_epoch(fm.handle, dataset.handle, self.comm.handle, self.eta, self.reg0, self.regw, self.regv, C.byref(st)))
+        else:
+            o = np.ascontiguousarray(order, np.int64)
+            _ffi.check(L.fmhip_dp_epoch_order(fm.handle, dataset.handle, self.comm.handle, self.eta, self.reg0, self.regw, self.regv,
+                                              _ffi.ptr(o), len(o), C.byref(st)))
         fm._device_updated()
         self.last_stats = st.as_dict()
         return fm

@@ -1,0 +1,192 @@
+"""The data-parallel step at the world size BASELINE's target is quoted on — EIGHT ranks — on the one GPU of the test box, and
+the threading rule of the C ABI.
+
+RCCL refuses a second rank on a device and the test pool admits at most 6 processes on the card, so the eight ranks are
+THREADS of one worker process (sparkfm_amd.distributed.ThreadStagedComm over fmhip_comm_create_external: every collective
+staged through the host, segment r of a sum reduced by rank r in rank order) — which is also the shape of the reference's own
+deployment, executor tasks as threads of one JVM under `local[*]` (S/driver.scala:14).  Everything but the transport is the
+RCCL path: fmhip_dp_plan's agreement over 8 ranks, the global row count, equal shares of n+1 rows over 8 with the slack rows
+behind the tables, interval edges at multiples of 8, cap x 8 id slots and the union of 8 ranks' touched rows, a rank without
+rows, ranks that run out of batches at different steps.  Checked against the fp64 oracle over the equivalent global batches
+(S/fm/lib/ALS.scala:153: the reduction the learner owns)."""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+ROWS8 = [1700, 700, 0, 1000, 300, 1000, 150, 1000]          # uneven shards; rank 2 holds no rows at all
+
+
+def case8(**kw):
+    cfg = dict(seed=4242, rows=ROWS8, n1_data=800, n1=803, k=32, lo=4, hi=24, batch_rows=500, exchange="dense", fractions=[], epochs=2,
+               eta=0.05, regw=1e-3, regv=1e-3, shuffle_seed=None)
+    cfg.update(kw)
+    return cfg
+
+
+def run_case(cfg, tmp_path, timeout=600):
+    path = os.path.join(str(tmp_path), "case.json")
+    with open(path, "w") as fh:
+        json.dump(cfg, fh)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "dp_case_worker.py"), "threads", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=timeout)
+    assert r.returncode == 0, r.stderr.decode()[-4000:]
+    return json.loads(r.stdout.decode().strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("exchange", ["dense", "sharded"])
+@pytest.mark.parametrize("fractions", [[], [0.3], [0.05, 0.15, 0.3, 0.55]])
+def test_eight_ranks_dense_and_sharded(tmp_path, exchange, fractions):
+    """803 feature rows over 8 ranks (n+1 is no multiple of 8: the top share reaches into the slack rows), 0 / 1 / 4 cuts, both
+    dense modes; replicas bit-identical, same collectives on all 8 ranks, the oracle matched (the worker asserts all three)."""
+    s = run_case(case8(exchange=exchange, fractions=fractions), tmp_path)
+    assert s["world"] == 8 and s["steps"] == 4 and s["rows"] == 200          # the last global batch: rank 0's 200 rows, seven ranks contribute zeros
+    assert s["rel_err_v"] <= 1e-5 and s["rel_err_w"] <= 1e-5
+    calls = np.array(s["calls"], np.int64).reshape(-1, 2)
+    n_int = len([c for c in s["cuts"] if c > 0]) + 1
+    assert len(s["cuts"]) == len(fractions)
+    steps = 2 * 4
+    if exchange == "dense":
+        sums = calls[calls[:, 0] == 0]
+        assert len(sums) == steps * (1 + (1 if n_int == 1 else 3 * n_int))
+    else:
+        assert all(c % 8 == 0 for c in s["cuts"])                               # equal shares: interval edges at multiples of the world
+        for kind in (4, 5):
+            seg = calls[calls[:, 0] == kind][:, 1]
+            assert len(seg) == steps * n_int
+            # per step the shares of one rank add up to ceil(803 / 8) = 101 rows of 32 floats: 808 > 803 rows — the slack rows
+            assert seg.reshape(steps, -1).sum(axis=1).tolist() == [101 * 32] * steps
+
+
+@pytest.mark.parametrize("n1", [803, 50_003])
+def test_eight_ranks_touched_rows(tmp_path, n1):
+    """The touched-rows exchange with 8 ranks: cap x 8 id slots per planned step, the union of eight batches' rows, one compact
+    all-reduce per step; a 50,003-row model of which the data touch 800 (the untouched rows decay as in the oracle's dense
+    update)."""
+    s = run_case(case8(exchange="touched", n1=n1), tmp_path)
+    assert s["world"] == 8 and s["steps"] == 4 and s["rows"] == 200
+    calls = np.array(s["calls"], np.int64).reshape(-1, 2)
+    assert (calls[:, 0] == 3).sum() == 4                                        # the plan: one id all-gather per step of the schedule
+    info = s["info"]
+    assert info["mode"] == "touched" and 0 < info["mean_union_rows"] <= 802 and info["id_slots_per_rank"] <= 802 + 64
+    packed = calls[(calls[:, 0] == 0) & (calls[:, 1] > 1)][:, 1]
+    assert len(packed) == 8 and packed.max() <= 1664 + 804 * 32
+
+
+@pytest.mark.parametrize("exchange", ["dense", "sharded", "touched"])
+def test_eight_ranks_permuted_batch_order(tmp_path, exchange):
+    """`HipSGD.shuffle_seed` data-parallel: every rank takes the same seeded permutation of the batch positions through
+    fmhip_dp_step (a rank without that batch passes -1) — the touched-rows plan is per batch position, so it holds too."""
+    s = run_case(case8(exchange=exchange, fractions=[0.3], shuffle_seed=11, n1=2003), tmp_path)
+    assert s["world"] == 8 and s["rel_err_v"] <= 1e-5
+
+
+def test_four_threads_score_through_one_frozen_model():
+    """include/fmhip.h's threading rule: the scoring calls hold the model's lock shared and work in a context of their own
+    (stream + workspace), so executor threads may score through ONE frozen model at once (S/Model.scala:14 under local[*]).
+    4 threads x 6 rounds of predict / rmse / residual / predict_rows over disjoint row sets == the serial results, bit for bit."""
+    import sparkfm_amd
+    from sparkfm_amd import synth
+    d = synth.make_zipf(5, 40_000, 3000, 4, 40, zipf_s=1.05)
+    w0, w, v = synth.init_params(3, 3000, 32, stdev=0.05)
+    w = np.random.default_rng(4).normal(0, 0.05, 3000)
+    fm = sparkfm_amd.FMModel(2999, 32)
+    fm.w0, fm.w, fm.v = 0.1, w, v
+    _ = fm.handle                                                  # uploaded before any thread starts: the model is frozen from here on
+    parts = []
+    for t in range(4):
+        lo, hi = t * 10_000, (t + 1) * 10_000
+        a, b = int(d["row_ptr"][lo]), int(d["row_ptr"][hi])
+        sub = dict(row_ptr=d["row_ptr"][lo:hi + 1] - a, col=d["col"][a:b], val=d["val"][a:b], y=d["y"][lo:hi])
+        parts.append((sub, sparkfm_amd.DataSet.from_arrays(sub, batch_rows=3000).cache()))
+
+    def score(t):
+        sub, ds = parts[t]
+        idx, val = sub["col"][:int(sub["row_ptr"][1])], sub["val"][:int(sub["row_ptr"][1])].astype(np.float64)
+        return fm.predict(ds), fm.computeRMSE(ds), fm.residual(ds), fm.predict((idx, val))
+
+    serial = [score(t) for t in range(4)]
+    assert abs(serial[0][0][0] - serial[0][3]) <= 1e-6 * (1 + abs(serial[0][3]))
+    got, errs = [[] for _ in range(4)], []
+
+    def body(t):
+        try:
+            for _ in range(6):
+                got[t].append(score(t))
+        except BaseException as ex:   # noqa: BLE001
+            errs.append(ex)
+
+    threads = [threading.Thread(target=body, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errs, errs
+    for t in range(4):
+        for yh, rmse, e, one in got[t]:
+            np.testing.assert_array_equal(yh, serial[t][0])
+            assert rmse == serial[t][1] and one == serial[t][3]
+            np.testing.assert_array_equal(e, serial[t][2])
+    # ... and against the oracle, so that "equal to the serial result" is not two equal mistakes
+    sub = parts[2][0]
+    oy = oracle.predict(0.1, w, v, sub["row_ptr"], sub["col"], sub["val"].astype(np.float64))
+    assert np.abs(serial[2][0] - oy).max() <= 1e-4
+    for _, ds in parts:
+        ds.unpersist()
+    fm.close()
+
+
+def test_two_threads_train_two_models_on_one_gpu():
+    """Two host threads, each training ITS model on ITS dataset on the same GPU at the same time (handles are independent;
+    the process-wide tuning keys are atomic) == the two runs one after the other, bit for bit."""
+    import sparkfm_amd
+    from sparkfm_amd import synth
+    jobs = []
+    for t, (k, n1) in enumerate([(32, 900), (16, 5000)]):
+        d = synth.make_zipf(60 + t, 20_000, n1, 4, 30, zipf_s=1.05)
+        w0, w, v = synth.init_params(8 + t, n1, k, stdev=0.05)
+        jobs.append((d, k, n1, w, v))
+
+    def train(t):
+        d, k, n1, w, v = jobs[t]
+        ds = sparkfm_amd.DataSet.from_arrays(d, batch_rows=4000).cache()
+        fm = sparkfm_amd.FMModel(n1 - 1, k)
+        fm.w0, fm.w, fm.v = 0.0, w, v
+        sgd = sparkfm_amd.HipSGD(eta=0.05, regw=1e-3, regv=1e-3)
+        for _ in range(3):
+            fm = sgd.learn(fm, ds)
+        out = (fm.w0, fm.w.copy(), fm.v.copy(), fm.computeRMSE(ds))
+        ds.unpersist()
+        fm.close()
+        return out
+
+    serial = [train(0), train(1)]
+    got, errs = [None, None], []
+
+    def body(t):
+        try:
+            got[t] = train(t)
+        except BaseException as ex:   # noqa: BLE001
+            errs.append(ex)
+
+    threads = [threading.Thread(target=body, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errs, errs
+    for t in range(2):
+        assert got[t][0] == serial[t][0] and got[t][3] == serial[t][3]
+        np.testing.assert_array_equal(got[t][1], serial[t][1])
+        np.testing.assert_array_equal(got[t][2], serial[t][2])

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     m = re.search(r"#define FMHIP_VERSION (\d+)", hdr)
-    assert L.fmhip_version() == int(m.group(1)) == 300
+    assert L.fmhip_version() == int(m.group(1)) == 400
     m = re.search(r"#define FMHIP_RANGE_LEN (\d+)", hdr)
     assert int(m.group(1)) == _ffi.RANGE_LEN
 
