@@ -13,7 +13,9 @@ synthetic workload, all inputs resident in HBM before the timed region.
           overlapped with the feature-chunked backward).  Per-GPU work per step is fixed -> "weak".
           Started either by the driver (python -m torch.distributed.run ... bench.py --gpus N) or by
           `python bench.py --gpus N` alone: with WORLD_SIZE unset the parent spawns the N ranks itself —
-          before it has touched the GPU — and forwards rank 0's JSON line.
+          before it has touched the GPU — and forwards rank 0's JSON line.  `--transport threads` runs the N
+          ranks as THREADS of this process on GPU 0 (a rehearsal of the whole N-rank flow on a one-GPU box:
+          a world of 8 fits neither RCCL, one rank per device, nor the test pool's 6 processes per card).
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events (recorded by the library on
 the stream its kernels run on) over the timed steps; `cpu_baseline` times the fp64 CPU oracle (a port —
@@ -214,13 +216,18 @@ def committed_pmc(config, k, batch_rows):
 
 
 STEP_KERNELS = ("k_forward", "k_backward", "k_fixup", "k_apply")
+PMC_STATE = {"dead": False}      # a counter pass that had to be killed ends the live collection for the run
 
 
-def pmc_pass(counters, child_argv, skip=4, timeout_s=150):
+def pmc_pass(counters, child_argv, skip=4, timeout_s=150, per_step=None):
     """One `rocprofv3 --pmc <counters> -- python3 <child_argv>` run (counter collection only: no trace domain beside it) as
     a CHILD process; -> {kernel: {counter: mean per dispatch after the first `skip` dispatches of that kernel}} for the
     kernels of the SGD step, or None when rocprofv3 is not there / fails (the caller falls back to the committed profile).
-    Kernel names are folded as in tools/make_pmc_json.py (k_forward_wt -> k_forward, k_backward_p -> k_backward, ...)."""
+    per_step = (warmup_steps, timed_steps) of the child: a kernel the step launches several times (the data-parallel step's
+    backward runs once per feature interval) is then summed over a step's launches — the figure is per STEP of that kernel.
+    Kernel names are folded as in tools/make_pmc_json.py (k_forward_wt -> k_forward, k_backward_p -> k_backward, ...).
+    A pass that runs into its time limit is killed with its whole process group (rocprofv3's grandchild would otherwise keep
+    the GPU busy beside the timed legs that follow) and ends the live collection for this run."""
     import collections
     import csv
     import glob
@@ -234,9 +241,22 @@ def pmc_pass(counters, child_argv, skip=4, timeout_s=150):
     try:
         cmd = [exe, "--pmc"] + list(counters) + ["-d", out_dir, "-o", "pmc", "--output-format", "csv", "--", sys.executable] + list(child_argv)
         env = dict(os.environ, TMPDIR="/tmp")
-        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
-        if r.returncode != 0:
-            sys.stderr.write("[bench] rocprofv3 --pmc %s failed (rc %d): %s\n" % (" ".join(counters), r.returncode, r.stderr.decode()[-400:]))
+        proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+        try:
+            _, err = proc.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            import signal
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            proc.communicate()
+            PMC_STATE["dead"] = True
+            sys.stderr.write("[bench] rocprofv3 --pmc %s ran into its %d s limit: process group killed, no further counter passes in this run\n" %
+                             (" ".join(counters), timeout_s))
+            return None
+        if proc.returncode != 0:
+            sys.stderr.write("[bench] rocprofv3 --pmc %s failed (rc %d): %s\n" % (" ".join(counters), proc.returncode, err.decode()[-400:]))
             return None
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
@@ -246,7 +266,12 @@ def pmc_pass(counters, child_argv, skip=4, timeout_s=150):
                     continue
                 kn = m.group(1).replace("k_forward_wt", "k_forward").replace("k_forward_lds", "k_forward").replace("k_backward_p", "k_backward").replace("k_apply_rows", "k_apply")
                 agg[kn][row["Counter_Name"]].append(float(row["Counter_Value"]))
-        return {kn: {cn: sum(v[skip:]) / max(len(v[skip:]), 1) for cn, v in cs.items() if len(v) > skip} for kn, cs in agg.items()} or None
+        def mean(v):
+            if per_step and len(v) % (per_step[0] + per_step[1]) == 0:
+                lps = len(v) // (per_step[0] + per_step[1])              # launches of this kernel per step
+                return sum(v[per_step[0] * lps:]) / per_step[1]
+            return sum(v[skip:]) / max(len(v[skip:]), 1)
+        return {kn: {cn: mean(v) for cn, v in cs.items() if len(v) > skip} for kn, cs in agg.items()} or None
     except (OSError, subprocess.SubprocessError, KeyError, ValueError) as ex:
         sys.stderr.write("[bench] rocprofv3 --pmc pass failed: %r\n" % (ex,))
         return None
@@ -254,14 +279,16 @@ def pmc_pass(counters, child_argv, skip=4, timeout_s=150):
         shutil.rmtree(out_dir, ignore_errors=True)
 
 
-def live_pmc(child_argv):
+def live_pmc(child_argv, per_step=None):
     """Fabric-side traffic per launch of the step's kernels, measured NOW: two rocprofv3 passes (FETCH_SIZE and WRITE_SIZE
     do not fit one) over tools/pmc_leg.py running the same workload.  Units and the gfx950 correction as
     MI355X_MICROARCH.md prescribes: both counters are KiB; FETCH_SIZE tallies the 128-B requests of wide (16 B per lane)
     reads at 64 B — the row gathers and the dense block's streams are such reads, the 4-B index / value streams are not and
     the counter cannot tell them apart, so the doubled figure is an upper bound.  -> {kernel: {...}} or None."""
-    fetch = pmc_pass(["FETCH_SIZE"], child_argv)
-    write = pmc_pass(["WRITE_SIZE"], child_argv) if fetch else None
+    if PMC_STATE["dead"]:
+        return None
+    fetch = pmc_pass(["FETCH_SIZE"], child_argv, per_step=per_step)
+    write = pmc_pass(["WRITE_SIZE"], child_argv, per_step=per_step) if fetch and not PMC_STATE["dead"] else None
     if not fetch or not write:
         return None
     out = {}
@@ -293,7 +320,8 @@ def roofline_block(kern, dom, ab, pd, pmc, step_ms, live):
     return {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved * 1e9 / HBM_PEAK if achieved else None, "traffic": traffic, "basis": basis,
             "traffic_source": e.get("traffic_source"), "traffic_measured_in_this_run": bool(live),
-            "avg_launch_ms": avg_ms, "nnz_per_launch": pd[dom]["nnz"] / max(pd[dom]["launches"], 1),
+            "avg_launch_ms": avg_ms, "nnz_per_launch": pd[dom]["nnz"] / max(pd[dom]["launches"], 1) * e.get("launches_per_step", 1),
+            "launches_per_step": e.get("launches_per_step", 1),
             "what": "achieved = fabric-side bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE: what left the L2s; Infinity-Cache hits "
                     "are included — the part exposes no DRAM-side or MALL hit counter, profiles/README.md — so an upper bound on HBM bytes) / "
                     "the launch's duration by HIP events in this run; frac = achieved / 8 TB/s",
@@ -307,9 +335,11 @@ def roofline_block(kern, dom, ab, pd, pmc, step_ms, live):
             "requested_GBps": e.get("requested_GBps"), "ceiling": e.get("ceiling"), "frac_of_ceiling": e.get("frac_of_ceiling")}
 
 
-def kernel_table(prof, k, kp, req, pmc, table_bytes):
+def kernel_table(prof, k, kp, req, pmc, table_bytes, launches_per_step=None):
     """Per-kernel: HIP-event time, algorithmic rate, requested-byte rate, the ceiling
-    that binds it and the fraction of THAT ceiling."""
+    that binds it and the fraction of THAT ceiling.  launches_per_step: kernels the data-parallel step launches once per
+    feature interval ({"backward": n, "fixup": n}) — their time, nonzeros and bytes are then per STEP (the sum over a
+    step's launches), which is what the requested-byte and counter figures beside them are."""
     ab = alg_bytes(k)
     pd = prof.as_dict()
     tot_ms = max(sum(x["ms"] for x in pd.values()), 1e-12)
@@ -317,11 +347,15 @@ def kernel_table(prof, k, kp, req, pmc, table_bytes):
     for name, p in pd.items():
         if not p["launches"]:
             continue
-        avg_ms = p["ms"] / p["launches"]
+        lps = max(int((launches_per_step or {}).get(name, 1)), 1)
+        avg_ms = p["ms"] / p["launches"] * lps
         ent = {"avg_ms": avg_ms, "launches": p["launches"], "share": p["ms"] / tot_ms}
+        if lps > 1:
+            ent["launches_per_step"] = lps
+            ent["avg_ms_is"] = "the sum over the %d feature-interval launches of one step" % lps
         if name in ab:
             ent["alg_bytes_per_nnz"] = ab[name]
-            ent["alg_GBps"] = (p["nnz"] / p["launches"]) * ab[name] / (avg_ms * 1e-3) / 1e9
+            ent["alg_GBps"] = (p["nnz"] / p["launches"] * lps) * ab[name] / (avg_ms * 1e-3) / 1e9
         if name in req:
             ent["requested_bytes_per_launch"] = req[name]
             ent["requested_GBps"] = req[name] / (avg_ms * 1e-3) / 1e9
@@ -491,6 +525,58 @@ def c4_one_gpu_leg(device, eta, regs, rows=10_000_000, batch_rows=625_000, passe
     return out
 
 
+class TorchCtl:
+    """The bench's control plane over torch.distributed (gloo; nccl when the exchange itself is torch's): barriers and
+    reductions of a few timers — never the gradients."""
+
+    def __init__(self, dist, torch, on_gpu):
+        self.dist, self.torch, self.on_gpu = dist, torch, on_gpu
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def allreduce(self, values, op="max"):
+        t = self.torch.tensor([float(v) for v in values], dtype=self.torch.float64)
+        if self.on_gpu:
+            t = t.cuda()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
+        return [float(x) for x in t.cpu()]
+
+    def sum_counts(self, counts):
+        t = self.torch.from_numpy(counts)
+        if self.on_gpu:
+            t = t.cuda()
+        self.dist.all_reduce(t)
+        return t.cpu().numpy()
+
+
+class ThreadCtl:
+    """The same over the ranks-as-threads group (--transport threads)."""
+
+    def __init__(self, group, rank):
+        self.group, self.rank = group, rank
+
+    def barrier(self):
+        self.group.barrier()
+
+    def allreduce(self, values, op="max"):
+        return self.group.allreduce(self.rank, values, op)
+
+    def sum_counts(self, counts):
+        return sum(self.group.exchange(self.rank, counts))
+
+
+class NoCtl:
+    def barrier(self):
+        pass
+
+    def allreduce(self, values, op="max"):
+        return [float(v) for v in values]
+
+    def sum_counts(self, counts):
+        return counts
+
+
 def spawn_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (this process
     has not touched the GPU and never will), forward rank 0's JSON line, exit with the worst exit code."""
@@ -554,10 +640,12 @@ def main():
                          "overlapped slices, every rank updates every row; sharded = the slices reduce-scattered, every rank updates its "
                          "1/N share, the updated rows all-gathered; touched = only the rows some rank touched; auto = touched for C5 "
                          "(an 8.9 GB gradient), otherwise dense and sharded are both timed during warm-up and the faster is kept")
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "host", "threads"],
                     help="rccl: one rank per GPU, the library's RCCL communicator; host: ALL ranks on GPU 0, the library's step over "
                          "fmhip_comm_create_external with every collective staged through the host and summed by gloo — the same "
-                         "schedule, plan and update, for boxes with fewer GPUs than ranks (a rehearsal, not a measurement)")
+                         "schedule, plan and update, for boxes with fewer GPUs than ranks (a rehearsal, not a measurement); threads: the "
+                         "same with the ranks as THREADS of this one process (ThreadStagedComm) — a world of 8 on a one-GPU box, where "
+                         "RCCL wants one device per rank and the test pool admits 6 processes per card")
     ap.add_argument("--upper-fractions", default="auto",
                     help="cuts of the backward for the overlapped exchange: comma-separated ascending shares of the nonzeros at or "
                          "above each cut (e.g. 0.3 or 0.12,0.4), 'none' = one all-reduce after the whole backward, 'auto' = "
@@ -576,6 +664,20 @@ def main():
                     help="A/B: fmhip_tune(KEY, VALUE) before anything is built (repeatable); see include/fmhip.h")
     ap.add_argument("--cpu-budget", type=float, default=30.0)
     args = ap.parse_args()
+    if args.transport == "threads":
+        if args.exchange != "rccl":
+            raise SystemExit("--transport threads runs the library's own step (--exchange rccl)")
+        # stdout carries exactly one JSON line (see below)
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
+        import torch
+        from sparkfm_amd import _ffi, synth
+        from sparkfm_amd.distributed import run_thread_ranks
+        _ffi.load()
+        synth.set_threads(max(1, host_cores() // max(1, min(args.gpus, 8))))
+        run_thread_ranks(args.gpus, lambda r, g: run_rank(args, r, args.gpus, 0, ThreadCtl(g, r), json_fd, torch, group=g), timeout=1800.0)
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args, sys.argv[1:])
     # stdout carries exactly one JSON line: libraries that print banners to fd 1 (RCCL prints its
@@ -596,20 +698,32 @@ def main():
         local_rank = 0                      # every rank shares the one GPU; the collectives are staged through the host
     torch.cuda.set_device(local_rank)
     use_dp = world > 1 or args.force_dp
-    exchange = args.exchange if use_dp else "none"
+    ctl = NoCtl()
     if use_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if exchange == "rccl":
+        if args.exchange == "rccl":
             # control plane only (unique id, barriers, the max over ranks): the gradients never pass through it
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        ctl = TorchCtl(dist, torch, args.exchange == "torch")
+    run_rank(args, rank, world, local_rank, ctl, json_fd, torch)
+    if use_dp:
+        dist.destroy_process_group()
 
+
+def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
+    """One rank of the bench (a process, or a thread under --transport threads)."""
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    use_dp = world > 1 or args.force_dp
+    exchange = args.exchange if use_dp else "none"
     from sparkfm_amd import DataSet, FMModel, _ffi, synth
-    from sparkfm_amd.distributed import DataParallelSGD, HipDataParallelSGD, HostStagedComm, RcclComm, torch_stream_handle
+    from sparkfm_amd.distributed import (DataParallelSGD, HipDataParallelSGD, HostStagedComm, RcclComm, ThreadStagedComm,
+                                         torch_stream_handle)
 
     config = args.config or ("C4" if world > 1 else "C3")
     cfg = synth.CONFIGS[config]
@@ -623,7 +737,8 @@ def main():
     for kv in args.tune:
         key, value = kv.split("=")
         _ffi.check(_ffi.load().fmhip_tune(int(key), int(value)))
-    synth.set_threads(max(1, host_cores() // max(1, min(world, 8))) if world > 1 else host_cores())
+    if group is None:       # (thread-ranks share the generator's thread count: set once, before they start)
+        synth.set_threads(max(1, host_cores() // max(1, min(world, 8))) if world > 1 else host_cores())
     t0 = time.time()
     d = synth.make_config(config, rows=rows, row_begin=rank * rows)
     relabelled = bool(cfg.get("criteo")) and not args.no_relabel
@@ -631,7 +746,7 @@ def main():
         # hashed slots come in no particular order: relabel by frequency at load (a pure renaming of the features;
         # the counts are summed over the ranks so that every replica uses the same numbering)
         from sparkfm_amd import FeatureOrder
-        d["col"] = FeatureOrder.fit(d["col"], cfg["features"], distributed=world > 1).relabel(d["col"])
+        d["col"] = FeatureOrder.from_counts(ctl.sum_counts(FeatureOrder.counts(d["col"], cfg["features"]))).relabel(d["col"])
     t_gen = time.time() - t0
     t0 = time.time()
     ds = DataSet.from_arrays(d, name=config, batch_rows=batch_rows, device=local_rank).cache()
@@ -654,7 +769,8 @@ def main():
     comm_note = None
     if exchange == "rccl":
         try:
-            comm = HostStagedComm(fm, rank, world) if args.transport == "host" else RcclComm(fm, rank, world)
+            comm = (ThreadStagedComm(fm, rank, group) if group is not None else
+                    (HostStagedComm(fm, rank, world) if args.transport == "host" else RcclComm(fm, rank, world)))
             fixed = None if args.upper_fractions == "auto" else (() if args.upper_fractions == "none" else
                                                                  tuple(float(x) for x in args.upper_fractions.split(",")))
             dp_mode = args.dp_exchange if args.dp_exchange != "auto" else ("touched" if cfg.get("criteo") else "dense")
@@ -671,6 +787,8 @@ def main():
                 _ffi.check(L.fmhip_comm_emulate(comm.handle, emu_busbw * emu_ranks / (2.0 * (emu_ranks - 1))))
                 _ffi.check(L.fmhip_comm_emulate_ranks(comm.handle, emu_ranks))
         except Exception as ex:   # noqa: BLE001 — reported in the JSON line, never silent
+            if group is not None:
+                raise
             # every rank fails or succeeds together (communicator creation is collective); fall back to the
             # Python-orchestrated exchange over torch.distributed
             comm_note = "library-side RCCL exchange unavailable (%r): fell back to torch.distributed" % (ex,)
@@ -678,6 +796,7 @@ def main():
             exchange = "torch"
             dist.destroy_process_group()
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            ctl = TorchCtl(dist, torch, True)
             fm.close()
             fm = FMModel(n1 - 1, k, device=local_rank, stream=torch_stream_handle(local_rank), init_on_device=wide,
                          seed=cfg["seed"] + 1000)
@@ -702,8 +821,7 @@ def main():
         torch.cuda.synchronize()
 
     def barrier():
-        if use_dp:
-            dist.barrier()
+        ctl.barrier()
 
     for j in range(args.warmup):
         step(j)
@@ -716,7 +834,7 @@ def main():
         tuning = []
         modes = ("dense", "sharded") if args.dp_exchange == "auto" else (dp.exchange,)
         cands = ((0.3,), (0.2,), (0.12, 0.4), (0.08, 0.25, 0.5), (0.05, 0.15, 0.3, 0.55), (0.04, 0.1, 0.2, 0.35, 0.6), ())
-        if args.transport == "host":
+        if args.transport != "rccl":
             cands = ((0.12, 0.4), ())        # a rehearsal of the flow: every step moves the whole gradient through the host
         for mode in modes:
             dp.set_exchange(mode)
@@ -730,10 +848,8 @@ def main():
                 for j in range(4):
                     step(j)
                 sync()
-                tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-                if use_dp:
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                tuning.append({"exchange": mode, "upper_fractions": list(cand), "cuts": list(dp.cuts), "ms_per_step": float(tt[0]) / 4 * 1e3})
+                tt = ctl.allreduce([time.perf_counter() - t0], "max")
+                tuning.append({"exchange": mode, "upper_fractions": list(cand), "cuts": list(dp.cuts), "ms_per_step": tt[0] / 4 * 1e3})
         best = min(tuning, key=lambda x: x["ms_per_step"])
         dp.set_exchange(best["exchange"])
         dp.upper_fractions = tuple(best["upper_fractions"])
@@ -768,16 +884,8 @@ def main():
         cprof = cp.as_dict()
         barrier()
     local_nnz = sum(bnnz[j % nb] for j in range(args.warmup, args.warmup + args.steps))
-    if use_dp:
-        t = torch.tensor([elapsed, float(local_nnz)], dtype=torch.float64)
-        if exchange == "torch":
-            t = t.cuda()
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed, total_nnz = float(tmax[0]), float(t[1])
-    else:
-        total_nnz = float(local_nnz)
+    elapsed = ctl.allreduce([elapsed], "max")[0]
+    total_nnz = ctl.allreduce([float(local_nnz)], "sum")[0]
     st = _ffi.Stats()
     _ffi.check(L.fmhip_step_stats(hm, C.byref(st)))
 
@@ -793,22 +901,12 @@ def main():
             n_done += 4 * nb
             sync()
             dt = time.perf_counter() - t0
-            flag = torch.tensor([1.0 if dt < 2.0 else 0.0])
-            if use_dp:
-                if exchange == "torch":
-                    flag = flag.cuda()
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX)     # every rank takes the same number of steps
-            if float(flag[0]) == 0.0:
+            if ctl.allreduce([1.0 if dt < 2.0 else 0.0], "max")[0] == 0.0:      # every rank takes the same number of steps
                 break
         barrier()
         dt = time.perf_counter() - t0
         s_nnz = float(sum(bnnz[j % nb] for j in range(n_done)))
-        if use_dp:
-            t = torch.tensor([s_nnz], dtype=torch.float64)
-            if exchange == "torch":
-                t = t.cuda()
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            s_nnz = float(t[0])
+        s_nnz = ctl.allreduce([s_nnz], "sum")[0]
         sustained = {"seconds": dt, "steps": n_done, "value": s_nnz / dt, "unit": "nnz/s", "ms_per_step": dt / n_done * 1e3}
 
     # ---- the same shard and batch WITHOUT the exchange (what one GPU of the job does alone)
@@ -846,8 +944,9 @@ def main():
     twin = None
     if exchange == "rccl" and dp.exchange != "touched" and config != "C3" and not args.no_extra:
         c3 = synth.CONFIGS["C3"]
-        d3 = synth.make_config("C3", rows=1_000_000, row_begin=rank * 1_000_000)
-        ds3 = DataSet.from_arrays(d3, name="C3", batch_rows=250_000, device=local_rank).cache()
+        rows3 = 1_000_000 if not args.rows else min(1_000_000, max(args.rows, 1000))     # a rehearsal with --rows keeps the twin small too
+        d3 = synth.make_config("C3", rows=rows3, row_begin=rank * rows3)
+        ds3 = DataSet.from_arrays(d3, name="C3", batch_rows=min(250_000, rows3), device=local_rank).cache()
         fm3 = FMModel(c3["features"] - 1, c3["k"], seed=c3["seed"] + 1000, device=local_rank, init_on_device=True)
         nb3 = ds3.n_batches
         nnz3 = [ds3.batch_info(b)["nnz"] for b in range(nb3)]
@@ -869,10 +968,9 @@ def main():
                 for j in range(8):
                     step3(j)
                 _ffi.check(L.fmhip_synchronize(fm3.handle))
-                tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                if best3 is None or float(tt[0]) < best3[0]:
-                    best3 = (float(tt[0]), cand, mode3)
+                tt = ctl.allreduce([time.perf_counter() - t0], "max")
+                if best3 is None or tt[0] < best3[0]:
+                    best3 = (tt[0], cand, mode3)
         dp.set_exchange(best3[2])
         dp.upper_fractions = best3[1]
         dp.plan(fm3, ds3)
@@ -885,12 +983,10 @@ def main():
             step3(j)
         _ffi.check(L.fmhip_synchronize(fm3.handle))
         barrier()
-        t3 = torch.tensor([time.perf_counter() - t0, float(sum(nnz3[j % nb3] for j in range(args.steps)))], dtype=torch.float64)
-        tm = t3.clone()
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t3, op=dist.ReduceOp.SUM)
-        twin = {"workload": "C3 on every GPU: 1000000 rows x 100000 features per GPU, k=32, batch 250000 rows per GPU — the N = 1 line's workload",
-                "value": float(t3[1]) / float(tm[0]), "unit": "nnz/s", "ms_per_step": float(tm[0]) / args.steps * 1e3,
+        tm = ctl.allreduce([time.perf_counter() - t0], "max")
+        t3 = ctl.allreduce([float(sum(nnz3[j % nb3] for j in range(args.steps)))], "sum")
+        twin = {"workload": "C3 on every GPU: %d rows x 100000 features per GPU, k=32, batch %d rows per GPU — the N = 1 line's workload" % (rows3, min(250_000, rows3)),
+                "value": t3[0] / tm[0], "unit": "nnz/s", "ms_per_step": tm[0] / args.steps * 1e3,
                 "allreduce_bytes_per_step": 4 * (32 + (c3["features"] + 31) // 32 * 32 * 34), "cuts": list(dp.cuts), "exchange": dp.exchange}
         ds3.unpersist()
         fm3.close(discard=True)
@@ -907,6 +1003,21 @@ def main():
         packed = k < kp
         pmc = committed_pmc(config, k, batch_rows)
         live = None
+        lps = None
+        if exchange == "rccl":
+            # the data-parallel step launches backward + fixup once per feature interval: figures are per step (kernel_table)
+            n_int = len([c for c in dp.cuts if c > 0]) + 1
+            lps = {"backward": n_int, "fixup": n_int}
+        if exchange == "rccl" and dp.exchange != "touched" and config == "C4" and not args.no_pmc and not args.tune and not args.hot_pages:
+            # N > 1 (or --force-dp): the counters of THIS rank's workload under the step this line timed — the same shard size,
+            # batch, cuts and exchange mode through the library's own data-parallel step with a one-rank communicator whose
+            # collectives are the identity (tools/pmc_leg.py c4) — measured now, on rank 0's GPU, while the other ranks wait
+            fr = ",".join(str(f) for f in dp.upper_fractions) or "none"
+            live = live_pmc([os.path.join(ROOT, "tools", "pmc_leg.py"), "c4", "--rows", str(min(rows, 2 * batch_rows)), "--batch-rows", str(batch_rows),
+                             "--upper-fractions", fr, "--dp-exchange", dp.exchange, "--steps", "8", "--warmup", "4"], per_step=(4, 8))
+            for kn, e in (live or {}).items():
+                pmc.setdefault(kn, {}).update(e, traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py invocation on "
+                                                                "rank 0's GPU (tools/pmc_leg.py c4: the same shard size, batch, cuts and mode)")
         if world == 1 and not use_dp and not args.no_pmc and config in ("C2", "C3") and not args.tune and not args.hot_pages:
             # the counters of THIS workload, measured now: rocprofv3 child processes over tools/pmc_leg.py (same config,
             # rows and batch; the committed profile is the fallback when rocprofv3 is not available)
@@ -924,7 +1035,7 @@ def main():
         dense_apply = (use_dp and not (exchange == "rccl" and dp.exchange == "touched")) or n_cols * 2 > n1
         req = requested_bytes(kp, rows0, nnz0, nnz0_sparse, n_cols, hot, n_cols, dense_apply, n1, packed, nnz0_sparse_b, lay["hot_pages"])
         table_bytes = {"forward": n1 * kp * 4, "backward": rows0 * kp * 4}
-        kern = kernel_table(prof, k, kp, req, pmc, table_bytes)
+        kern = kernel_table(prof, k, kp, req, pmc, table_bytes, lps)
         # the dominant kernel = the longest launch (not the largest sampled total: kinds are sampled in rotation)
         dom = max(("forward", "backward"), key=lambda n: kern.get(n, {}).get("avg_ms", 0.0))
         pd = prof.as_dict()
@@ -952,7 +1063,9 @@ def main():
                                               "note": "ranges of long columns walked on the XCD that owns their row band (fmhip_tune key 4)"},
                        "parallelism": "dp%d" % world, "exchange": exchange,
                        "transport": ("host-staged gloo over fmhip_comm_create_external, all ranks on GPU 0 (a rehearsal of the N-rank flow, "
-                                     "not a measurement)" if args.transport == "host" and use_dp else ("RCCL" if use_dp else "none")),
+                                     "not a measurement)" if args.transport == "host" and use_dp else
+                                     ("host-staged between the ranks-as-threads of ONE process over fmhip_comm_create_external, all on GPU 0 (a "
+                                      "rehearsal of the N-rank flow, not a measurement)" if args.transport == "threads" else ("RCCL" if use_dp else "none"))),
                        "allreduce": ("inside the library, touched rows only" if exchange == "rccl" and dp.exchange == "touched" else
                                      ("inside the library, %s, overlapped with the feature-chunked backward, cuts at features %s" %
                                       ("reduce-scatter -> sharded update -> all-gather" if dp.exchange == "sharded" else "all-reduce, every rank updates every row", dp.cuts))
@@ -979,7 +1092,10 @@ def main():
                   "mode": dp.exchange if exchange == "rccl" else "dense"}
             if exchange == "rccl" and dp.exchange == "touched":
                 info = dp.exchange_info()
-                xc["mode_note"] = "touched rows (fmhip_dp_exchange): all-gather of ids, sorted union, packed all-reduce, rows-only update"
+                xc["mode_note"] = ("touched rows (fmhip_dp_exchange): the union of the rows every position's batches touch is planned ONCE "
+                                   "(fmhip_dp_plan: all-gather of ids, sort, unique); a step writes its gradient into a compact buffer with one "
+                                   "row per union feature, all-reduces it in feature-interval slices under the backward, and applies the "
+                                   "rows-only update with lazy weight decay — no id exchange, sort or read-back in the step")
                 xc["dense_gradient_bytes"] = payload
                 xc["id_slots_per_rank"] = info["id_slots_per_rank"]
                 xc["mean_union_rows"] = info["mean_union_rows"]
@@ -1000,8 +1116,8 @@ def main():
             if one_gpu_plain:
                 # the like-for-like scaling of THIS line: the job's throughput over what one GPU does alone on the same workload
                 # (C4's shard and batch, the plain step) — the driver's N = 1 line is C3, another width
-                xc["c4_one_gpu"] = one_gpu_plain
-                xc["scaling_vs_c4_one_gpu"] = value / one_gpu_plain["value"]
+                xc["%s_one_gpu" % config.lower()] = one_gpu_plain
+                xc["scaling_vs_%s_one_gpu" % config.lower()] = value / one_gpu_plain["value"]
             if comm_note:
                 xc["note"] = comm_note
             if tuning:
@@ -1009,7 +1125,9 @@ def main():
             if args.emulate_allreduce:
                 xc["emulated"] = "ring all-reduce over %s GPUs at bus bandwidth %s GB/s, as a delay on the comm stream (one real rank)" % tuple(args.emulate_allreduce.split(":"))
             out["exchange"] = xc
-        if world == 1 and not args.no_cpu_baseline and not wide:
+        if not args.no_cpu_baseline and not wide:
+            # rank 0's host cores, on rank 0's shard of the line's own workload, after every timed region (at N > 1 the other
+            # ranks wait at the closing barrier); the ratio at N > 1 is the JOB's throughput over that one-host baseline
             out["cpu_baseline"] = cpu_baseline(d, k, n1, batch_rows, args.eta, regs, w0, w, v, args.cpu_budget)
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
         if world == 1 and not args.no_extra and not use_dp:
@@ -1033,10 +1151,9 @@ def main():
             out["extra"] = extra
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dp:
-        dist.barrier()
+        ctl.barrier()
         if comm is not None:
             comm.close()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -68,9 +68,14 @@ class FMModel(Model):
         self._h = None
         self._host_fresh = not self._init_on_device   # host arrays hold the current parameters
         self._dev_fresh = False                       # device holds the current parameters
+        self._lost = False                            # close() dropped the only copy of the parameters (see close)
 
     # -- parameter access (lazy host<->device sync) --------------------------------------
     def _pull(self):
+        if self._lost:
+            raise RuntimeError("this FMModel's parameters were discarded by close(): the device copy was freed without being read back "
+                               "(close(discard=True), or a model drawn on the device that nobody had read) — pull them before closing "
+                               "(fm.v, fm.rows(ids)) or assign new ones (fm.w0, fm.w, fm.v = ...)")
         if not self._host_fresh:
             w0 = C.c_double()
             flat = np.empty(self.num_factor * (self.num_attribute + 1))
@@ -84,9 +89,20 @@ class FMModel(Model):
         self._pull()
         return self._w0
 
+    def _assign(self):
+        """Before a setter replaces one of the three parameters: the other two must be current (or, after a discarding
+        close, restart from the state of a fresh model so that assigning all three brings the model back)."""
+        if self._lost:
+            self._lost = False
+            self._host_fresh = True
+            self._w0 = 0.0
+            self._w = np.zeros(self.num_attribute + 1)
+            self._v = np.zeros((self.num_factor, self.num_attribute + 1), order="F")
+        self._pull()
+
     @w0.setter
     def w0(self, x):
-        self._pull()
+        self._assign()
         self._w0 = float(x)
         self._dev_fresh = False
 
@@ -98,7 +114,7 @@ class FMModel(Model):
 
     @w.setter
     def w(self, x):
-        self._pull()
+        self._assign()
         self._w = np.array(x, np.float64).reshape(self.num_attribute + 1)
         self._dev_fresh = False
 
@@ -109,7 +125,7 @@ class FMModel(Model):
 
     @v.setter
     def v(self, x):
-        self._pull()
+        self._assign()
         x = np.asarray(x, np.float64)
         if x.shape != (self.num_factor, self.num_attribute + 1):
             raise ValueError("v must have shape (num_factor, num_attribute + 1)")
@@ -134,6 +150,8 @@ class FMModel(Model):
     def handle(self):
         """Device model with the current parameters uploaded."""
         L = _ffi.load()
+        if self._lost:
+            self._pull()       # raises: there is nothing to upload
         if self._h is None:
             h = C.c_void_p()
             _ffi.check(L.fmhip_model_create(self.device, self.num_attribute, self.num_factor, self._stream, C.byref(h)))
@@ -155,11 +173,14 @@ class FMModel(Model):
         """Frees the device model.  The parameters are copied back to the host first so that `fm.w` / `fm.v` keep
         working — except with `discard=True`, or for a model drawn on the device (`init_on_device=True`: it exists so
         that no host copy is made until one is asked for; at 2^25 x 64 the copy is 8.6 GB of fp32 staging plus a 17 GB
-        fp64 array) whose parameters nobody has read yet.  After such a close `fm.w` / `fm.v` are gone: pull them
-        first (`fm.v`, `fm.rows(ids)`) if they are wanted."""
+        fp64 array) whose parameters nobody has read yet.  After such a close the trained values are GONE and the model
+        says so: `fm.w` / `fm.v` / `predict` raise until new parameters are assigned — it does not quietly hand back stale
+        host arrays or re-draw the initial ones.  Pull them first (`fm.v`, `fm.rows(ids)`) if they are wanted."""
         if self._h is not None:
             if not discard and not (self._init_on_device and self._v is None):
                 self._pull()
+            elif not self._host_fresh:
+                self._lost = True          # the device held the only current copy
             _ffi.load().fmhip_model_destroy(self._h)
             self._h = None
             self._dev_fresh = False

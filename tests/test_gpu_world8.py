@@ -190,3 +190,39 @@ def test_two_threads_train_two_models_on_one_gpu():
         assert got[t][0] == serial[t][0] and got[t][3] == serial[t][3]
         np.testing.assert_array_equal(got[t][1], serial[t][1])
         np.testing.assert_array_equal(got[t][2], serial[t][2])
+
+
+def test_bench_with_eight_thread_ranks():
+    """`python bench.py --gpus 8 --transport threads`: the bench's whole N = 8 flow on the one GPU of the test box — eight ranks
+    as threads of one process, the library's communicators over the thread transport, plan agreement, cut AND mode tuning over
+    8 ranks, the timed region with its barriers and max over ranks, the exchange profile, the legs without exchange, the C3
+    twin, rank 0's counter passes (rocprofv3 child processes over tools/pmc_leg.py c4) and CPU baseline while the other ranks
+    wait, the JSON assembly.  Timings mean nothing here (every byte crosses PCIe twice); the flow, the record's completeness
+    and its wall time are what is tested."""
+    import time
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--transport", "threads", "--steps", "4", "--warmup", "2",
+           "--rows", "100000", "--batch-rows", "50000", "--cpu-budget", "3"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stderr.decode()[-4000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["steps"] == 4 and out["warmup"] == 2
+    assert out["metric"] == "nnz_per_sec_fm_sgd_training" and out["value"] > 0 and out["ms_per_step"] > 0
+    assert out["config"]["workload"].startswith("C4") and out["config"]["rows_per_gpu"] == 100000
+    x = out["exchange"]
+    assert x["nranks"] == 8 and x["transport"] == "threads" and x["mode"] in ("dense", "sharded")
+    assert {t["exchange"] for t in x["cut_tuning"]} == {"dense", "sharded"} and all(t["ms_per_step"] > 0 for t in x["cut_tuning"])
+    assert any(len(t["cuts"]) == 2 and all(c % 8 == 0 for c in t["cuts"]) for t in x["cut_tuning"] if t["exchange"] == "sharded")
+    assert x["exposed_comm_ms"] >= 0 and x["comm_busy_ms"] > 0
+    assert x["c3_on_every_gpu"]["value"] > 0 and x["per_gpu_without_exchange"]["value"] > 0
+    assert x["c4_one_gpu"]["value"] > 0 and x["scaling_vs_c4_one_gpu"] > 0
+    # the N > 1 line is a complete record: roofline from counters (measured in this run, or the committed C4 pass) + cpu_baseline
+    rf = out["roofline"]
+    assert rf["basis"] == "counters" and rf["traffic"] > 0 and 0 < rf["frac"] < 1.5 and rf["kernel"] in ("k_forward", "k_backward")
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["cores"] >= 1 and out["cpu_baseline"]["kind"] == "port"
+    assert out["train"]["nonfinite"] == 0 and out["sustained"]["steps"] > 0
+    assert wall < 600, wall

@@ -27,6 +27,9 @@ def short(name):
     return (m.group(1), (m.group(1) + (m.group(2) or ""))) if m else (None, name[:40])
 
 
+PER_STEP = None      # (warmup steps, timed steps) of the profiled command: kernels launched several times per step are summed per step
+
+
 def load_pmc(tag, name, skip):
     files = glob.glob(os.path.join(ROOT, "gpurun_out", "%s_%s" % (tag, name), "**", "*counter_collection.csv"), recursive=True)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -37,9 +40,15 @@ def load_pmc(tag, name, skip):
             if base:
                 agg[base][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 full[base] = fn
+    def mean(v):
+        if PER_STEP and len(v) % (PER_STEP[0] + PER_STEP[1]) == 0:
+            lps = len(v) // (PER_STEP[0] + PER_STEP[1])
+            return sum(v[PER_STEP[0] * lps:]) / PER_STEP[1]
+        return sum(v[skip:]) / max(len(v[skip:]), 1)
+
     out = {}
     for kn, cs in agg.items():
-        out[kn] = {cn: sum(v[skip:]) / max(len(v[skip:]), 1) for cn, v in cs.items()}
+        out[kn] = {cn: mean(v) for cn, v in cs.items()}
     return out, full
 
 
@@ -47,6 +56,11 @@ def main():
     tag, config, k, batch_rows = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
     command = sys.argv[5] if len(sys.argv) > 5 else "python3 bench.py --no-cpu-baseline --no-extra --steps 12 --warmup 4"
     skip = 4
+    per_step_note = ""
+    if len(sys.argv) > 7:      # <warmup steps> <timed steps>: per-STEP figures (the data-parallel step launches its backward once per interval)
+        global PER_STEP
+        PER_STEP = (int(sys.argv[6]), int(sys.argv[7]))
+        per_step_note = " — kernels launched several times per step: SUM over one step's launches"
     lines = []
     stats = glob.glob(os.path.join(ROOT, "gpurun_out", tag + "_stats", "**", "*kernel_stats.csv"), recursive=True)
     durations = {}
@@ -65,7 +79,7 @@ def main():
     sq, _ = load_pmc(tag, "sq", skip)
     extra = {name: load_pmc(tag, name, skip)[0] for name in EXTRA_PASSES}
     lines.append("")
-    lines.append("# rocprofv3 --pmc, one pass per group (mean per dispatch after the first %d dispatches of each kernel)" % skip)
+    lines.append("# rocprofv3 --pmc, one pass per group (mean per dispatch after the first %d dispatches of each kernel%s)" % (skip, per_step_note))
     entries = []
     step_kernels = ("k_forward", "k_backward", "k_fixup", "k_apply")      # the SGD step; the dataset build's kernels are setup
     for kn in sorted(set(fetch) | set(write) | set(l2)):
@@ -100,7 +114,7 @@ def main():
             ent = {"config": config, "k": k, "batch_rows": batch_rows, "kernel": kn.replace("k_forward_wt", "k_forward").replace("k_backward_p", "k_backward").replace("k_apply_rows", "k_apply"),
                    "kernel_instance": full.get(kn, kn), "fetch_raw_bytes": int(fr * 1024), "fetch_corrected_bytes": int(2 * fr * 1024),
                    "write_bytes": int(wr * 1024), "traffic_bytes": int(2 * fr * 1024 + wr * 1024), "l2_hit": h,
-                   "avg_us_kernel_trace": durations.get(kn),
+                   "avg_us_kernel_trace": durations.get(kn), "per": "step" if PER_STEP else "launch",
                    "correction": "x2 applied to ALL fetches (upper bound: the 4-B index/value streams may not need it)",
                    "source": "profiles/%s_summary.txt" % tag}
             entries.append(ent)
@@ -118,7 +132,9 @@ def main():
                        "tools/profile_round.sh + tools/make_pmc_json.py). FETCH_SIZE is in KiB and doubled per the gfx950 wide-read "
                        "correction of MI355X_MICROARCH.md (upper bound); Infinity-Cache hits are counted too, so this is NOT an HBM "
                        "byte count for cache-resident tables. bench.py copies traffic_bytes into roofline.traffic and l2_hit into the "
-                       "kernels' ceilings; counters cannot be collected from inside bench.py.",
+                       "kernels' ceilings when no live pass ran; bench.py ALSO runs these passes itself (rocprofv3 --pmc child processes over "
+                       "tools/pmc_leg.py, roofline.traffic_measured_in_this_run) and then this file is only the labelled fallback. Entries "
+                       "with per = step (C4: the data-parallel step) are summed over the feature-interval launches of one step.",
            "entries": keep + entries + [step]}
     json.dump(doc, open(pj, "w"), indent=1)
     print(open(out_txt).read())
