@@ -197,6 +197,55 @@ def als_long(device, shapes=((100_000, 1_000, 10), (1_000_000, 1_000, 10), (1_00
     return out
 
 
+def als_fields(device, n_rows=1_000_000, users=6040, items=3706, k=8):
+    """ALS.learn on rows shaped like the reference's own demo (S/driver.scala:73-113: MovieLens — a user field and an item
+    field, one id each per row, ML-1M's vocabulary sizes): all columns of a field share no row, so the sweep's level
+    schedule (fmhip_dataset_als_levels) has TWO levels and every pass is two launches with thousands of columns side by
+    side.  One epoch on the GPU (fp64) beside the CPU oracle's (one core: the reference's sweep is a sequential recurrence),
+    the largest parameter difference between the two, and the GPU's own sequential walk for comparison."""
+    import oracle
+    from sparkfm_amd import DataSet, FMModel, HipALS
+    rng = np.random.default_rng(20261004)
+    # item popularity ~ 1 / (rank + 30): ML-1M's most rated film has ~3,400 of 1M ratings
+    pw = 1.0 / (np.arange(items) + 30.0)
+    col = np.stack([rng.integers(0, users, n_rows), users + rng.choice(items, n_rows, p=pw / pw.sum())], axis=1).reshape(-1).astype(np.int32)
+    val = np.ones(2 * n_rows, np.float64)
+    y = rng.integers(1, 6, n_rows).astype(np.float64)
+    row_ptr = np.arange(0, 2 * n_rows + 1, 2, dtype=np.int64)
+    ds = DataSet(row_ptr, col, val, y, name="fields", device=device).cache()
+    lv = ds.alsLevels()
+    out = {"workload": "%d rows x (%d user ids + %d item ids), one id per field and row, k=%d, one ALS epoch (fp64)" % (n_rows, users, items, k),
+           "levels": lv["levels"], "columns": lv["columns"], "widest_level": lv["widest_level"]}
+    res = {}
+    for name, env in (("level_schedule", None), ("sequential_walk", "0")):
+        if env is None:
+            os.environ.pop("FMHIP_ALS_LEVELS", None)
+        else:
+            os.environ["FMHIP_ALS_LEVELS"] = env
+        fm = FMModel(ds.dimension, k, seed=1, device=device)
+        w0, w, v = fm.w0, fm.w.copy(), fm.v.copy()
+        als = HipALS.run()
+        als.learn(fm, ds)                                   # warm-up (allocations); also the epoch that is compared
+        _ = fm.w0
+        res[name] = (fm.w0, fm.w.copy(), fm.v.copy())
+        t = time.perf_counter()
+        als.learn(fm, ds)
+        _ = fm.w0                                           # pulls the fp64 result: includes the sync
+        out["gpu_s_per_epoch_" + name] = time.perf_counter() - t
+        fm.close()
+    os.environ.pop("FMHIP_ALS_LEVELS", None)
+    t = time.perf_counter()
+    o = oracle.als_epoch(w0, w, v, 0.0, 0.0, 10.0, row_ptr, col, val, y)
+    out["cpu_oracle_s_per_epoch"] = time.perf_counter() - t
+    g = res["level_schedule"]
+    out["cpu_over_gpu"] = out["cpu_oracle_s_per_epoch"] / out["gpu_s_per_epoch_level_schedule"]
+    out["max_abs_parameter_difference_after_one_epoch"] = max(abs(g[0] - o[0]), float(np.abs(g[1] - o[1]).max()), float(np.abs(g[2] - o[2]).max()))
+    q = res["sequential_walk"]
+    out["max_abs_difference_level_schedule_vs_sequential_walk"] = max(abs(g[0] - q[0]), float(np.abs(g[1] - q[1]).max()), float(np.abs(g[2] - q[2]).max()))
+    ds.unpersist()
+    return out
+
+
 def committed_pmc(config, k, batch_rows):
     """Counter-derived figures of the committed rocprofv3 --pmc passes for this configuration
     (profiles/pmc_traffic.json): {kernel: {traffic_bytes, l2_hit}}; empty when no pass exists."""
@@ -1148,6 +1197,10 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
                 extra["als_long_columns"] = als_long(local_rank)
             except Exception as ex:   # noqa: BLE001
                 extra["als_long_columns"] = {"error": repr(ex)}
+            try:
+                extra["als_fields"] = als_fields(local_rank)
+            except Exception as ex:   # noqa: BLE001
+                extra["als_fields"] = {"error": repr(ex)}
             out["extra"] = extra
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dp:

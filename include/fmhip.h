@@ -248,6 +248,13 @@ int fmhip_batch_grad(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, double *
  * fmhip_model_get_params returns the fp64 result exactly; the fp32 device copy used by the scoring
  * calls is refreshed from it. */
 int fmhip_als_epoch(fmhip_model_t m, fmhip_dataset_t d, double reg0, double regw, double regv);
+/* The sweep's level schedule, made when a single-batch dataset is created: the reference walks the features in id order
+ * (S/fm/lib/ALS.scala:38,52) and every step sees the residuals the previous one left — but two columns WITHOUT A COMMON ROW
+ * touch disjoint residuals, so their steps commute exactly.  level(c) = 1 + the largest level of an earlier column sharing a
+ * row with c; fmhip_als_epoch takes the levels one launch each, all columns of a level side by side, whenever they hold 16
+ * columns or more on average (one-hot fields — the reference's MovieLens demo, S/driver.scala:73-113 — give one level per
+ * field) and leaves the same bits as the sequential walk.  n_levels = 0: no schedule (not a single-batch dataset). */
+int fmhip_dataset_als_levels(fmhip_dataset_t d, int64_t *n_levels, int64_t *n_columns, int64_t *widest_level);
 
 /* ---- data-parallel split step ---------------------------------------------------
  * packed fp32 gradient: [ scalars (32, 8 used) | G_w (n1p) | G_b (n1p) | pad to 32 | G_V (n1p*Kp) ],

@@ -32,7 +32,7 @@ SYMBOLS = (
     "fmhip_feature_counts", "fmhip_rank_from_counts", "fmhip_relabel_columns", "fmhip_dataset_hot_pages",
     "fmhip_comm_create_external", "fmhip_stream_wait", "fmhip_device_read", "fmhip_device_write",
     "fmhip_dp_exchange", "fmhip_dp_exchange_info", "fmhip_comm_emulate_ranks", "fmhip_model_tune", "fmhip_dataset_band_plan",
-    "fmhip_dp_step_at", "fmhip_dp_epoch_order", "fmhip_dp_plan_info",
+    "fmhip_dp_step_at", "fmhip_dp_epoch_order", "fmhip_dp_plan_info", "fmhip_dataset_als_levels",
 )
 UNIQUE_ID_BYTES = 128
 
@@ -156,6 +156,7 @@ def load():
     L.fmhip_dp_step_at.argtypes = [vp, vp, i64, vp, dbl, dbl, dbl, dbl]
     L.fmhip_dp_epoch_order.argtypes = [vp, vp, vp, dbl, dbl, dbl, dbl, vp, i64, P(Stats)]
     L.fmhip_dp_plan_info.argtypes = [vp, P(i64), P(i64)]
+    L.fmhip_dataset_als_levels.argtypes = [vp, P(i64), P(i64), P(i64)]
     L.fmhip_comm_emulate.argtypes = [vp, dbl]
     L.fmhip_comm_emulate_ranks.argtypes = [vp, C.c_int]
     L.fmhip_comm_profile_begin.argtypes = [vp]

@@ -31,6 +31,9 @@ struct AlsArgs {
     // workspace: e[n_rows]; q[n_rows * k] (every factor's q comes from an up-front pass over the feature-sorted rows);
     // part[2 * kAlsMaxParts + 2]: per-workgroup partial sums of a long column's chip-wide step
     double *e, *q, *part;
+    // level schedule (optional): the compressed columns sorted by (level, id) — columns of one level share no row and
+    // their steps commute exactly (fmhip_dataset::als_lev_cols)
+    const int32_t *lev_cols;
 };
 
 constexpr int kAlsMaxParts = 512;       // workgroups of a chip-wide column step
@@ -39,6 +42,9 @@ constexpr int kAlsMaxParts = 512;       // workgroups of a chip-wide column step
 constexpr int kAlsLongColumn = 8192;
 
 // h_cfeat / h_cptr: HOST copies of cfeat / cptr (the sweep's launch plan follows the column lengths)
-hipError_t launch_als_epoch(const AlsArgs &a, const int32_t *h_cfeat, const int32_t *h_cptr, hipStream_t s);
+// h_lev_ptr / n_levels: the level schedule's offsets into a.lev_cols (NULL / 0: none); h_lev_cols: host copy of a.lev_cols.  Taken when the levels hold at least
+// 16 columns on average (FMHIP_ALS_LEVELS=0 / 1 in the environment: never / always — a test and measurement knob).
+hipError_t launch_als_epoch(const AlsArgs &a, const int32_t *h_cfeat, const int32_t *h_cptr, const int32_t *h_lev_ptr,
+                            const int32_t *h_lev_cols, int n_levels, hipStream_t s);
 
 }  // namespace fmhip

@@ -224,6 +224,7 @@ __global__ __launch_bounds__(256) void k_als_q_all(AlsArgs a, double *qall) {
 
 // ---- LDS-resident sweep -------------------------------------------------------------------------------
 constexpr int kLdsSweepThreads = 1024;
+constexpr int kLevelBlock = 256;            // level sweep: four waves = four columns per workgroup
 constexpr size_t kAlsLdsBytes = 160000;     // e + q of at most 10,000 rows (the static reduction scratch fits beside it)
 
 template <int CTRL>
@@ -274,12 +275,12 @@ __device__ __forceinline__ ColHead load_head(const AlsArgs &a, int c0, int lane)
 // The first two wave-iterations of the column (<= 128 entries: every column of config 1) stay in registers
 // between the sums and the update — e and q are read from LDS once; `head` arrives prefetched and leaves holding
 // the next column's.
-template <bool FACTOR>
+template <bool FACTOR, bool NEXT = true>
 __device__ __forceinline__ double column_step(const AlsArgs &a, double *e, double *q, int c0, int c1, double theta, double reg,
                                               ColHead &head, int lane) {
 #pragma clang fp contract(off)
     const int n = c1 - c0;
-    const ColHead next = load_head(a, c1, lane);                    // in flight while this column is reduced
+    const ColHead next = NEXT ? load_head(a, c1, lane) : head;      // in flight while this column is reduced
     const bool v0 = lane < n, v1 = 64 + lane < n;
     const uint32_t ra = v0 ? head.r0 & 0x7fffffffu : 0u, rb = v1 ? head.r1 & 0x7fffffffu : 0u;
     const double xa = head.x0, xb = head.x1;
@@ -358,6 +359,30 @@ __device__ __forceinline__ void walk_columns(const AlsArgs &a, double *e, double
     }
 }
 
+// ---- level sweep ----------------------------------------------------------------------------------------
+// The columns of ONE level of the schedule side by side, a wave each: they share no row, so each step reads and writes
+// residuals / q entries no other step of the launch touches, and all the columns it depends on (smaller ids sharing a
+// row) sit in earlier levels = earlier launches.  The step itself is column_step — the operations and the summation order
+// of the one-wave LDS walk, on global memory — so a level-scheduled pass leaves the bits the sequential walk leaves.
+// One-hot fields (the reference's own MovieLens demo, S/driver.scala:73-113: a user field and an item field) are the
+// case this is for: all columns of a field form one level.
+template <bool FACTOR>
+__global__ __launch_bounds__(kLevelBlock) void k_als_level(AlsArgs a, double *q, const int32_t *cols, int n, int f, int long_col) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63;
+    const int j = (int)blockIdx.x * (kLevelBlock / 64) + (int)(threadIdx.x >> 6);
+    if (j >= n) return;
+    const int s = cols[j];
+    const int64_t i = a.cfeat[s];
+    if (i >= a.num_attribute) return;                              // `0 until num_attribute` (quirk Q1)
+    const int c0 = a.cptr[s], c1 = a.cptr[s + 1];
+    if (c1 - c0 >= long_col) return;                               // a long column of the level: the chip-wide step behind this launch
+    double *par = FACTOR ? a.v + f + i * a.k : a.w + i;
+    ColHead head = load_head(a, c0, lane);
+    const double tn = column_step<FACTOR, false>(a, a.e, q, c0, c1, *par, FACTOR ? a.regv : a.regw, head, lane);
+    if (lane == 0) *par = tn;                                      // :40 / :64
+}
+
 __global__ __launch_bounds__(kLdsSweepThreads) void k_als_sweep_lds(AlsArgs a, const double *qall) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) double lds_eq[];
@@ -382,6 +407,15 @@ __global__ __launch_bounds__(kLdsSweepThreads) void k_als_sweep_lds(AlsArgs a, c
 
 namespace {
 
+// one chip-wide closed-form step of a long column (two launches; see k_als_col_sums)
+template <bool FACTOR>
+void long_column_step(const AlsArgs &a, double *q, int c0, int c1, int64_t i, int f, hipStream_t s) {
+    int G = (c1 - c0 + 2047) / 2048;
+    if (G > kAlsMaxParts) G = kAlsMaxParts;
+    hipLaunchKernelGGL((k_als_col_sums<FACTOR>), dim3((unsigned)G), dim3(kColBlock), 0, s, a, q, c0, c1, i, f);
+    hipLaunchKernelGGL((k_als_col_update<FACTOR>), dim3((unsigned)G), dim3(kColBlock), 0, s, a, q, c0, c1, i, f);
+}
+
 template <bool FACTOR>
 hipError_t sweep_pass(const AlsArgs &a, const int32_t *h_cfeat, const int32_t *h_cptr, int f, int long_col, bool wide_wg, hipStream_t s) {
     double *q = a.q + (FACTOR ? (int64_t)f * a.n_rows : 0);
@@ -389,12 +423,7 @@ hipError_t sweep_pass(const AlsArgs &a, const int32_t *h_cfeat, const int32_t *h
     while (s0 < a.n_cols) {
         const int len = h_cptr[s0 + 1] - h_cptr[s0];
         if (len >= long_col) {
-            if (h_cfeat[s0] < a.num_attribute) {
-                int G = (len + 2047) / 2048;
-                if (G > kAlsMaxParts) G = kAlsMaxParts;
-                hipLaunchKernelGGL((k_als_col_sums<FACTOR>), dim3((unsigned)G), dim3(kColBlock), 0, s, a, q, h_cptr[s0], h_cptr[s0 + 1], (int64_t)h_cfeat[s0], f);
-                hipLaunchKernelGGL((k_als_col_update<FACTOR>), dim3((unsigned)G), dim3(kColBlock), 0, s, a, q, h_cptr[s0], h_cptr[s0 + 1], (int64_t)h_cfeat[s0], f);
-            }
+            if (h_cfeat[s0] < a.num_attribute) long_column_step<FACTOR>(a, q, h_cptr[s0], h_cptr[s0 + 1], (int64_t)h_cfeat[s0], f, s);
             ++s0;
             continue;
         }
@@ -409,7 +438,29 @@ hipError_t sweep_pass(const AlsArgs &a, const int32_t *h_cfeat, const int32_t *h
 
 }  // namespace
 
-hipError_t launch_als_epoch(const AlsArgs &a, const int32_t *h_cfeat, const int32_t *h_cptr, hipStream_t s) {
+namespace {
+template <bool FACTOR>
+hipError_t level_pass(const AlsArgs &a, const int32_t *h_cfeat, const int32_t *h_cptr, const int32_t *h_lev_ptr, const int32_t *h_lev_cols,
+                      int n_levels, int f, int long_col, hipStream_t s) {
+    double *q = a.q + (FACTOR ? (int64_t)f * a.n_rows : 0);
+    for (int l = 0; l < n_levels; ++l) {
+        const int n = h_lev_ptr[l + 1] - h_lev_ptr[l];
+        if (n < 1) continue;
+        hipLaunchKernelGGL((k_als_level<FACTOR>), dim3((unsigned)((n + kLevelBlock / 64 - 1) / (kLevelBlock / 64))), dim3(kLevelBlock), 0, s, a, q,
+                           a.lev_cols + h_lev_ptr[l], n, f, long_col);
+        // the level's long columns share no row with its other columns either: their chip-wide steps follow, in any order
+        for (int j = h_lev_ptr[l]; j < h_lev_ptr[l + 1]; ++j) {
+            const int c = h_lev_cols[j];
+            if (h_cptr[c + 1] - h_cptr[c] >= long_col && h_cfeat[c] < a.num_attribute)
+                long_column_step<FACTOR>(a, q, h_cptr[c], h_cptr[c + 1], (int64_t)h_cfeat[c], f, s);
+        }
+    }
+    return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_als_epoch(const AlsArgs &a, const int32_t *h_cfeat, const int32_t *h_cptr, const int32_t *h_lev_ptr,
+                            const int32_t *h_lev_cols, int n_levels, hipStream_t s) {
     int64_t blocks = (a.n_rows + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
@@ -426,6 +477,21 @@ hipError_t launch_als_epoch(const AlsArgs &a, const int32_t *h_cfeat, const int3
     if ((e = hipGetLastError()) != hipSuccess) return e;
     int long_col = kAlsLongColumn;
     if (const char *ev = getenv("FMHIP_ALS_LONG")) long_col = atoi(ev) > 0 ? atoi(ev) : long_col;
+    {
+        // level schedule: a launch per level and pass, every column of the level on a wave of its own — pays when the
+        // levels are wide (one-hot fields: two levels of thousands of columns); a dense conflict graph (config 1: every
+        // column shares rows with most others) has about as many levels as columns and keeps the sequential walks below.
+        // A level's columns long enough for the chip-wide step take it, behind the level's launch.
+        const bool have = h_lev_ptr && h_lev_cols && a.lev_cols && n_levels > 0;
+        bool levels = have && (int64_t)n_levels * 16 <= a.n_cols;
+        if (const char *ev = getenv("FMHIP_ALS_LEVELS")) levels = have && atoi(ev) != 0;
+        if (levels) {
+            if ((e = level_pass<false>(a, h_cfeat, h_cptr, h_lev_ptr, h_lev_cols, n_levels, 0, long_col, s)) != hipSuccess) return e;
+            for (int f = 0; f < a.k; ++f)
+                if ((e = level_pass<true>(a, h_cfeat, h_cptr, h_lev_ptr, h_lev_cols, n_levels, f, long_col, s)) != hipSuccess) return e;
+            return hipSuccess;
+        }
+    }
     if ((size_t)a.n_rows * 2 * sizeof(double) <= kAlsLdsBytes && !getenv("FMHIP_ALS_NO_LDS")) {
         // e and q fit the LDS of one CU: the one-wave column walk
         e = hipFuncSetAttribute((const void *)k_als_sweep_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAlsLdsBytes);

@@ -553,7 +553,10 @@ int fmhip_als_epoch(fmhip_model_t m, fmhip_dataset_t d, double reg0, double regw
         a.e = m->als_e.p;
         a.q = m->als_q.p;
         a.part = m->als_part.p;
-        HIP_TRY(launch_als_epoch(a, d->h_cfeat.data(), d->h_cptr.data(), m->stream));
+        a.lev_cols = d->als_lev_cols.p;
+        const int n_levels = d->als_lev_ptr.empty() ? 0 : (int)d->als_lev_ptr.size() - 1;
+        HIP_TRY(launch_als_epoch(a, d->h_cfeat.data(), d->h_cptr.data(), n_levels ? d->als_lev_ptr.data() : nullptr, d->h_als_lev_cols.data(), n_levels,
+                                 m->stream));
     }
     std::vector<double> w(n1), v(nv);
     double w0 = 0.0;

@@ -615,6 +615,37 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
                 return fail(FMHIP_ERR_HIP, "device transpose of batch %lld failed: %s", (long long)b, hipGetErrorString(he));
             }
             finish_batch_meta(hb, bm.cnnz, cnt, base);
+            if (keep64 && nb == 1 && d->rb_rows == 0 && nc > 0 && bm.cnnz > 0) {
+                // ALS level schedule (S/fm/lib/ALS.scala:36-70 walks the features in id order; two columns without a common
+                // row touch disjoint residuals and q entries, so their closed-form steps commute EXACTLY): one pass over the
+                // transpose in id order, level(c) = 1 + max over c's rows of the level of the last column that touched the row
+                std::vector<uint32_t> h_crow((size_t)bm.cnnz);
+                he = hipMemcpy(h_crow.data(), d->crow.p + bm.nnz0, h_crow.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
+                if (he != hipSuccess) {
+                    delete d;
+                    return fail(FMHIP_ERR_HIP, "reading the transpose back for the ALS level schedule: %s", hipGetErrorString(he));
+                }
+                std::vector<int32_t> row_level((size_t)bm.rows, 0), level((size_t)nc, 0);
+                int32_t n_levels = 0;
+                for (int32_t c = 0; c < (int32_t)hb.cfeat.size(); ++c) {
+                    int32_t lv = 0;
+                    for (int32_t p = hb.cptr[(size_t)c]; p < hb.cptr[(size_t)c + 1]; ++p) lv = std::max(lv, row_level[h_crow[(size_t)p] & 0x7fffffffu]);
+                    ++lv;
+                    level[(size_t)c] = lv;
+                    n_levels = std::max(n_levels, lv);
+                    for (int32_t p = hb.cptr[(size_t)c]; p < hb.cptr[(size_t)c + 1]; ++p) row_level[h_crow[(size_t)p] & 0x7fffffffu] = lv;
+                }
+                d->als_lev_ptr.assign((size_t)n_levels + 1, 0);
+                for (size_t c = 0; c < hb.cfeat.size(); ++c) ++d->als_lev_ptr[(size_t)level[c]];
+                for (int32_t l = 1; l <= n_levels; ++l) d->als_lev_ptr[(size_t)l] += d->als_lev_ptr[(size_t)l - 1];
+                std::vector<int32_t> cols(hb.cfeat.size()), at(d->als_lev_ptr.begin(), d->als_lev_ptr.end() - 1);
+                for (size_t c = 0; c < hb.cfeat.size(); ++c) cols[(size_t)at[(size_t)level[c] - 1]++] = (int32_t)c;   // ascending id inside a level
+                if ((rc = upload(d->als_lev_cols, cols.data(), cols.size()))) {
+                    delete d;
+                    return rc;
+                }
+                d->h_als_lev_cols.swap(cols);
+            }
             // band-affine placement of the ranges (large batches of feature-sorted transposes only)
             if (d->rb_rows == 0 && hb.range_seg.size() >= 1024) {
                 const int32_t nr = (int32_t)hb.range_seg.size();
@@ -884,6 +915,17 @@ int fmhip_dataset_band_plan(fmhip_dataset_t d, int64_t *n_ranges, int64_t *plann
     if (n_ranges) *n_ranges = all;
     if (planned_ranges) *planned_ranges = planned;
     if (band_affine_ranges) *band_affine_ranges = affine;
+    return FMHIP_OK;
+}
+
+int fmhip_dataset_als_levels(fmhip_dataset_t d, int64_t *n_levels, int64_t *n_columns, int64_t *widest_level) {
+    if (!d) return fail(FMHIP_ERR_INVALID, "dataset is NULL");
+    const int64_t nl = d->als_lev_ptr.empty() ? 0 : (int64_t)d->als_lev_ptr.size() - 1;
+    int64_t widest = 0;
+    for (int64_t l = 0; l < nl; ++l) widest = std::max<int64_t>(widest, d->als_lev_ptr[(size_t)l + 1] - d->als_lev_ptr[(size_t)l]);
+    if (n_levels) *n_levels = nl;
+    if (n_columns) *n_columns = nl ? d->als_lev_ptr.back() : 0;
+    if (widest_level) *widest_level = widest;
     return FMHIP_OK;
 }
 

@@ -164,6 +164,11 @@ struct fmhip_dataset {
     DevBuf<int32_t> scol;
     DevBuf<double> sval64;
     bool als_dup = false;
+    // level schedule of the ALS sweep (single-batch datasets): columns that share no row commute exactly, so the sweep may
+    // take them side by side — level(c) = 1 + the largest level of an earlier column (smaller id) sharing a row with c.
+    // als_lev_cols: the compressed columns sorted by (level, id); als_lev_ptr[l] .. [l + 1]: level l's slice of it
+    DevBuf<int32_t> als_lev_cols;
+    std::vector<int32_t> als_lev_ptr, h_als_lev_cols;
 };
 
 struct fmhip_model {

@@ -173,6 +173,12 @@ class DataSet(Features):
                     hot_ids_all=all_ids[:n_all.value].tolist(), nnz_sparse_backward=int(spb.value),
                     ranges=int(nr.value), planned_ranges=int(planned.value), band_affine_ranges=int(affine.value))
 
+    def alsLevels(self):
+        """The ALS sweep's level schedule (fmhip_dataset_als_levels): levels, columns, the widest level's columns."""
+        v = [C.c_int64() for _ in range(3)]
+        _ffi.check(_ffi.load().fmhip_dataset_als_levels(self.handle, *[C.byref(x) for x in v]))
+        return dict(zip(("levels", "columns", "widest_level"), (int(x.value) for x in v)))
+
     def transposeInput(self, batch=0):
         """transposeInput (S/DataSet.scala:48, :31-38) of one mini-batch, read back from the GPU:
         (feat, ptr, rows, vals) — ascending present feature ids, offsets, batch-local row ids, values."""

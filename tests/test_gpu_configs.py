@@ -614,6 +614,74 @@ def test_als_long_columns_on_the_whole_chip(fmhip, monkeypatch, n_rows, n1, k, l
     fm.close()
 
 
+def _one_hot_fields(seed, n_rows, sizes, extra=0):
+    """Rows with one id per field (fields = consecutive id ranges of the given sizes), like the reference's MovieLens
+    demo (S/driver.scala:73-113: a user field and an item field); `extra`: that many more random ids from a last, shared range."""
+    rng = np.random.default_rng(seed)
+    cols, off = [], 0
+    for sz in sizes:
+        cols.append(off + rng.integers(0, sz, n_rows))
+        off += sz
+    col = np.stack(cols, axis=1)
+    if extra:
+        col = np.concatenate([col, off + np.stack([rng.permutation(40)[:extra] for _ in range(n_rows)])], axis=1)
+        off += 40
+    nnz_r = col.shape[1]
+    val = np.where(rng.random(col.shape) < 0.5, 1.0, rng.uniform(0.2, 1.0, col.shape))
+    y = rng.normal(3.5, 1.0, n_rows)
+    return dict(row_ptr=np.arange(0, (n_rows + 1) * nnz_r, nnz_r, dtype=np.int64), col=col.reshape(-1).astype(np.int32), val=val.reshape(-1).astype(np.float64),
+                y=y, n1=off)
+
+
+@pytest.mark.parametrize("n_rows,sizes,extra,k", [(9000, (300, 200), 0, 4), (9000, (120, 80, 50), 0, 3), (60000, (2000, 1500), 0, 4), (30000, (500, 400), 2, 2)])
+def test_als_level_schedule_is_the_sequential_sweep(fmhip, monkeypatch, n_rows, sizes, extra, k):
+    """ALS.learn's sweep (S/fm/lib/ALS.scala:36-70) level by level: columns that share no row commute exactly, so the columns
+    of a level run side by side and the result must be THE sequential sweep's — bit for bit against the one-wave LDS walk
+    (<= 10,000 rows: the same column step, the same summation order), to fp64 rounding against the workgroup walk of larger
+    datasets (another summation order inside a column), and 1e-8 against the oracle.  One-hot fields give one level per
+    field; a last range of shared ids (extra) adds levels of a few columns behind them."""
+    d = _one_hot_fields(7, n_rows, sizes, extra)
+    n1 = d["n1"]
+    ds = fmhip.DataSet(d["row_ptr"], d["col"], d["val"], d["y"]).cache()
+    lv = ds.alsLevels()
+    assert lv["columns"] == ds.batch_info(0)["n_columns"] and lv["levels"] >= len(sizes)
+    if not extra:
+        assert lv["levels"] == len(sizes) and lv["widest_level"] <= max(sizes)       # one level per field
+    rng = np.random.default_rng(3)
+    w0, w, v = 0.3, rng.normal(0, 0.1, n1), rng.normal(0, 0.1, (k, n1))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FMHIP_ALS_LEVELS", mode)
+        fm = fmhip.FMModel(n1 - 1, k)
+        fm.w0, fm.w, fm.v = w0, w, v
+        als = fmhip.HipALS.run()
+        for _ in range(2):
+            als.learn(fm, ds)
+        out[mode] = (fm.w0, fm.w.copy(), fm.v.copy())
+        fm.close()
+    monkeypatch.delenv("FMHIP_ALS_LEVELS")
+    if n_rows <= 10000:
+        assert out["1"][0] == out["0"][0]
+        np.testing.assert_array_equal(out["1"][1], out["0"][1])
+        np.testing.assert_array_equal(out["1"][2], out["0"][2])
+    else:
+        assert abs(out["1"][0] - out["0"][0]) <= 1e-12 and np.abs(out["1"][1] - out["0"][1]).max() <= 1e-11 and np.abs(out["1"][2] - out["0"][2]).max() <= 1e-11
+    o0, ow, ov = w0, w, v
+    for _ in range(2):
+        o0, ow, ov = oracle.als_epoch(o0, ow, ov, 0.0, 0.0, 10.0, d["row_ptr"], d["col"], d["val"], d["y"])
+    assert abs(out["1"][0] - o0) <= 1e-8 and np.abs(out["1"][1] - ow).max() <= 1e-8 and np.abs(out["1"][2] - ov).max() <= 1e-8
+    # the default choice: wide levels -> the level sweep (the same bits as forcing it)
+    fm = fmhip.FMModel(n1 - 1, k)
+    fm.w0, fm.w, fm.v = w0, w, v
+    als = fmhip.HipALS.run()
+    for _ in range(2):
+        als.learn(fm, ds)
+    if lv["levels"] * 16 <= lv["columns"]:
+        np.testing.assert_array_equal(fm.v, out["1"][2])
+    fm.close()
+    ds.unpersist()
+
+
 def test_als_refuses_rows_with_a_repeated_feature(fmhip):
     from sparkfm_amd import _ffi
     ds = fmhip.DataSet.from_rows([(1.0, ([0, 2, 2], [1.0, 2.0, 0.5])), (0.0, ([1], [1.0]))]).cache()
