@@ -483,7 +483,7 @@ def hbm_resident_leg(device, steps=48, rows=6_000_000, batch_rows=250_000, hashe
         return res
 
     t0 = time.time()
-    col_rel = FeatureOrder.fit(col_hashed, n1).relabel(col_hashed)      # a pure renaming (sparkfm_amd.FeatureOrder), outside any timed region
+    col_rel = FeatureOrder.fit(col_hashed, n1, device=device).relabel(col_hashed)      # a pure renaming (sparkfm_amd.FeatureOrder, on the GPU), outside any timed region
     t_rel = time.time() - t0
     r = run(col_rel, steps, "relabelled")
     lay, bi, prof = r["lay"], r["bi"], r["prof"]
@@ -795,7 +795,8 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
         # hashed slots come in no particular order: relabel by frequency at load (a pure renaming of the features;
         # the counts are summed over the ranks so that every replica uses the same numbering)
         from sparkfm_amd import FeatureOrder
-        d["col"] = FeatureOrder.from_counts(ctl.sum_counts(FeatureOrder.counts(d["col"], cfg["features"]))).relabel(d["col"])
+        d["col"] = FeatureOrder.from_counts(ctl.sum_counts(FeatureOrder.counts(d["col"], cfg["features"], device=local_rank)),
+                                            device=local_rank).relabel(d["col"])
     t_gen = time.time() - t0
     t0 = time.time()
     ds = DataSet.from_arrays(d, name=config, batch_rows=batch_rows, device=local_rank).cache()

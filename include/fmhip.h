@@ -433,6 +433,13 @@ int fmhip_shard_rows(int64_t n_rows, const int64_t *row_ptr, int world, int rank
 int fmhip_feature_counts(int64_t nnz, const int32_t *col, int64_t n1, int64_t *counts);
 int fmhip_rank_from_counts(int64_t n1, const int64_t *counts, int32_t *rank, int32_t *by_rank);
 int fmhip_relabel_columns(int64_t nnz, const int32_t *col, int64_t n1, const int32_t *rank, int32_t *out);
+/* The same three steps ON THE GPU `device` (a histogram by atomic adds, a stable descending radix sort of (count, id), a gather;
+ * the ids travel in chunks of 2^26): same arguments, same results BIT FOR BIT — the same order for the same counts, ties by
+ * ascending id — for hosts whose cores are the slow part (2^25 slots x 210 M ids: 9.7 s of host arithmetic, under half a
+ * second here).  The host versions above stay the reference and need no GPU. */
+int fmhip_feature_counts_gpu(int device, int64_t nnz, const int32_t *col, int64_t n1, int64_t *counts);
+int fmhip_rank_from_counts_gpu(int device, int64_t n1, const int64_t *counts, int32_t *rank, int32_t *by_rank);
+int fmhip_relabel_columns_gpu(int device, int64_t nnz, const int32_t *col, int64_t n1, const int32_t *rank, int32_t *out);
 
 /* ---- measurement ------------------------------------------------------------------ */
 /* How the library laid a dataset out (for byte accounting; not needed to use it): the number of

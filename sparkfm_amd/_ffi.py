@@ -33,6 +33,7 @@ SYMBOLS = (
     "fmhip_comm_create_external", "fmhip_stream_wait", "fmhip_device_read", "fmhip_device_write",
     "fmhip_dp_exchange", "fmhip_dp_exchange_info", "fmhip_comm_emulate_ranks", "fmhip_model_tune", "fmhip_dataset_band_plan",
     "fmhip_dp_step_at", "fmhip_dp_epoch_order", "fmhip_dp_plan_info", "fmhip_dataset_als_levels",
+    "fmhip_feature_counts_gpu", "fmhip_rank_from_counts_gpu", "fmhip_relabel_columns_gpu",
 )
 UNIQUE_ID_BYTES = 128
 
@@ -173,6 +174,9 @@ def load():
     L.fmhip_feature_counts.argtypes = [i64, vp, i64, vp]
     L.fmhip_rank_from_counts.argtypes = [i64, vp, vp, vp]
     L.fmhip_relabel_columns.argtypes = [i64, vp, i64, vp, vp]
+    L.fmhip_feature_counts_gpu.argtypes = [C.c_int, i64, vp, i64, vp]
+    L.fmhip_rank_from_counts_gpu.argtypes = [C.c_int, i64, vp, vp, vp]
+    L.fmhip_relabel_columns_gpu.argtypes = [C.c_int, i64, vp, i64, vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("fmhip_version", "fmhip_last_error"):

@@ -5,6 +5,8 @@
 #include "fmhip_internal.h"
 #include "csc_build.h"
 
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -985,6 +987,118 @@ int fmhip_relabel_columns(int64_t nnz, const int32_t *col, int64_t n1, const int
         }
     });
     if (bad.load() >= 0) return fail(FMHIP_ERR_INVALID, "col[%lld] outside [0, %lld): nothing can be relied on in `out`", (long long)bad.load(), (long long)n1);
+    return FMHIP_OK;
+}
+
+}  // extern "C"
+
+// ---- the same three steps on the GPU (the *_gpu entry points): a histogram by atomic adds, a stable descending radix sort
+// of (count, id) pairs, a gather — host arithmetic that took 9.7 s for 6M Criteo-shaped rows over 2^25 slots
+namespace {
+__global__ __launch_bounds__(256) void k_count_ids(const int32_t *col, int64_t n, int64_t n1, unsigned long long *counts, unsigned long long *bad) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t c = col[i];
+        if (c < 0 || c >= n1) atomicMin(bad, (unsigned long long)i);
+        else atomicAdd(counts + c, 1ull);
+    }
+}
+__global__ __launch_bounds__(256) void k_iota(int32_t *ids, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) ids[i] = (int32_t)i;
+}
+__global__ __launch_bounds__(256) void k_invert(const int32_t *by_rank, int64_t n, int32_t *rank) {
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) rank[by_rank[r]] = (int32_t)r;
+}
+__global__ __launch_bounds__(256) void k_relabel(const int32_t *col, int64_t n, int64_t n1, const int32_t *rank, int32_t *out, unsigned long long *bad) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t c = col[i];
+        if (c < 0 || c >= n1) atomicMin(bad, (unsigned long long)i);
+        else out[i] = rank[c];
+    }
+}
+constexpr int64_t kRelabelChunk = (int64_t)1 << 26;      // entries per transfer: 256 MB of ids on the card at a time
+inline unsigned grid_for(int64_t n) { return (unsigned)std::min<int64_t>(std::max<int64_t>((n + 255) / 256, 1), 16384); }
+}  // namespace
+
+extern "C" {
+
+int fmhip_feature_counts_gpu(int device, int64_t nnz, const int32_t *col, int64_t n1, int64_t *counts) {
+    if (nnz < 0 || n1 < 1 || n1 > INT32_MAX || !counts || (nnz > 0 && !col)) return fail(FMHIP_ERR_INVALID, "bad arguments");
+    TRY(set_device(device));
+    DevBuf<unsigned long long> d_cnt, d_bad;
+    DevBuf<int32_t> d_col;
+    TRY(d_cnt.alloc((size_t)n1));
+    TRY(d_bad.alloc(1));
+    TRY(d_col.alloc((size_t)std::max<int64_t>(std::min(nnz, kRelabelChunk), 1)));
+    HIP_TRY(hipMemset(d_cnt.p, 0, (size_t)n1 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(d_bad.p, 0xff, sizeof(unsigned long long)));
+    for (int64_t at = 0; at < nnz; at += kRelabelChunk) {
+        const int64_t n = std::min(kRelabelChunk, nnz - at);
+        HIP_TRY(hipMemcpy(d_col.p, col + at, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_count_ids, dim3(grid_for(n)), dim3(256), 0, nullptr, d_col.p, n, n1, d_cnt.p, d_bad.p);
+        HIP_TRY(hipGetLastError());
+        unsigned long long bad = 0;
+        HIP_TRY(hipMemcpy(&bad, d_bad.p, sizeof bad, hipMemcpyDeviceToHost));
+        if (bad != ~0ull) return fail(FMHIP_ERR_INVALID, "col[%lld] = %d outside [0, %lld)", (long long)(at + (int64_t)bad), col[at + (int64_t)bad], (long long)n1);
+    }
+    std::vector<unsigned long long> h((size_t)n1);
+    HIP_TRY(hipMemcpy(h.data(), d_cnt.p, (size_t)n1 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    parallel_chunks(n1, host_threads(n1), [&](int, int64_t lo, int64_t hi) {
+        for (int64_t f = lo; f < hi; ++f) counts[f] += (int64_t)h[(size_t)f];
+    });
+    return FMHIP_OK;
+}
+
+int fmhip_rank_from_counts_gpu(int device, int64_t n1, const int64_t *counts, int32_t *rank, int32_t *by_rank) {
+    if (n1 < 1 || n1 > INT32_MAX || !counts || !rank) return fail(FMHIP_ERR_INVALID, "bad arguments");
+    for (int64_t f = 0; f < n1; ++f)
+        if (counts[f] < 0) return fail(FMHIP_ERR_INVALID, "counts[%lld] is negative", (long long)f);
+    TRY(set_device(device));
+    DevBuf<unsigned long long> k_in, k_out;
+    DevBuf<int32_t> v_in, v_out, d_rank;
+    DevBuf<uint8_t> tmp;
+    TRY(k_in.alloc((size_t)n1));
+    TRY(k_out.alloc((size_t)n1));
+    TRY(v_in.alloc((size_t)n1));
+    TRY(v_out.alloc((size_t)n1));
+    TRY(d_rank.alloc((size_t)n1));
+    size_t tb = 0;
+    // descending count; the sort is stable and the ids go in ascending, so ties keep ascending id — the host version's order
+    HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, tb, k_in.p, k_out.p, v_in.p, v_out.p, (size_t)n1, 0, 64, (hipStream_t) nullptr));
+    TRY(tmp.alloc(tb + 16));
+    HIP_TRY(hipMemcpy(k_in.p, counts, (size_t)n1 * sizeof(int64_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(n1)), dim3(256), 0, nullptr, v_in.p, n1);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(rocprim::radix_sort_pairs_desc(tmp.p, tb, k_in.p, k_out.p, v_in.p, v_out.p, (size_t)n1, 0, 64, (hipStream_t) nullptr));
+    hipLaunchKernelGGL(k_invert, dim3(grid_for(n1)), dim3(256), 0, nullptr, v_out.p, n1, d_rank.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(rank, d_rank.p, (size_t)n1 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (by_rank) HIP_TRY(hipMemcpy(by_rank, v_out.p, (size_t)n1 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return FMHIP_OK;
+}
+
+int fmhip_relabel_columns_gpu(int device, int64_t nnz, const int32_t *col, int64_t n1, const int32_t *rank, int32_t *out) {
+    if (nnz < 0 || n1 < 1 || !rank || (nnz > 0 && (!col || !out))) return fail(FMHIP_ERR_INVALID, "bad arguments");
+    TRY(set_device(device));
+    DevBuf<int32_t> d_rank, d_col, d_out;
+    DevBuf<unsigned long long> d_bad;
+    const int64_t chunk = std::max<int64_t>(std::min(nnz, kRelabelChunk), 1);
+    TRY(d_rank.alloc((size_t)n1));
+    TRY(d_col.alloc((size_t)chunk));
+    TRY(d_out.alloc((size_t)chunk));
+    TRY(d_bad.alloc(1));
+    HIP_TRY(hipMemcpy(d_rank.p, rank, (size_t)n1 * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_bad.p, 0xff, sizeof(unsigned long long)));
+    for (int64_t at = 0; at < nnz; at += kRelabelChunk) {
+        const int64_t n = std::min(kRelabelChunk, nnz - at);
+        HIP_TRY(hipMemcpy(d_col.p, col + at, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_relabel, dim3(grid_for(n)), dim3(256), 0, nullptr, d_col.p, n, n1, d_rank.p, d_out.p, d_bad.p);
+        HIP_TRY(hipGetLastError());
+        unsigned long long bad = 0;
+        HIP_TRY(hipMemcpy(&bad, d_bad.p, sizeof bad, hipMemcpyDeviceToHost));
+        if (bad != ~0ull)
+            return fail(FMHIP_ERR_INVALID, "col[%lld] outside [0, %lld): nothing can be relied on in `out`", (long long)(at + (int64_t)bad), (long long)n1);
+        HIP_TRY(hipMemcpy(out + at, d_out.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
     return FMHIP_OK;
 }
 

@@ -20,9 +20,13 @@ from . import _ffi
 
 
 class FeatureOrder:
-    def __init__(self, rank, by_rank):
+    """`device` (everywhere below): None = the library's host arithmetic; a GPU index = the same three steps on that GPU
+    (fmhip_*_gpu: same results bit for bit, for hosts whose cores are the slow part)."""
+
+    def __init__(self, rank, by_rank, device=None):
         self.rank = np.ascontiguousarray(rank, np.int32)          # caller's id -> internal id
         self.by_rank = np.ascontiguousarray(by_rank, np.int32)    # internal id -> caller's id
+        self.device = device
         if self.rank.shape != self.by_rank.shape or self.rank.ndim != 1:
             raise ValueError("rank and by_rank must be 1-d and equally long")
 
@@ -31,28 +35,36 @@ class FeatureOrder:
         return len(self.rank)
 
     @staticmethod
-    def counts(col, n1, into=None):
+    def counts(col, n1, into=None, device=None):
         """Stored nonzeros per feature id (int64[n1]); `into` accumulates over partitions."""
         col = np.ascontiguousarray(col, np.int32)
         out = np.zeros(n1, np.int64) if into is None else into
         if out.dtype != np.int64 or out.shape != (n1,) or not out.flags.c_contiguous:
             raise ValueError("`into` must be a contiguous int64[n1]")
-        _ffi.check(_ffi.load().fmhip_feature_counts(len(col), _ffi.ptr(col), n1, _ffi.ptr(out)))
+        L = _ffi.load()
+        if device is None:
+            _ffi.check(L.fmhip_feature_counts(len(col), _ffi.ptr(col), n1, _ffi.ptr(out)))
+        else:
+            _ffi.check(L.fmhip_feature_counts_gpu(device, len(col), _ffi.ptr(col), n1, _ffi.ptr(out)))
         return out
 
     @classmethod
-    def from_counts(cls, counts):
+    def from_counts(cls, counts, device=None):
         counts = np.ascontiguousarray(counts, np.int64)
         rank = np.empty(len(counts), np.int32)
         by_rank = np.empty(len(counts), np.int32)
-        _ffi.check(_ffi.load().fmhip_rank_from_counts(len(counts), _ffi.ptr(counts), _ffi.ptr(rank), _ffi.ptr(by_rank)))
-        return cls(rank, by_rank)
+        L = _ffi.load()
+        if device is None:
+            _ffi.check(L.fmhip_rank_from_counts(len(counts), _ffi.ptr(counts), _ffi.ptr(rank), _ffi.ptr(by_rank)))
+        else:
+            _ffi.check(L.fmhip_rank_from_counts_gpu(device, len(counts), _ffi.ptr(counts), _ffi.ptr(rank), _ffi.ptr(by_rank)))
+        return cls(rank, by_rank, device)
 
     @classmethod
-    def fit(cls, col, n1, group=None, distributed=False):
+    def fit(cls, col, n1, group=None, distributed=False, device=None):
         """Order of the ids in `col`; `distributed` (or a `group`): counts are summed over the ranks of
         torch.distributed first, so that all of them derive the same order."""
-        cnt = cls.counts(col, n1)
+        cnt = cls.counts(col, n1, device=device)
         if distributed or group is not None:
             import torch
             import torch.distributed as dist
@@ -61,7 +73,7 @@ class FeatureOrder:
                 t = t.cuda()
             dist.all_reduce(t, group=group)
             cnt = t.cpu().numpy()
-        return cls.from_counts(cnt)
+        return cls.from_counts(cnt, device)
 
     @classmethod
     def identity(cls, n1):
@@ -72,7 +84,10 @@ class FeatureOrder:
         """rank[col] as int32 (ids outside [0, n1) raise)."""
         col = np.ascontiguousarray(col, np.int32)
         out = np.empty_like(col) if out is None else out
-        _ffi.check(_ffi.load().fmhip_relabel_columns(len(col), _ffi.ptr(col), self.n1, _ffi.ptr(self.rank), _ffi.ptr(out)))
+        if self.device is None:
+            _ffi.check(_ffi.load().fmhip_relabel_columns(len(col), _ffi.ptr(col), self.n1, _ffi.ptr(self.rank), _ffi.ptr(out)))
+        else:
+            _ffi.check(_ffi.load().fmhip_relabel_columns_gpu(self.device, len(col), _ffi.ptr(col), self.n1, _ffi.ptr(self.rank), _ffi.ptr(out)))
         return out
 
     # -- parameters between the two numberings (w: [n1], v: [k, n1] as FMModel holds them) --------

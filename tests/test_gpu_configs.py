@@ -864,3 +864,28 @@ def test_training_on_relabelled_ids_is_the_same_model(fmhip, regs):
     assert fm.computeRMSE(ds) == pytest.approx(oracle.rmse(ow0, ow, ov, a["row_ptr"], col, a["val"], a["y"]), rel=1e-4)
     ds.unpersist()
     fm.close()
+
+
+def test_relabelling_on_the_gpu_is_the_host_numbering_bit_for_bit(fmhip):
+    """fmhip_feature_counts_gpu / fmhip_rank_from_counts_gpu / fmhip_relabel_columns_gpu against the host arithmetic they
+    replace: the same counts, the same order (descending count, ties by ascending id — many ties here, and ids that never
+    occur), the same relabelled stream; counts accumulate over partitions; an id outside [0, n1) is refused with its position."""
+    from sparkfm_amd import FeatureOrder, _ffi
+    rng = np.random.default_rng(17)
+    n1 = 300_007
+    col = np.minimum((rng.pareto(0.9, 5_000_000) * 40).astype(np.int64), n1 - 1).astype(np.int32)     # heavy head, long tail of ties
+    a, b = col[:2_000_000], col[2_000_000:]
+    ch = FeatureOrder.counts(b, n1, into=FeatureOrder.counts(a, n1))
+    cg = FeatureOrder.counts(b, n1, into=FeatureOrder.counts(a, n1, device=0), device=0)
+    np.testing.assert_array_equal(ch, cg)
+    assert (ch == 0).sum() > 1000 and np.bincount(ch[ch > 0]).max() > 1000            # absent ids and plenty of ties
+    oh, og = FeatureOrder.from_counts(ch), FeatureOrder.from_counts(cg, device=0)
+    np.testing.assert_array_equal(oh.rank, og.rank)
+    np.testing.assert_array_equal(oh.by_rank, og.by_rank)
+    np.testing.assert_array_equal(oh.relabel(col), og.relabel(col))
+    bad = col.copy()
+    bad[1234567] = n1
+    with pytest.raises(_ffi.FmhipError, match="1234567"):
+        og.relabel(bad)
+    with pytest.raises(_ffi.FmhipError, match="1234567"):
+        FeatureOrder.counts(bad, n1, device=0)
