@@ -39,7 +39,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md); measured streaming copy ~6.3e12
 # Ceilings for gathers of whole 128-B-multiple rows by where the table lives (MI355X_MICROARCH.md,
 # "Indexed rows"): the XCD's own L2, the Infinity Cache, HBM (measured sweep / spec peak)
-CEIL = {"l2_gather": 16.8e12, "mall_gather": 8.6e12, "hbm_gather": 6.0e12, "hbm_stream": 6.3e12}
+# (the UPPER end of the guide's measured ranges — 16.8-18.8 TB/s from L2 — so that a "ceiling" is one: a kernel that also
+# hits in its CU's L1, which these rates do not price, must not pass it)
+CEIL = {"l2_gather": 18.8e12, "mall_gather": 8.6e12, "hbm_gather": 6.1e12, "hbm_stream": 6.3e12}
 L2_BYTES_PER_XCD = 4 << 20
 MALL_BYTES = 256 << 20
 
@@ -349,6 +351,16 @@ def live_pmc(child_argv, per_step=None):
                    "traffic_bytes": int(2 * fr * 1024 + wr * 1024)}
     if out:
         out["step"] = {"traffic_bytes": sum(e["traffic_bytes"] for e in out.values())}
+        # the hit rates of THIS run (one more pass: the L2's hits / misses and the L1s' accesses / requests passed on to L2 fit
+        # one counter set): what the gather ceilings are blended with, instead of the committed profile's figure
+        hits = None if PMC_STATE["dead"] else pmc_pass(["TCC_HIT_sum", "TCC_MISS_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum"],
+                                                       child_argv, per_step=per_step)
+        for kn, c in (hits or {}).items():
+            if kn in out and c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum") is not None:
+                out[kn]["l2_hit"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0)
+                out[kn]["l2_hit_measured_in_this_run"] = True
+                if c.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+                    out[kn]["l1_hit_share_of_accesses"] = 1.0 - c.get("TCP_TCC_READ_REQ_sum", 0.0) / c["TCP_TOTAL_CACHE_ACCESSES_sum"]
     return out or None
 
 
@@ -412,11 +424,18 @@ def kernel_table(prof, k, kp, req, pmc, table_bytes, launches_per_step=None):
                 hit = pmc.get("k_" + name, {}).get("l2_hit")
                 cname, c, h = gather_ceiling(table_bytes[name], hit)
                 ent["ceiling"] = {"name": cname, "GBps": c / 1e9, "table_bytes": table_bytes[name],
-                                  "l2_hit": h, "l2_hit_source": ("profiles/pmc_traffic.json" if hit is not None else
+                                  "l2_hit": h, "l2_hit_source": (("rocprofv3 --pmc TCC_HIT / TCC_MISS pass of this run" if pmc.get("k_" + name, {}).get("l2_hit_measured_in_this_run")
+                                                                  else "profiles/pmc_traffic.json") if hit is not None else
                                                                  ("uniform-gather model" if h is not None else None))}
+                l1 = pmc.get("k_" + name, {}).get("l1_hit_share_of_accesses")
+                if l1 is not None:
+                    ent["ceiling"]["l1_hit_share_of_accesses"] = l1      # served by the CU's own L1: not priced by the ceiling (it only adds headroom)
             else:
                 ent["ceiling"] = {"name": "hbm_stream", "GBps": CEIL["hbm_stream"] / 1e9}
             ent["frac_of_ceiling"] = ent["requested_GBps"] / ent["ceiling"]["GBps"]
+            if ent["frac_of_ceiling"] > 1.0:
+                ent["ceiling_exceeded"] = ("the kernel asked for bytes faster than the L2 / Infinity-Cache gather rates allow: the excess was "
+                                           "served by the CUs' L1s, which the ceiling does not price")
         pe = pmc.get("k_" + name, {})
         if pe.get("traffic_bytes") is not None:
             ent["traffic_bytes"] = pe["traffic_bytes"]           # fabric-side: FETCH_SIZE x2 + WRITE_SIZE per launch

@@ -97,6 +97,10 @@ typedef struct fmhip_profile {
 
 /* ---- library ----------------------------------------------------------------- */
 int fmhip_version(void);
+/* 0 in a library anyone may train with.  Non-zero: this build carries a timing-only ablation of a kernel (a part of the
+ * arithmetic or of the memory traffic compiled out to measure what it costs, FMHIP_EXP_* in the kernel sources): its results
+ * are wrong by construction and it exists only as an A/B variant beside the real library (tools/build_variant.sh). */
+int fmhip_ablation_mask(void);
 const char *fmhip_last_error(void);
 int fmhip_device_count(int *count);
 /* tuning knobs — fmhip_tune sets the PROCESS-WIDE DEFAULT of a key, fmhip_model_tune overrides it for one model (value < 0:

@@ -15,7 +15,7 @@ RANGE_LEN = 64
 
 # every symbol include/fmhip.h declares (tests check the library exports all of them)
 SYMBOLS = (
-    "fmhip_version", "fmhip_last_error", "fmhip_device_count", "fmhip_tune",
+    "fmhip_ablation_mask", "fmhip_version", "fmhip_last_error", "fmhip_device_count", "fmhip_tune",
     "fmhip_model_create", "fmhip_model_destroy", "fmhip_model_info",
     "fmhip_model_set_params", "fmhip_model_get_params", "fmhip_model_set_params_f32", "fmhip_model_get_params_f32",
     "fmhip_synchronize",
@@ -185,6 +185,8 @@ def load():
     for item in filter(None, os.environ.get("FMHIP_TUNE", "").split(",")):
         k, v = item.split("=")
         L.fmhip_tune(int(k), int(v))
+    if L.fmhip_ablation_mask() != 0 and not os.environ.get("FMHIP_LIB"):
+        raise ImportError("libfmhip.so was built with a timing-only kernel ablation (mask %d): rebuild it without FMHIP_EXP_* flags" % L.fmhip_ablation_mask())
     _lib = L
     return L
 

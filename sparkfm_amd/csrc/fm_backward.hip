@@ -508,6 +508,10 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
 #ifndef FMHIP_EXP_NO_XE_BCAST
 #define FMHIP_EXP_NO_XE_BCAST 0   // timing-only ablation: the value / residual broadcasts of the pipelined walk dropped (results wrong)
 #endif
+#define FMHIP_BWD_ABLATIONS ((FMHIP_EXP_FIX_SKIP ? 64 : 0) | (FMHIP_EXP_NO_XE_BCAST ? 128 : 0))
+#if FMHIP_BWD_ABLATIONS && !defined(FMHIP_ABLATION_BUILD)
+#error "a result-changing FMHIP_EXP_* ablation is set without FMHIP_ABLATION_BUILD: timing-only variants are built by tools/build_variant.sh"
+#endif
 #ifndef FMHIP_BWD_WAVES
 #define FMHIP_BWD_WAVES 3
 #endif
@@ -878,6 +882,8 @@ hipError_t launch_fixup2(int Kp, const BwdArgs &a, hipStream_t s) {
     FMHIP_KP_SWITCH(Kp, CALL)
 #undef CALL
 }
+
+int backward_ablations() { return FMHIP_BWD_ABLATIONS; }
 
 int hot_blocks(int Kp, int64_t n_rows) {
     (void)Kp;

@@ -31,6 +31,18 @@
 #ifndef FMHIP_EXP_NO_HOT
 #define FMHIP_EXP_NO_HOT 0
 #endif
+// ... none of which may reach a library anyone trains with: a build that sets one must say so (FMHIP_ABLATION_BUILD, which
+// tools/build_variant.sh passes for A/B variants), and fmhip_ablation_mask() reports it at run time (tests/test_host_cpu.py
+// asserts the shipped library's mask is 0)
+#define FMHIP_FWD_ABLATIONS ((FMHIP_EXP_NO_STREAM ? 1 : 0) | (FMHIP_EXP_NO_MATH ? 2 : 0) | (FMHIP_EXP_NO_W ? 4 : 0) | (FMHIP_EXP_NO_GATHER ? 8 : 0) | \
+                             (FMHIP_EXP_L1_GATHER ? 16 : 0) | (FMHIP_EXP_NO_HOT ? 32 : 0))
+#if FMHIP_FWD_ABLATIONS && !defined(FMHIP_ABLATION_BUILD)
+#error "a result-changing FMHIP_EXP_* ablation is set without FMHIP_ABLATION_BUILD: timing-only variants are built by tools/build_variant.sh"
+#endif
+
+namespace fmhip {
+int forward_ablations() { return FMHIP_FWD_ABLATIONS; }
+}
 
 namespace fmhip {
 

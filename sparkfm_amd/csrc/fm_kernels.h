@@ -188,6 +188,9 @@ struct BwdArgs {
 
 
 int hot_blocks(int Kp, int64_t n_rows);
+// bit mask of the result-changing timing ablations (FMHIP_EXP_*) compiled into the kernels; 0 in every shipped build
+int forward_ablations();
+int backward_ablations();
 
 // n_partials (optional): the number of per-block statistic partials the launch writes to a.bsum
 hipError_t launch_forward(int Kp, FwdMode mode, const FwdArgs &a, hipStream_t s, int *n_partials = nullptr);

@@ -112,6 +112,8 @@ extern "C" {
 
 int fmhip_version(void) { return FMHIP_VERSION; }
 
+int fmhip_ablation_mask(void) { return forward_ablations() | backward_ablations(); }
+
 const char *fmhip_last_error(void) { return g_err.c_str(); }
 
 int fmhip_tune(int key, int value) {

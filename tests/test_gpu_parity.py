@@ -1039,6 +1039,22 @@ def test_full_size_properties(fmhip, config):
     check_grad(gv, gw, gv_p, gw_p, np.abs(v).max())
     check_grad(gv_p, gw_p, ogv, ogw, np.abs(v).max())
     assert st_p["sse"] == pytest.approx(st["sse"], rel=1e-6)
+    # (5) two SGD steps with weight decay at this size against the oracle's (the steps were compared layout
+    # against layout only): the fused step of batches 0 and 1 — the merged finish at these widths — on a fresh model
+    thr = min(oracle.max_threads(), 16)
+    regs = (0.0, 1e-3, 2e-3)
+    o0, ow, ov, _ = oracle.sgd_step(w0, w, v, 0, br, row_ptr, col, val, y, 0.05, *regs, threads=thr)
+    o0, ow, ov, osse1 = oracle.sgd_step(o0, ow, ov, br, 2 * br, row_ptr, col, val, y, 0.05, *regs, threads=thr)
+    fm_s = fmhip.FMModel(n1 - 1, k)
+    fm_s.w0, fm_s.w, fm_s.v = w0, w, v
+    st1 = _ffi.Stats()
+    _ffi.check(L.fmhip_sgd_step(fm_s.handle, ds.handle, 0, 0.05, *regs, None))
+    _ffi.check(L.fmhip_sgd_step(fm_s.handle, ds.handle, 1, 0.05, *regs, C.byref(st1)))
+    fm_s._device_updated()
+    assert st1.sse == pytest.approx(osse1, rel=1e-5) and st1.rows == br
+    assert np.linalg.norm(fm_s.v - ov) <= 1e-5 * np.linalg.norm(ov) and np.linalg.norm(fm_s.w - ow) <= 1e-5 * np.linalg.norm(ow)
+    assert np.abs(fm_s.v - ov).max() <= 1e-6 + 1e-5 * np.abs(ov).max() and fm_s.w0 == pytest.approx(o0, rel=1e-5, abs=1e-7)
+    fm_s.close()
     # and training moves the loss the same way on both
     for m_, d_ in ((fm, ds), (fm_p, ds_p)):
         fmhip.HipSGD(eta=0.02, regw=1e-4, regv=1e-4).learn(m_, d_)

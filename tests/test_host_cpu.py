@@ -26,6 +26,20 @@ def test_library_exports_every_declared_symbol():
     assert int(m.group(1)) == _ffi.RANGE_LEN
 
 
+def test_shipped_build_carries_no_ablation():
+    """The kernel sources hold timing-only ablation switches (FMHIP_EXP_*: parts of the arithmetic or the traffic compiled out,
+    results wrong by construction).  The shipped build must have none set: the flags of sparkfm_amd/_build.py name none, the
+    sources refuse to compile with one unless the build declares itself an ablation build, and the library reports a zero mask."""
+    from sparkfm_amd import _build, _ffi
+    assert not any("FMHIP_EXP" in f or "FMHIP_ABLATION" in f for f in _build.HIPCC_FLAGS)
+    assert _ffi.load().fmhip_ablation_mask() == 0
+    for name in ("fm_forward.hip", "fm_backward.hip"):
+        src = open(os.path.join(ROOT, "sparkfm_amd", "csrc", name)).read()
+        assert "!defined(FMHIP_ABLATION_BUILD)" in src and "#error" in src
+        for m in set(re.findall(r"FMHIP_EXP_[A-Z0-9_]+", src)):
+            assert re.search(r"#define %s 0\b" % m, src), m          # every switch defaults to off
+
+
 def test_argument_validation_without_a_gpu():
     from sparkfm_amd import _ffi
     L = _ffi.load()

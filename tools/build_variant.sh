@@ -14,7 +14,7 @@ done
 if [ "$rev" = WORK ]; then cp $root/include/fmhip.h $tmp/include/fmhip.h; else git -C $root show $rev:include/fmhip.h > $tmp/include/fmhip.h; fi
 objs=""
 for f in fm_forward fm_backward fm_apply als_kernels csc_build fmhip_api fmhip_dataset fmhip_step fmhip_comm; do
-  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC $EXTRA_FLAGS -c $tmp/sparkfm_amd/csrc/$f.hip -o $tmp/$f.o &
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC ${EXTRA_FLAGS:+-DFMHIP_ABLATION_BUILD} $EXTRA_FLAGS -c $tmp/sparkfm_amd/csrc/$f.hip -o $tmp/$f.o &
   objs="$objs $tmp/$f.o"
 done
 wait
