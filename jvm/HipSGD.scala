@@ -36,10 +36,15 @@ class HipSGD protected (eta: Double, reg0: Double, regw: Double, regv: Double, b
 
   /** relabel feature ids by descending frequency before the upload (off: ids go to the GPU as the loader produced them) */
   var relabel: Boolean = false
-  /** what a data-parallel step exchanges: 0 = the dense gradient, all-reduced; 2 = the same reduce-scattered, every rank
-    * updating its share (default: the update shrinks `gpus`-fold); 1 = only the rows some rank touched (models far
-    * wider than a global batch) */
-  var exchange: Int = 2
+  /** what a data-parallel step exchanges: 0 = the dense gradient, all-reduced in slices under the backward, every rank
+    * applying the identical update (default: the faster of the two dense modes in every schedule measured so far —
+    * DESIGN.md section 7; bench.py times both on the node it runs on); 2 = the same reduce-scattered, every rank updating
+    * its share; 1 = only the rows some rank touched (models far wider than a global batch) */
+  var exchange: Int = 0
+  /** visit the mini-batches in a seeded random order, a fresh permutation per epoch (None = ascending).  Data-parallel: every
+    * rank draws the SAME permutation of the epoch's positions (fmhip_dp_epoch_order) */
+  var shuffleSeed: Option[Long] = None
+  private var epoch: Long = 0L
   /** cuts of the backward for the overlapped exchange (fmhip_dp_plan) */
   var upperFractions: Array[Double] = Array(0.05, 0.15, 0.3, 0.55)
 
@@ -83,8 +88,14 @@ class HipSGD protected (eta: Double, reg0: Double, regw: Double, regv: Double, b
       else {
         val n1 = fm.num_attribute + 1
         val counts = parts.mapPartitions { rows =>
+          // ONE native call per partition: the partition's ids flattened first (a call per row would copy the n1-long
+          // counts array in and out every time)
+          val buf = rows.map { case (_, sv) => java.util.Arrays.copyOf(sv.index, sv.used) }.toArray
+          val flat = new Array[Int](buf.map(_.length.toLong).sum.toInt)
+          var o = 0
+          buf.foreach { a => System.arraycopy(a, 0, flat, o, a.length); o += a.length }
           val c = new Array[Long](n1)
-          rows.foreach { case (_, sv) => HipSGD.featureCounts(java.util.Arrays.copyOf(sv.index, sv.used), n1, c) }
+          HipSGD.featureCounts(flat, n1, c)
           Iterator(c)
         }.reduce { (a, b) => var i = 0; while (i < a.length) { a(i) += b(i); i += 1 }; a }
         val rank = new Array[Int](n1); val byRank = new Array[Int](n1)
@@ -94,6 +105,8 @@ class HipSGD protected (eta: Double, reg0: Double, regw: Double, regv: Double, b
     val params = sc.broadcast((fm.w0, fm.w.data, fm.v.data, uniqueId, idRank))
     val (key, nAttr, nFac, bRows, perHost, xchg, fracs) = (jobKey, fm.num_attribute, fm.num_factor, batchRows, gpusPerHost, exchange, upperFractions)
     val (e, r0, rw, rv) = (eta, reg0, regw, regv)
+    val orderSeed: Option[Long] = shuffleSeed.map(_ + epoch)
+    epoch += 1
     val out = parts.mapPartitionsWithIndex { (rank, rows) =>
       val (w0, w, v, id, ranks) = params.value
       val st = HipSGD.rankState(key, rank) {
@@ -105,7 +118,13 @@ class HipSGD protected (eta: Double, reg0: Double, regw: Double, regv: Double, b
         s
       }
       st.setParams(w0, w, v)
-      HipSGD.dpEpoch(st.model, st.data, st.comm, e, r0, rw, rv)      // every rank the same number of steps; replicas identical
+      orderSeed match {      // every rank the same number of steps, in the same order; replicas identical
+        case None => HipSGD.dpEpoch(st.model, st.data, st.comm, e, r0, rw, rv)
+        case Some(seed) =>
+          val steps = HipSGD.dpPlanSteps(st.comm).toInt                  // agreed over all ranks by dpPlan
+          val order = new scala.util.Random(seed).shuffle((0 until steps).toList).map(_.toLong).toArray
+          HipSGD.dpEpochOrder(st.model, st.data, st.comm, e, r0, rw, rv, order)
+      }
       if (rank == 0) {
         val wOut = new Array[Double](w.length); val vOut = new Array[Double](v.length)
         val w0Out = st.getParams(wOut, vOut)
@@ -259,6 +278,11 @@ object HipSGD {
   /** 0 = dense all-reduce, 1 = touched rows only (Criteo-width models), 2 = reduce-scatter + sharded update + all-gather;
     * every rank, before dpPlan */
   @native def dpExchange(comm: Long, mode: Int): Unit
+  /** the lock-step steps of an epoch agreed by dpPlan (the largest batch count of any rank) */
+  @native def dpPlanSteps(comm: Long): Long
+  /** dpEpoch with the positions visited in `order` — a permutation of 0 until dpPlanSteps, the same on every rank */
+  @native def dpEpochOrder(model: Long, data: Long, comm: Long, eta: Double, reg0: Double, regw: Double, regv: Double,
+                           order: Array[Long]): Unit
   /** [lo, hi) of `rank`, balanced by stored nonzeros (fmhip_shard_rows). */
   @native def shardRows(rowPtr: Array[Long], world: Int, rank: Int): Array[Long]
   // feature relabelling by frequency (a pure renaming; ids that arrive hashed or in dictionary order cost ~20 % of the forward):

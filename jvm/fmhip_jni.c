@@ -182,6 +182,22 @@ JNIEXPORT void JNI_FN(dpEpoch)(JNIEnv *env, jobject o, jlong m, jlong d, jlong c
     raise(env, fmhip_dp_epoch(H_MODEL(m), H_DATA(d), H_COMM(c), eta, r0, rw, rv, NULL));
 }
 
+JNIEXPORT jlong JNI_FN(dpPlanSteps)(JNIEnv *env, jobject o, jlong c) {
+    int64_t steps = 0;
+    raise(env, fmhip_dp_plan_info(H_COMM(c), &steps, NULL));
+    return (jlong)steps;
+}
+
+JNIEXPORT void JNI_FN(dpEpochOrder)(JNIEnv *env, jobject o, jlong m, jlong d, jlong c, jdouble eta, jdouble r0, jdouble rw,
+                                    jdouble rv, jlongArray order) {
+    jsize n = (*env)->GetArrayLength(env, order);
+    jlong *p = (*env)->GetLongArrayElements(env, order, NULL);       /* a long call: elements, not a critical region */
+    if (!p) return;
+    int rc = fmhip_dp_epoch_order(H_MODEL(m), H_DATA(d), H_COMM(c), eta, r0, rw, rv, (const int64_t *)p, (int64_t)n, NULL);
+    (*env)->ReleaseLongArrayElements(env, order, p, JNI_ABORT);
+    raise(env, rc);
+}
+
 /* what a data-parallel step exchanges: FMHIP_EXCHANGE_DENSE 0, _TOUCHED 1, _SHARDED 2 */
 JNIEXPORT void JNI_FN(dpExchange)(JNIEnv *env, jobject o, jlong c, jint mode) { raise(env, fmhip_dp_exchange(H_COMM(c), mode)); }
 
