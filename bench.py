@@ -381,7 +381,7 @@ def roofline_block(kern, dom, ab, pd, pmc, step_ms, live):
     return {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved * 1e9 / HBM_PEAK if achieved else None, "traffic": traffic, "basis": basis,
             "traffic_source": e.get("traffic_source"), "traffic_measured_in_this_run": bool(live),
-            "avg_launch_ms": avg_ms, "nnz_per_launch": pd[dom]["nnz"] / max(pd[dom]["launches"], 1) * e.get("launches_per_step", 1),
+            "avg_launch_ms": avg_ms, "nnz_per_launch": pd[dom]["nnz"] / max(pd[dom].get("steps") or pd[dom]["launches"], 1),
             "launches_per_step": e.get("launches_per_step", 1),
             "what": "achieved = fabric-side bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE: what left the L2s; Infinity-Cache hits "
                     "are included — the part exposes no DRAM-side or MALL hit counter, profiles/README.md — so an upper bound on HBM bytes) / "
@@ -396,11 +396,11 @@ def roofline_block(kern, dom, ab, pd, pmc, step_ms, live):
             "requested_GBps": e.get("requested_GBps"), "ceiling": e.get("ceiling"), "frac_of_ceiling": e.get("frac_of_ceiling")}
 
 
-def kernel_table(prof, k, kp, req, pmc, table_bytes, launches_per_step=None):
+def kernel_table(prof, k, kp, req, pmc, table_bytes):
     """Per-kernel: HIP-event time, algorithmic rate, requested-byte rate, the ceiling
-    that binds it and the fraction of THAT ceiling.  launches_per_step: kernels the data-parallel step launches once per
-    feature interval ({"backward": n, "fixup": n}) — their time, nonzeros and bytes are then per STEP (the sum over a
-    step's launches), which is what the requested-byte and counter figures beside them are."""
+    that binds it and the fraction of THAT ceiling.  A kernel the data-parallel step launches once per feature interval
+    (backward, fixup, update) is summed over the launches of one step — the profile counts the steps each kind was timed
+    in — so its time, nonzeros and bytes are per STEP, which is what the requested-byte and counter figures beside them are."""
     ab = alg_bytes(k)
     pd = prof.as_dict()
     tot_ms = max(sum(x["ms"] for x in pd.values()), 1e-12)
@@ -408,32 +408,41 @@ def kernel_table(prof, k, kp, req, pmc, table_bytes, launches_per_step=None):
     for name, p in pd.items():
         if not p["launches"]:
             continue
-        lps = max(int((launches_per_step or {}).get(name, 1)), 1)
-        avg_ms = p["ms"] / p["launches"] * lps
+        steps = max(p.get("steps") or p["launches"], 1)
+        lps = p["launches"] / steps
+        avg_ms = p["ms"] / steps
         ent = {"avg_ms": avg_ms, "launches": p["launches"], "share": p["ms"] / tot_ms}
         if lps > 1:
             ent["launches_per_step"] = lps
-            ent["avg_ms_is"] = "the sum over the %d feature-interval launches of one step" % lps
+            ent["avg_ms_is"] = "the sum over the %.3g launches of one step (one per feature interval)" % lps
         if name in ab:
             ent["alg_bytes_per_nnz"] = ab[name]
-            ent["alg_GBps"] = (p["nnz"] / p["launches"] * lps) * ab[name] / (avg_ms * 1e-3) / 1e9
+            ent["alg_GBps"] = (p["nnz"] / steps) * ab[name] / (avg_ms * 1e-3) / 1e9
         if name in req:
             ent["requested_bytes_per_launch"] = req[name]
             ent["requested_GBps"] = req[name] / (avg_ms * 1e-3) / 1e9
             if name in ("forward", "backward"):
                 hit = pmc.get("k_" + name, {}).get("l2_hit")
                 cname, c, h = gather_ceiling(table_bytes[name], hit)
-                ent["ceiling"] = {"name": cname, "GBps": c / 1e9, "table_bytes": table_bytes[name],
-                                  "l2_hit": h, "l2_hit_source": (("rocprofv3 --pmc TCC_HIT / TCC_MISS pass of this run" if pmc.get("k_" + name, {}).get("l2_hit_measured_in_this_run")
-                                                                  else "profiles/pmc_traffic.json") if hit is not None else
-                                                                 ("uniform-gather model" if h is not None else None))}
-                l1 = pmc.get("k_" + name, {}).get("l1_hit_share_of_accesses")
-                if l1 is not None:
-                    ent["ceiling"]["l1_hit_share_of_accesses"] = l1      # served by the CU's own L1: not priced by the ceiling (it only adds headroom)
+                if cname == "hbm_gather":
+                    # a table beyond the Infinity Cache and no measured hit rate: skewed gathers are served by the caches in a
+                    # share nobody measured here, so no rate is a ceiling for them — none is claimed
+                    ent["ceiling"] = None
+                    ent["frac_of_ceiling"] = None
+                    ent["ceiling_note"] = "no ceiling claimed: the table is beyond the Infinity Cache and this configuration has no measured L2 hit rate"
+                else:
+                    measured = pmc.get("k_" + name, {}).get("l2_hit_measured_in_this_run")
+                    ent["ceiling"] = {"name": cname, "GBps": c / 1e9, "table_bytes": table_bytes[name], "l2_hit": h,
+                                      "l2_hit_source": (("rocprofv3 --pmc TCC_HIT / TCC_MISS pass of this run" if measured else "profiles/pmc_traffic.json")
+                                                        if hit is not None else ("uniform-gather model" if h is not None else None))}
+                    l1 = pmc.get("k_" + name, {}).get("l1_hit_share_of_accesses")
+                    if l1 is not None:
+                        ent["ceiling"]["l1_hit_share_of_accesses"] = l1      # served by the CU's own L1: not priced by the ceiling (it only adds headroom)
             else:
                 ent["ceiling"] = {"name": "hbm_stream", "GBps": CEIL["hbm_stream"] / 1e9}
-            ent["frac_of_ceiling"] = ent["requested_GBps"] / ent["ceiling"]["GBps"]
-            if ent["frac_of_ceiling"] > 1.0:
+            if ent.get("ceiling"):
+                ent["frac_of_ceiling"] = ent["requested_GBps"] / ent["ceiling"]["GBps"]
+            if (ent.get("frac_of_ceiling") or 0.0) > 1.0:
                 ent["ceiling_exceeded"] = ("the kernel asked for bytes faster than the L2 / Infinity-Cache gather rates allow: the excess was "
                                            "served by the CUs' L1s, which the ceiling does not price")
         pe = pmc.get("k_" + name, {})
@@ -879,7 +888,9 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
 
     def step(j):
         if exchange == "rccl":
-            _ffi.check(L.fmhip_dp_step(hm, hd, j % nb, comm.handle, args.eta, regs[0], regs[1], regs[2]))
+            # a POSITION of the lock-step schedule, named by every rank alike (the touched-rows exchange picks that position's
+            # planned union; the tuning passes revisit positions out of order)
+            _ffi.check(L.fmhip_dp_step_at(hm, hd, j % nb, comm.handle, args.eta, regs[0], regs[1], regs[2]))
         elif exchange == "torch":
             dp.step(eng, j % nb)
         else:
@@ -897,12 +908,16 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
     sync()
     barrier()
     tuning = None
-    if exchange == "rccl" and dp.exchange != "touched" and args.upper_fractions == "auto" and (world > 1 or args.emulate_allreduce):
+    if exchange == "rccl" and args.upper_fractions == "auto" and (world > 1 or args.emulate_allreduce or dp.exchange == "touched"):
         # measure, don't guess: the best cut — and whether the sharded update pays — depends on the collectives' real
         # bandwidth on this node.  Candidates are timed for 4 steps each; the ranks agree through a max-reduce.
         tuning = []
-        modes = ("dense", "sharded") if args.dp_exchange == "auto" else (dp.exchange,)
+        modes = ("dense", "sharded") if args.dp_exchange == "auto" and dp.exchange != "touched" else (dp.exchange,)
         cands = ((0.3,), (0.2,), (0.12, 0.4), (0.08, 0.25, 0.5), (0.05, 0.15, 0.3, 0.55), (0.04, 0.1, 0.2, 0.35, 0.6), ())
+        if dp.exchange == "touched":
+            # the compact gradient's slices overlap the backward as the dense one's do; with one rank there is nothing to hide
+            # and every cut only costs launches — measured like everything else
+            cands = ((), (0.3,), (0.12, 0.4), (0.05, 0.15, 0.3, 0.55))
         if args.transport != "rccl":
             cands = ((0.12, 0.4), ())        # a rehearsal of the flow: every step moves the whole gradient through the host
         for mode in modes:
@@ -1021,7 +1036,7 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
         nnz3 = [ds3.batch_info(b)["nnz"] for b in range(nb3)]
 
         def step3(j):
-            _ffi.check(L.fmhip_dp_step(fm3.handle, ds3.handle, j % nb3, comm.handle, args.eta, regs[0], regs[1], regs[2]))
+            _ffi.check(L.fmhip_dp_step_at(fm3.handle, ds3.handle, j % nb3, comm.handle, args.eta, regs[0], regs[1], regs[2]))
         keep, keep_mode = dp.upper_fractions, dp.exchange
         best3 = None
         for mode3 in (("dense", "sharded") if args.dp_exchange == "auto" else (dp.exchange,)):
@@ -1072,11 +1087,6 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
         packed = k < kp
         pmc = committed_pmc(config, k, batch_rows)
         live = None
-        lps = None
-        if exchange == "rccl":
-            # the data-parallel step launches backward + fixup once per feature interval: figures are per step (kernel_table)
-            n_int = len([c for c in dp.cuts if c > 0]) + 1
-            lps = {"backward": n_int, "fixup": n_int}
         if exchange == "rccl" and dp.exchange != "touched" and config == "C4" and not args.no_pmc and not args.tune and not args.hot_pages:
             # N > 1 (or --force-dp): the counters of THIS rank's workload under the step this line timed — the same shard size,
             # batch, cuts and exchange mode through the library's own data-parallel step with a one-rank communicator whose
@@ -1104,14 +1114,14 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
         dense_apply = (use_dp and not (exchange == "rccl" and dp.exchange == "touched")) or n_cols * 2 > n1
         req = requested_bytes(kp, rows0, nnz0, nnz0_sparse, n_cols, hot, n_cols, dense_apply, n1, packed, nnz0_sparse_b, lay["hot_pages"])
         table_bytes = {"forward": n1 * kp * 4, "backward": rows0 * kp * 4}
-        kern = kernel_table(prof, k, kp, req, pmc, table_bytes, lps)
+        kern = kernel_table(prof, k, kp, req, pmc, table_bytes)
         # the dominant kernel = the longest launch (not the largest sampled total: kinds are sampled in rotation)
         dom = max(("forward", "backward"), key=lambda n: kern.get(n, {}).get("avg_ms", 0.0))
         pd = prof.as_dict()
         value = total_nnz / elapsed
         step_ms = elapsed / args.steps * 1e3
         # fraction of the step's time that the kernels' own ceilings account for (<= 1 when no kernel beats its ceiling)
-        explained_ms = sum(e["requested_bytes_per_launch"] / (e["ceiling"]["GBps"] * 1e9) * 1e3 for e in kern.values() if "ceiling" in e)
+        explained_ms = sum(e["requested_bytes_per_launch"] / (e["ceiling"]["GBps"] * 1e9) * 1e3 for e in kern.values() if e.get("ceiling"))
         out = {
             "metric": "nnz_per_sec_fm_sgd_training", "value": value, "unit": "nnz/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -93,6 +93,8 @@ typedef struct fmhip_profile {
     int64_t launches[FMHIP_K_COUNT];
     int64_t nnz[FMHIP_K_COUNT];      /* stored nonzeros those launches covered */
     int64_t rows[FMHIP_K_COUNT];
+    int64_t steps[FMHIP_K_COUNT];    /* steps in which the kind was timed: a data-parallel step launches its backward / fixup /
+                                      * update once per feature interval, so ms / steps is the kind's time PER STEP */
 } fmhip_profile;
 
 /* ---- library ----------------------------------------------------------------- */

@@ -48,10 +48,10 @@ class Stats(C.Structure):
 
 class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * K_COUNT), ("launches", C.c_int64 * K_COUNT), ("nnz", C.c_int64 * K_COUNT),
-                ("rows", C.c_int64 * K_COUNT)]
+                ("rows", C.c_int64 * K_COUNT), ("steps", C.c_int64 * K_COUNT)]
 
     def as_dict(self):
-        return {KERNEL_NAMES[i]: dict(ms=self.ms[i], launches=self.launches[i], nnz=self.nnz[i], rows=self.rows[i])
+        return {KERNEL_NAMES[i]: dict(ms=self.ms[i], launches=self.launches[i], nnz=self.nnz[i], rows=self.rows[i], steps=self.steps[i])
                 for i in range(K_COUNT)}
 
 

@@ -681,6 +681,8 @@ int fmhip_profile_end(fmhip_model_t m, fmhip_profile *p) {
     m->profiling = false;
     memset(p, 0, sizeof *p);
     HIP_TRY(hipStreamSynchronize(m->stream));
+    int64_t last_step[FMHIP_K_COUNT];
+    for (int64_t &x : last_step) x = -1;
     for (auto &r : m->prof) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
@@ -688,6 +690,10 @@ int fmhip_profile_end(fmhip_model_t m, fmhip_profile *p) {
             p->launches[r.kind] += 1;
             p->nnz[r.kind] += r.nnz;
             p->rows[r.kind] += r.rows;
+            if (r.step != last_step[r.kind]) {       // records are in launch order: a new step index = one more timed step
+                p->steps[r.kind] += 1;
+                last_step[r.kind] = r.step;
+            }
         }
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);

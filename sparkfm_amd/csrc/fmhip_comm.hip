@@ -510,9 +510,16 @@ int dp_step_touched(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_com
     const float my_rows = live ? (float)d->batches[(size_t)batch].rows : 0.f;
     hipLaunchKernelGGL(k_set_float, dim3(1), dim3(1), 0, m->stream, c->rows_dev, my_rows);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev_rows, m->stream));
-    HIP_TRY(hipStreamWaitEvent(c->cs, c->ev_rows, 0));
-    TRY(collective(c, c->rows_dev, 1, FMHIP_COLL_SUM_F32, c->cs));
+    // one interval (no cuts): nothing can overlap, so both collectives run on the compute stream itself — no event hops
+    // between the streams, which cost a one-rank step ~40 us of idle time (profiles/r04_experiments.md)
+    const bool serial = c->cuts.empty();
+    if (serial) {
+        TRY(collective(c, c->rows_dev, 1, FMHIP_COLL_SUM_F32, m->stream));
+    } else {
+        HIP_TRY(hipEventRecord(c->ev_rows, m->stream));
+        HIP_TRY(hipStreamWaitEvent(c->cs, c->ev_rows, 0));
+        TRY(collective(c, c->rows_dev, 1, FMHIP_COLL_SUM_F32, c->cs));
+    }
     if (live) {
         // the packed gradient is not written by this step: a pending memset of it (8.9 GB at C5's width) would be wasted
         m->grad_dirty = false;
@@ -550,7 +557,17 @@ int dp_step_touched(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_com
             TRY(rc);
         }
         const size_t plo = (size_t)pe[(size_t)i], phi = (size_t)pe[(size_t)i + 1];
-        if (n_int == 1) {
+        if (serial) {
+            int pi = -1;
+            if (pr && pr->n_coll < kProfColl) {
+                pi = pr->n_coll++;
+                HIP_TRY(hipEventRecord(pr->c0[pi], m->stream));
+            }
+            TRY(collective(c, c->cg, L.total, FMHIP_COLL_SUM_F32, m->stream));
+            TRY(emu_delay(c, (double)L.total * sizeof(float), m->stream));
+            if (pi >= 0) HIP_TRY(hipEventRecord(pr->c1[pi], m->stream));
+            if (c->profiling) c->prof_bytes += (int64_t)(L.total * sizeof(float));
+        } else if (n_int == 1) {
             const Region whole[1] = {{c->cg, L.total}};
             TRY(reduce_regions(m, c, whole, 1, c->ev_ready[i], c->ev_done[i], pr));
         } else {
@@ -568,7 +585,7 @@ int dp_step_touched(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_com
         const int64_t plo = pe[(size_t)i], phi = pe[(size_t)i + 1];
         if (pend_hi < 0) pend_hi = phi;
         const bool last = i == 0;
-        HIP_TRY(hipStreamWaitEvent(m->stream, c->ev_done[i], 0));
+        if (!serial) HIP_TRY(hipStreamWaitEvent(m->stream, c->ev_done[i], 0));
         if (!last && (pend_hi - plo) * 8 < ts.n_u) continue;      // small slices share the next one's launch
         if (last)       // the step's global sums where fmhip_step_stats / fmhip_dp_epoch read them
             HIP_TRY(hipMemcpyAsync(m->scal(), c->cg, (size_t)kScalars * sizeof(float), hipMemcpyDeviceToDevice, m->stream));

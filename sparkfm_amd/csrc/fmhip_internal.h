@@ -100,6 +100,7 @@ struct ProfRec {
     int kind;
     hipEvent_t a, b;
     int64_t nnz, rows;
+    int64_t step;       // the step (fmhip_model::prof_step) the launch belongs to
 };
 
 // What ONE scoring call (predict / rmse / residual / term_q) works in: its own stream and workspace, so that any number of

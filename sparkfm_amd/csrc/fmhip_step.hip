@@ -43,6 +43,7 @@ struct ProfScope {
         r.kind = kind;
         r.nnz = nnz;
         r.rows = rows;
+        r.step = m->prof_step;
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
         (void)hipEventRecord(r.a, m->stream);
     }
