@@ -194,6 +194,45 @@ int32_t plan_bands(const HostBatch &hb, int32_t cnnz, int64_t rows, const std::v
     return affine;
 }
 
+// The gradient-side pages of the dense hot block, filled on the device from the CSR stream that was just uploaded (their
+// entries stay in it): 8 lanes per row walk the row's entries, an entry whose feature sits in slot h >= kHotT of the id table
+// (ascending inside a page: a binary search per page) stores its value to xhot[page][row][h % kHotT].  One writer per
+// element: a feature chosen for the block occurs at most once per row.
+__global__ __launch_bounds__(256) void k_fill_hot_pages(const int64_t *row_ptr, const int32_t *col, const float *val, int64_t n_rows,
+                                                        const int32_t *hot_ids, int pages, float *xhot, int64_t page_floats) {
+    __shared__ int32_t ids[kHotPages * kHotT];
+    for (int i = threadIdx.x; i < pages * kHotT; i += 256) ids[i] = hot_ids[i];
+    __syncthreads();
+    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int l = threadIdx.x & 7;
+    if (r >= n_rows) return;
+    for (int64_t p = row_ptr[r] + l; p < row_ptr[r + 1]; p += 8) {
+        const int32_t c = col[p];
+        for (int pg = 1; pg < pages; ++pg) {
+            const int32_t *t = ids + pg * kHotT;
+            // the page's live slots come first, ascending; unused slots are -1
+            int n = 0;
+            while (n < kHotT && t[n] >= 0) ++n;
+            if (n == 0 || c < t[0] || c > t[n - 1]) continue;
+            int lo = 0, hi = n;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (t[mid] < c) lo = mid + 1;
+                else hi = mid;
+            }
+            if (lo < n && t[lo] == c) xhot[(size_t)pg * page_floats + (size_t)r * kHotT + lo] = val[p];
+        }
+    }
+}
+
+hipError_t fill_hot_pages(const int64_t *row_ptr, const int32_t *col, const float *val, int64_t n_rows, const int32_t *hot_ids, int pages,
+                          float *xhot, int64_t page_floats) {
+    if (n_rows < 1 || pages < 2) return hipSuccess;
+    hipLaunchKernelGGL(k_fill_hot_pages, dim3((unsigned)((n_rows * 8 + 255) / 256)), dim3(256), 0, nullptr, row_ptr, col, val, n_rows, hot_ids, pages, xhot,
+                       page_floats);
+    return hipGetLastError();
+}
+
 // scoring = true: rows + labels only (FMModel.predict / Model.computeRMSE on held-out data,
 // S/driver.scala:100-112) — no transposes, no hot block, nothing a training step needs
 // hot_opt: -1 = the process-wide defaults (fmhip_tune keys 5, 12), 0 = no hot block, n >= 1 = up to n pages of it;
@@ -370,7 +409,10 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
             const size_t page_floats = (size_t)std::max<int64_t>(n_rows, 1) * kHotT;
             sp_col_buf.reset(new int32_t[(size_t)std::max<int64_t>(sp_ptr[(size_t)n_rows], 1)]);
             sp_val_buf.reset(new float[(size_t)std::max<int64_t>(sp_ptr[(size_t)n_rows], 1)]);
-            xhot_buf.reset(new float[page_floats * (size_t)pages]);
+            // page 0 is filled here (its entries leave the CSR stream); the gradient-side pages' entries STAY in the CSR stream,
+            // so their pages are filled on the device from the uploaded stream (k_fill_hot_pages): 64 MB per page and million
+            // rows that neither the host writes nor PCIe carries
+            xhot_buf.reset(new float[page_floats]);
             int32_t *sp_col = sp_col_buf.get();
             float *sp_val = sp_val_buf.get(), *xhot = xhot_buf.get();
             std::vector<std::vector<slotmask_t>> tmask((size_t)T, std::vector<slotmask_t>((size_t)nb, 0u));
@@ -379,15 +421,15 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
                 for (int64_t r = lo; r < hi; ++r) {
                     slotmask_t seen = 0;
                     int64_t o = sp_ptr[(size_t)r], outb = 0;
-                    for (int pg = 0; pg < pages; ++pg) {
-                        float *xr = xhot + (size_t)pg * page_floats + (size_t)r * kHotT;
+                    {
+                        float *xr = xhot + (size_t)r * kHotT;
                         for (int h = 0; h < kHotT; ++h) xr[h] = 0.f;
                     }
                     for (int64_t p = row_ptr[r]; p < row_ptr[r + 1]; ++p) {
                         const int8_t h = slot[(size_t)col[p]];
                         if (h >= 0) {
                             seen |= (slotmask_t)1 << h;
-                            xhot[(size_t)(h / kHotT) * page_floats + (size_t)r * kHotT + (h % kHotT)] = (float)val[p];
+                            if (h < kHotT) xhot[(size_t)r * kHotT + h] = (float)val[p];
                         }
                         if (h < 0 || h >= kHotT) {
                             sp_col[(size_t)o] = col[p];
@@ -491,10 +533,23 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     if ((rc = upload(d->row_ptr, row_ptr, (size_t)n_rows + 1)) || (rc = upload(d->col, col, (size_t)nnz_s)) ||
         (rc = upload(d->val, val_up, (size_t)nnz_s)) || (rc = upload(d->y, yf.data(), (size_t)n_rows)) ||
         (!scoring && ((rc = d->crow.alloc((size_t)nnz_s)) || (rc = d->cval.alloc((size_t)nnz_s)))) ||
-        (split && ((rc = upload(d->xhot, xhot_buf.get(), (size_t)std::max<int64_t>(n_rows, 1) * kHotT * (size_t)d->hot_pages)) ||
+        (split && ((rc = d->xhot.alloc((size_t)std::max<int64_t>(n_rows, 1) * kHotT * (size_t)d->hot_pages)) ||
                    (rc = upload(d->d_hot_ids, d->hot_ids.data(), d->hot_ids.size()))))) {
         delete d;
         return rc;
+    }
+    if (split) {
+        const size_t page_floats = (size_t)std::max<int64_t>(n_rows, 1) * kHotT;
+        hipError_t he = hipMemcpy(d->xhot.p, xhot_buf.get(), page_floats * sizeof(float), hipMemcpyHostToDevice);
+        if (he == hipSuccess && d->hot_pages > 1) {
+            he = hipMemsetAsync(d->xhot.p + page_floats, 0, page_floats * (size_t)(d->hot_pages - 1) * sizeof(float), nullptr);
+            if (he == hipSuccess) he = fill_hot_pages(d->row_ptr.p, d->col.p, d->val.p, n_rows, d->d_hot_ids.p, d->hot_pages, d->xhot.p, (int64_t)page_floats);
+            if (he == hipSuccess) he = hipStreamSynchronize(nullptr);
+        }
+        if (he != hipSuccess) {
+            delete d;
+            return fail(FMHIP_ERR_HIP, "filling the dense hot block's pages: %s", hipGetErrorString(he));
+        }
     }
     std::vector<float>().swap(valf);
     xhot_buf.reset();
