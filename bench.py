@@ -106,6 +106,14 @@ def cpu_baseline(d, k, n1, batch_rows, eta, regs, w0, w, v, budget_s=15.0):
     from oracle import capi
     L = capi.lib()
     threads = host_cores()
+    # launchers such as torch.distributed.run export OMP_NUM_THREADS=1 to every rank: the oracle would then run on ONE thread
+    # whatever it is asked for (it clamps to omp_get_max_threads) while this record said 16 — raise the OpenMP limit of this
+    # process first, and report the threads that really ran
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(threads)
+    except OSError:
+        pass
+    threads = max(1, min(threads, int(L.fmo_max_threads())))
     n_rows = len(d["row_ptr"]) - 1
     nb = -(-n_rows // batch_rows)
     rp = np.ascontiguousarray(d["row_ptr"], np.int64)
@@ -733,6 +741,10 @@ def main():
                     help="RANKS:BUSBW_GBps, one-rank runs only (with --force-dp): hold the comm stream after every collective for "
                          "the time a ring all-reduce over RANKS GPUs at that bus bandwidth would take (fmhip_comm_emulate), so the "
                          "overlap schedule and the cut tuning can be timed on a one-GPU box")
+    ap.add_argument("--emulate-load", type=int, default=0,
+                    help="with --emulate-allreduce: spend every emulated collective's duration with this many workgroups streaming the "
+                         "payload through HBM (fmhip_comm_emulate_load) instead of idling — the CU slots and memory bandwidth a real "
+                         "collective takes from the backward beside it")
     ap.add_argument("--no-relabel", action="store_true",
                     help="C5 only: keep the hashed ids as generated instead of relabelling them by frequency at load")
     ap.add_argument("--hot-pages", type=int, default=0,
@@ -864,6 +876,7 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
                 # the sharded update's reduce-scatter and all-gather are half of that each, and this rank plays rank 0 of N
                 _ffi.check(L.fmhip_comm_emulate(comm.handle, emu_busbw * emu_ranks / (2.0 * (emu_ranks - 1))))
                 _ffi.check(L.fmhip_comm_emulate_ranks(comm.handle, emu_ranks))
+                _ffi.check(L.fmhip_comm_emulate_load(comm.handle, args.emulate_load))
         except Exception as ex:   # noqa: BLE001 — reported in the JSON line, never silent
             if group is not None:
                 raise
@@ -1203,6 +1216,8 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
                 xc["cut_tuning"] = tuning
             if args.emulate_allreduce:
                 xc["emulated"] = "ring all-reduce over %s GPUs at bus bandwidth %s GB/s, as a delay on the comm stream (one real rank)" % tuple(args.emulate_allreduce.split(":"))
+                if args.emulate_load:
+                    xc["emulated"] += "; the delay is spent by %d workgroups streaming the payload through HBM (read + write, twice per all-reduce)" % args.emulate_load
             out["exchange"] = xc
         if not args.no_cpu_baseline and not wide:
             # rank 0's host cores, on rank 0's shard of the line's own workload, after every timed region (at N > 1 the other

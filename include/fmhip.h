@@ -412,6 +412,11 @@ typedef struct fmhip_comm_profile {
  * that payload would take at that rate — so the overlap schedule can be timed with one rank.  0 = off.
  * (Optimistic: a real collective also takes CUs and memory bandwidth from the backward beside it.) */
 int fmhip_comm_emulate(fmhip_comm_t c, double payload_gb_per_s);
+/* ... with the collective's FOOTPRINT on this GPU instead of an idle wait: for the emulated duration `workgroups` workgroups
+ * (RCCL keeps a few dozen resident) stream the payload through HBM — read and written back unchanged, twice for an all-reduce,
+ * once for a reduce-scatter or an all-gather — so the backward beside it loses the CU slots and the memory bandwidth a real
+ * collective takes.  0 = the idle wait (default). */
+int fmhip_comm_emulate_load(fmhip_comm_t c, int workgroups);
 /* ... and for the sharded update: pretend to be rank 0 of `ranks` (one real rank only): intervals are cut into `ranks` shares,
  * this rank updates and zeroes only the first, the reduce-scatter / all-gather delays are those of `ranks` GPUs (half an
  * all-reduce each).  The rows of the other shares are NOT updated — a timing aid, not a training mode.  0 = off. */

@@ -33,7 +33,7 @@ SYMBOLS = (
     "fmhip_comm_create_external", "fmhip_stream_wait", "fmhip_device_read", "fmhip_device_write",
     "fmhip_dp_exchange", "fmhip_dp_exchange_info", "fmhip_comm_emulate_ranks", "fmhip_model_tune", "fmhip_dataset_band_plan",
     "fmhip_dp_step_at", "fmhip_dp_epoch_order", "fmhip_dp_plan_info", "fmhip_dataset_als_levels",
-    "fmhip_feature_counts_gpu", "fmhip_rank_from_counts_gpu", "fmhip_relabel_columns_gpu",
+    "fmhip_feature_counts_gpu", "fmhip_rank_from_counts_gpu", "fmhip_relabel_columns_gpu", "fmhip_comm_emulate_load",
 )
 UNIQUE_ID_BYTES = 128
 
@@ -160,6 +160,7 @@ def load():
     L.fmhip_dataset_als_levels.argtypes = [vp, P(i64), P(i64), P(i64)]
     L.fmhip_comm_emulate.argtypes = [vp, dbl]
     L.fmhip_comm_emulate_ranks.argtypes = [vp, C.c_int]
+    L.fmhip_comm_emulate_load.argtypes = [vp, C.c_int]
     L.fmhip_comm_profile_begin.argtypes = [vp]
     L.fmhip_comm_profile_end.argtypes = [vp, P(CommProfile)]
     L.fmhip_shard_rows.argtypes = [i64, vp, C.c_int, C.c_int, P(i64), P(i64)]

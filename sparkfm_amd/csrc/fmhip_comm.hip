@@ -121,6 +121,34 @@ __global__ void k_comm_delay(uint64_t ticks) {
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
+// The same stand-in with the collective's FOOTPRINT on this GPU (fmhip_comm_emulate_load): `gridDim.x` workgroups stream the
+// payload through HBM `rounds` times — read, write back unchanged (nobody else touches a slice while it is "exchanged") — at a
+// pace that makes the whole take `ticks`: a ring all-reduce reads and writes about 2(N-1)/N x the payload twice on every rank
+// and keeps a few dozen workgroups resident while it does, which is what takes CU slots and memory bandwidth from the backward
+// running beside it.  Bounded: the chunk count is finite and every wait ends by the clock.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_comm_traffic(f32x4_t *buf, size_t n4, uint64_t ticks, int rounds) {
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    const size_t per = (n4 + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per < n4 ? (size_t)blockIdx.x * per : n4;
+    const size_t hi = lo + per < n4 ? lo + per : n4;
+    constexpr size_t kChunk = 256 * 16;                     // float4 per workgroup and chunk: 64 KB
+    const size_t chunks = ((hi - lo + kChunk - 1) / kChunk) * (size_t)rounds;
+    size_t done = 0;
+    for (int r = 0; r < rounds; ++r)
+        for (size_t base = lo; base < hi; base += kChunk) {
+            const size_t end = base + kChunk < hi ? base + kChunk : hi;
+            for (size_t i = base + threadIdx.x; i < end; i += 256) {
+                const f32x4_t v = __builtin_nontemporal_load(buf + i);
+                __builtin_nontemporal_store(v, buf + i);
+            }
+            ++done;
+            const uint64_t due = chunks ? ticks * done / chunks : ticks;
+            while (__builtin_amdgcn_s_memrealtime() - t0 < due) __builtin_amdgcn_s_sleep(8);
+        }
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 // the row count of this rank's mini-batch travels as a kernel argument (a host buffer would have to outlive the
 // asynchronous copy, and the host runs steps ahead of the stream)
 __global__ void k_set_float(float *p, float v) { *p = v; }
@@ -215,6 +243,7 @@ struct fmhip_comm {
     std::vector<int64_t> cuts;                // ascending feature ids in (0, n+1) cutting the backward into intervals (empty: one collective)
     int64_t *scratch = nullptr;               // device int64[kMaxCuts + 1] for the small control collectives
     double emu_bytes_per_us = 0.0;            // > 0: every collective is followed by a delay of bytes / this (fmhip_comm_emulate)
+    int emu_wgs = 0;                          // > 0: the delay is spent by this many workgroups streaming the payload (fmhip_comm_emulate_load)
     bool profiling = false;
     std::vector<CommProf> prof;               // the pool of event sets (fmhip_comm_profile_begin)
     size_t prof_next = 0;                     // sets handed out since _begin
@@ -292,9 +321,15 @@ int collective(fmhip_comm_t c, void *buf, size_t count, int kind, hipStream_t s)
 }
 
 // holds stream `s` for the time `bytes` would take at the emulated payload rate (fmhip_comm_emulate)
-int emu_delay(fmhip_comm_t c, double bytes, hipStream_t s) {
+// buf / floats: the payload itself (16-byte aligned), for the emulation with a footprint; rounds: passes over it (2 = an
+// all-reduce, 1 = a reduce-scatter or an all-gather)
+int emu_delay(fmhip_comm_t c, double bytes, hipStream_t s, float *buf = nullptr, size_t floats = 0, int rounds = 2) {
     if (c->emu_bytes_per_us <= 0.0 || bytes <= 0.0) return FMHIP_OK;
-    hipLaunchKernelGGL(k_comm_delay, dim3(1), dim3(64), 0, s, (uint64_t)(bytes / c->emu_bytes_per_us * 100.0));
+    const uint64_t ticks = (uint64_t)(bytes / c->emu_bytes_per_us * 100.0);
+    if (c->emu_wgs > 0 && buf && floats >= 4 && (reinterpret_cast<uintptr_t>(buf) & 15u) == 0)
+        hipLaunchKernelGGL(k_comm_traffic, dim3((unsigned)c->emu_wgs), dim3(256), 0, s, reinterpret_cast<f32x4_t *>(buf), floats / 4, ticks, rounds);
+    else
+        hipLaunchKernelGGL(k_comm_delay, dim3(1), dim3(64), 0, s, ticks);
     HIP_TRY(hipGetLastError());
     return FMHIP_OK;
 }
@@ -329,7 +364,12 @@ int reduce_regions(fmhip_model_t m, fmhip_comm_t c, const Region *reg, int n_reg
         bytes += reg[i].n * sizeof(float);
     }
     if (group) NCCL_TRY(rccl().GroupEnd());
-    TRY(emu_delay(c, (double)bytes, c->cs));
+    if (c->emu_wgs > 0) {
+        for (int i = 0; i < n_reg; ++i)
+            if (reg[i].n) TRY(emu_delay(c, (double)reg[i].n * sizeof(float), c->cs, reg[i].p, reg[i].n));
+    } else {
+        TRY(emu_delay(c, (double)bytes, c->cs));
+    }
     if (pi >= 0) HIP_TRY(hipEventRecord(pr->c1[pi], c->cs));
     HIP_TRY(hipEventRecord(done, c->cs));
     c->prof_bytes += c->profiling ? (int64_t)bytes : 0;
@@ -564,7 +604,7 @@ int dp_step_touched(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_com
                 HIP_TRY(hipEventRecord(pr->c0[pi], m->stream));
             }
             TRY(collective(c, c->cg, L.total, FMHIP_COLL_SUM_F32, m->stream));
-            TRY(emu_delay(c, (double)L.total * sizeof(float), m->stream));
+            TRY(emu_delay(c, (double)L.total * sizeof(float), m->stream, c->cg, L.total));
             if (pi >= 0) HIP_TRY(hipEventRecord(pr->c1[pi], m->stream));
             if (c->profiling) c->prof_bytes += (int64_t)(L.total * sizeof(float));
         } else if (n_int == 1) {
@@ -731,7 +771,7 @@ int dp_step_sharded(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_com
         TRY(collective(c, gw, n_gw, FMHIP_COLL_SUM_F32, c->cs));
         TRY(collective(c, m->Gb() + lo, n_gb, FMHIP_COLL_SUM_F32, c->cs));
         if (!c->ext) NCCL_TRY(rccl().GroupEnd());
-        TRY(emu_delay(c, half * gv_bytes + head_bytes, c->cs));
+        TRY(emu_delay(c, half * gv_bytes + head_bytes, c->cs, m->GV() + (size_t)lo * kp, (size_t)(hi_r - lo) * kp, 1));
         if (pi >= 0) HIP_TRY(hipEventRecord(pr->c1[pi], c->cs));
         TRY(step_apply_shard(m, eta, reg0, regw, regv, lo, hi, hi_r, vlo, vhi, c->rows_dev, last, c->cs));
         pi = -1;
@@ -740,7 +780,7 @@ int dp_step_sharded(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_com
             HIP_TRY(hipEventRecord(pr->c0[pi], c->cs));
         }
         TRY(collective(c, m->V.p + at, count, FMHIP_COLL_ALLGATHER_F32, c->cs));
-        TRY(emu_delay(c, half * gv_bytes, c->cs));
+        TRY(emu_delay(c, half * gv_bytes, c->cs, m->V.p + (size_t)lo * kp, (size_t)(hi_r - lo) * kp, 1));
         if (pi >= 0) HIP_TRY(hipEventRecord(pr->c1[pi], c->cs));
         if (c->profiling) c->prof_bytes += (int64_t)(gv_bytes + head_bytes);
     }
@@ -926,6 +966,13 @@ int fmhip_comm_emulate(fmhip_comm_t c, double payload_gb_per_s) {
     if (!c) return fail(FMHIP_ERR_INVALID, "communicator is NULL");
     if (payload_gb_per_s < 0.0) return fail(FMHIP_ERR_INVALID, "negative rate");
     c->emu_bytes_per_us = payload_gb_per_s * 1e3;      // GB/s = 1e3 bytes per microsecond
+    return FMHIP_OK;
+}
+
+int fmhip_comm_emulate_load(fmhip_comm_t c, int workgroups) {
+    if (!c) return fail(FMHIP_ERR_INVALID, "communicator is NULL");
+    if (workgroups < 0 || workgroups > 1024) return fail(FMHIP_ERR_INVALID, "workgroups must be 0..1024");
+    c->emu_wgs = workgroups;
     return FMHIP_OK;
 }
 

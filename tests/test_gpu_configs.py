@@ -354,6 +354,8 @@ def test_library_side_exchange_one_rank(fmhip, upper, exchange):
                 # hold the comm stream for every collective as a 40 GB/s all-reduce would: the schedule must not care
                 from sparkfm_amd import _ffi as ffi
                 ffi.check(ffi.load().fmhip_comm_emulate(comm.handle, 40.0))
+                # ... spent by 8 workgroups streaming the payload through HBM (read, written back unchanged): not a bit may move
+                ffi.check(ffi.load().fmhip_comm_emulate_load(comm.handle, 8))
             dp = HipDataParallelSGD(comm, eta=0.05, regw=1e-3, regv=1e-3, upper_fractions=upper, exchange=exchange)
             for _ in range(2):
                 dp.learn(fm, ds)
