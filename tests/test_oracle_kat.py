@@ -195,3 +195,26 @@ def test_sgd_epoch_order_and_ragged_batches():
     # multi-threaded accumulation agrees to fp64 reassociation
     rt = oracle.sgd_epoch(a["w0"], a["w"], a["v"], 25, *args, threads=4)
     np.testing.assert_allclose(rt[2], v, rtol=1e-12, atol=1e-14)
+
+
+def test_als_epoch_never_raises_the_regularised_objective():
+    """A pin from first principles, independent of how the closed form was restated: the prediction is LINEAR in any single
+    parameter with the others held fixed (h = d yhat / d theta does not depend on theta: S/fm/lib/ALS.scala:56-58 gives
+    h(v_fi) = x q_f - x^2 v_fi = x (q_f - x v_fi)), so theta* = -(sum e h - theta sum h^2) / (lambda + sum h^2) (:167-176) is the exact
+    minimiser of  sum_r e_r^2 + lambda theta^2  along that coordinate — every step, and therefore every epoch, must leave
+    J = sum e^2 + reg0 w0^2 + regw |w|^2 + regv |V|^2  (over the trained slots: quirk Q1 leaves the last one alone) no larger."""
+    for seed, regs in ((3, (0.0, 0.0, 10.0)), (4, (0.5, 0.1, 2.0)), (5, (0.0, 0.0, 0.0))):
+        a = random_problem(seed, 400, 30, 4, 1, 9)
+        w0, w, v = a["w0"], a["w"], a["v"]
+
+        def objective(w0, w, v):
+            e = oracle.predict(w0, w, v, a["row_ptr"], a["col"], a["val"]) - a["y"]
+            return float((e * e).sum() + regs[0] * w0 * w0 + regs[1] * (w[:-1] ** 2).sum() + regs[2] * (v[:, :-1] ** 2).sum())
+
+        j = objective(w0, w, v)
+        for _ in range(4):
+            w0, w, v = oracle.als_epoch(w0, w, v, regs[0], regs[1], regs[2], a["row_ptr"], a["col"], a["val"], a["y"])
+            jn = objective(w0, w, v)
+            assert jn <= j * (1 + 1e-12) + 1e-12, (seed, j, jn)
+            j = jn
+        assert j < objective(a["w0"], a["w"], a["v"])          # and it does learn
