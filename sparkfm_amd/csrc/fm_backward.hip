@@ -508,7 +508,12 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
 #ifndef FMHIP_EXP_NO_XE_BCAST
 #define FMHIP_EXP_NO_XE_BCAST 0   // timing-only ablation: the value / residual broadcasts of the pipelined walk dropped (results wrong)
 #endif
-#define FMHIP_BWD_ABLATIONS ((FMHIP_EXP_FIX_SKIP ? 64 : 0) | (FMHIP_EXP_NO_XE_BCAST ? 128 : 0))
+#ifndef FMHIP_EXP_NO_E
+#define FMHIP_EXP_NO_E 0          // timing-only ablation: 1 = the residual gather of the pipelined walk dropped (G_w / G_b wrong);
+                                  // 2 = the residual read at the entry's STREAM position instead of its row (coalesced: the cost of
+                                  // the loads without the gather) — what an LDS-staged or stream-resident e could save at most
+#endif
+#define FMHIP_BWD_ABLATIONS ((FMHIP_EXP_FIX_SKIP ? 64 : 0) | (FMHIP_EXP_NO_XE_BCAST ? 128 : 0) | (FMHIP_EXP_NO_E ? 256 : 0))
 #if FMHIP_BWD_ABLATIONS && !defined(FMHIP_ABLATION_BUILD)
 #error "a result-changing FMHIP_EXP_* ablation is set without FMHIP_ABLATION_BUILD: timing-only variants are built by tools/build_variant.sh"
 #endif
@@ -546,7 +551,7 @@ __global__ __launch_bounds__(kBlock, (HOT && J == 1 ? FMHIP_BWD_WAVES : 1)) void
         for (int g = 0; g < SG; ++g) {
             const int p = sbase + g * LPN + l;
             ee[g] = 0.f;
-            if (!PACKED && p < w.stop) ee[g] = a.e[rf[g] & 0x7fffffffu];
+            if (!PACKED && p < w.stop && FMHIP_EXP_NO_E != 1) ee[g] = a.e[FMHIP_EXP_NO_E == 2 ? (uint32_t)(p & 0xffff) : (rf[g] & 0x7fffffffu)];
         }
         float4 pv[2][CHB][J];
         uint32_t rj[2][CHB];
