@@ -536,8 +536,13 @@ int plan_touched(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, int64_t cap
 int dp_step_touched(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, double eta, double reg0, double regw, double regv,
                     int64_t position) {
     const bool live = batch >= 0;
-    if (c->tsteps.empty() || !c->cg || c->msg_kp != m->Kp)
-        return fail(FMHIP_ERR_INVALID, "the touched-rows exchange is not planned for this model: call fmhip_dp_plan (every rank)");
+    // (no plan at all is a state every rank shares — the plan is collective — so this returns on all of them alike; a model
+    // of another width than the plan's can only be THIS rank's mistake: local_checks turns it into a zero contribution,
+    // sized by the plan's width, whose update is skipped)
+    if (c->tsteps.empty() || !c->cg)
+        return fail(FMHIP_ERR_INVALID, "the touched-rows exchange is not planned: call fmhip_dp_plan (every rank)");
+    const bool foreign = c->msg_kp != m->Kp;
+    if (foreign && live) return fail(FMHIP_ERR_INVALID, "the touched-rows exchange was planned for rows of %d floats, this model has %d", c->msg_kp, m->Kp);
     if (!lazy_decay_ok(m, eta, regw, regv))
         return fail(FMHIP_ERR_UNSUPPORTED, "the touched-rows exchange needs weight decay that fits the tables' scale (0.5 <= 1 - eta*reg <= 1)");
     const bool packed_dirty = m->grad_dirty;      // this step neither writes nor cleans the model's packed gradient
@@ -545,7 +550,7 @@ int dp_step_touched(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_com
     if (t >= (int64_t)c->tsteps.size())
         return fail(FMHIP_ERR_INVALID, "position %lld outside the planned schedule of %zu steps", (long long)t, c->tsteps.size());
     const auto &ts = c->tsteps[(size_t)t];
-    const CompactLayout L(ts.n_u, m->Kp);
+    const CompactLayout L(ts.n_u, c->msg_kp);
     const GradView view{c->cg, c->cg + L.gw, c->cg + L.gb, c->cg + L.gv, ts.cdst, ts.hot_pos};
     const float my_rows = live ? (float)d->batches[(size_t)batch].rows : 0.f;
     hipLaunchKernelGGL(k_set_float, dim3(1), dim3(1), 0, m->stream, c->rows_dev, my_rows);
@@ -612,7 +617,7 @@ int dp_step_touched(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_com
             TRY(reduce_regions(m, c, whole, 1, c->ev_ready[i], c->ev_done[i], pr));
         } else {
             // the interval's G_V rows, G_w and G_b entries; the lowest interval's G_w region starts at the scalars in front of it
-            const Region reg[3] = {{view.GV + plo * m->Kp, (phi - plo) * m->Kp},
+            const Region reg[3] = {{view.GV + plo * (size_t)c->msg_kp, (phi - plo) * (size_t)c->msg_kp},
                                    {last ? c->cg : view.Gw + plo, (phi - plo) + (last ? (size_t)kGradHead : 0)},
                                    {view.Gb + plo, phi - plo}};
             TRY(reduce_regions(m, c, reg, 3, c->ev_ready[i], c->ev_done[i], pr));
@@ -626,6 +631,12 @@ int dp_step_touched(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_com
         if (pend_hi < 0) pend_hi = phi;
         const bool last = i == 0;
         if (!serial) HIP_TRY(hipStreamWaitEvent(m->stream, c->ev_done[i], 0));
+        if (foreign) {
+            // this rank only kept the peers' collectives company: the compact buffer must be clean for the next step, its
+            // rows mean nothing to a model of another width
+            if (last) HIP_TRY(hipMemsetAsync(c->cg, 0, L.total * sizeof(float), m->stream));
+            continue;
+        }
         if (!last && (pend_hi - plo) * 8 < ts.n_u) continue;      // small slices share the next one's launch
         if (last)       // the step's global sums where fmhip_step_stats / fmhip_dp_epoch read them
             HIP_TRY(hipMemcpyAsync(m->scal(), c->cg, (size_t)kScalars * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
@@ -798,7 +809,9 @@ int dp_step_sharded(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_com
 // collective: the caller runs the step with a zero contribution (as a rank that has run out of rows does) and
 // reports the error afterwards.
 int local_checks(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, bool in_schedule = true) {
-    (void)m;
+    if (c->exchange == FMHIP_EXCHANGE_TOUCHED && !c->tsteps.empty() && c->msg_kp != m->Kp)
+        return fail(FMHIP_ERR_INVALID, "the touched-rows exchange was planned for rows of %d floats, this model has %d: call fmhip_dp_plan "
+                                       "with this model (every rank)", c->msg_kp, m->Kp);
     if (batch < 0) return FMHIP_OK;
     const auto &bm = d->batches[(size_t)batch];
     if (c->exchange != FMHIP_EXCHANGE_TOUCHED && d->rb_rows != 0 && !c->cuts.empty())

@@ -226,3 +226,50 @@ def test_bench_with_eight_thread_ranks():
     assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["cores"] >= 1 and out["cpu_baseline"]["kind"] == "port"
     assert out["train"]["nonfinite"] == 0 and out["sustained"]["steps"] > 0
     assert wall < 600, wall
+
+
+def test_a_rank_that_brings_the_wrong_model_keeps_the_step_alive():
+    """A failure only ONE rank can see must not leave its peers inside a collective: in the touched-rows mode a rank
+    that calls the step with a model of another width than the plan's contributes zeros — sized by the PLAN's width, its own
+    update skipped — and gets the error afterwards; the other rank's step completes and equals the oracle over its rows alone."""
+    import ctypes as C
+    import dp_cases
+    from sparkfm_amd import DataSet, FMModel, _ffi
+    from sparkfm_amd.distributed import HipDataParallelSGD, ThreadStagedComm, run_thread_ranks
+    L = _ffi.load()
+    cfg = case8(rows=[900, 700], exchange="touched", n1=2003, batch_rows=900, epochs=1)
+    w0, w, v = dp_cases.init(cfg)
+
+    def body(r, g):
+        ds = DataSet.from_arrays(dp_cases.shard(cfg, r), batch_rows=900, device=0).cache()
+        fm = FMModel(cfg["n1"] - 1, 32, device=0)
+        fm.w0, fm.w, fm.v = w0, w, v
+        comm = ThreadStagedComm(fm, r, g)
+        dp = HipDataParallelSGD(comm, eta=0.05, regw=1e-3, regv=1e-3, exchange="touched", upper_fractions=(0.3,))
+        dp.plan(fm, ds)
+        if r == 1:
+            other = FMModel(cfg["n1"] - 1, 64, device=0)         # rows of 64 floats: not what the plan was made for
+            rc = L.fmhip_dp_step_at(other.handle, ds.handle, 0, comm.handle, 0.05, 0.0, 1e-3, 1e-3)
+            msg = L.fmhip_last_error().decode()
+            other.close(discard=True)
+            out = (rc, msg)
+        else:
+            dp.step_at(fm, ds, 0)
+            out = (fm.w0, fm.w.copy(), fm.v.copy())
+        g.barrier()
+        # ... and the communicator is still usable: a regular step of both ranks afterwards
+        dp.step_at(fm, ds, 0)
+        res = (out, fm.v.copy())
+        g.barrier()
+        comm.close()
+        ds.unpersist()
+        fm.close(discard=True)
+        return res
+
+    (r0, v0_after), (r1, v1_after) = run_thread_ranks(2, body, timeout=120.0)
+    assert r1[0] == _ffi.load().fmhip_version() * 0 - 1 and "planned for rows of 32 floats" in r1[1] and "contributed zeros" in r1[1]
+    d0 = dp_cases.shard(cfg, 0)
+    o0, ow, ov, _ = oracle.sgd_step(w0, w, v, 0, 900, d0["row_ptr"], d0["col"], d0["val"].astype(np.float64), d0["y"].astype(np.float64),
+                                    0.05, 0.0, 1e-3, 1e-3)
+    assert np.linalg.norm(r0[2] - ov) <= 1e-5 * np.linalg.norm(ov) and np.linalg.norm(r0[1] - ow) <= 1e-5 * np.linalg.norm(ow)
+    assert np.isfinite(v0_after).all() and np.isfinite(v1_after).all()
