@@ -419,6 +419,7 @@ struct RangeWalk {
                 if (jj == kj) pk = f4pick(pv[jj], kc);
             sb = fmaf(__fmul_rn(pk, xj), xj, sb);
         } else {
+            if (kEInP) ej = e_from_row(pv[0], l);      // the residual rides in the row just gathered (fm_device.h): no e gather
             accum_scalars(sa, sb, ej, xj);
         }
     }
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
         if (p < w.stop) {
             rf = stream_load(a.crow + p);
             x = stream_load(a.cval + p);
-            if (!PACKED) ee = a.e[rf & 0x7fffffffu];
+            if (!PACKED && !kEInP) ee = a.e[rf & 0x7fffffffu];
         }
         const int cnt = (w.stop - base) < LPN ? (w.stop - base) : LPN;
 #pragma unroll
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 const float xj = slot_bcast<LPN>(x, c0 + j);
-                const float ej = PACKED ? 0.f : slot_bcast<LPN>(ee, c0 + j);
+                const float ej = (PACKED || kEInP) ? 0.f : slot_bcast<LPN>(ee, c0 + j);
                 if (c0 + j < cnt) w.entry(a, base + c0 + j, rj[j], pv[j], xj, ej);
             }
         }
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(kBlock, (HOT && J == 1 ? FMHIP_BWD_WAVES : 1)) void
         for (int g = 0; g < SG; ++g) {
             const int p = sbase + g * LPN + l;
             ee[g] = 0.f;
-            if (!PACKED && p < w.stop && FMHIP_EXP_NO_E != 1) ee[g] = a.e[FMHIP_EXP_NO_E == 2 ? (uint32_t)(p & 0xffff) : (rf[g] & 0x7fffffffu)];
+            if (!PACKED && !kEInP && p < w.stop && FMHIP_EXP_NO_E != 1) ee[g] = a.e[FMHIP_EXP_NO_E == 2 ? (uint32_t)(p & 0xffff) : (rf[g] & 0x7fffffffu)];
         }
         float4 pv[2][CHB][J];
         uint32_t rj[2][CHB];
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(kBlock, (HOT && J == 1 ? FMHIP_BWD_WAVES : 1)) void
                 for (int j = 0; j < CHB; ++j) {
                     const int ent = ch * CHB + j;
                     const int g = ent / LPN, jl = ent % LPN;
-                    w.add(pv[buf][j], FMHIP_EXP_NO_XE_BCAST ? x[g] : slot_bcast<LPN>(x[g], jl), PACKED ? 0.f : (FMHIP_EXP_NO_XE_BCAST ? ee[g] : slot_bcast<LPN>(ee[g], jl)));
+                    w.add(pv[buf][j], FMHIP_EXP_NO_XE_BCAST ? x[g] : slot_bcast<LPN>(x[g], jl), (PACKED || kEInP) ? 0.f : (FMHIP_EXP_NO_XE_BCAST ? ee[g] : slot_bcast<LPN>(ee[g], jl)));
                 }
                 continue;
             }
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(kBlock, (HOT && J == 1 ? FMHIP_BWD_WAVES : 1)) void
                 const int ent = ch * CHB + j;
                 const int g = ent / LPN, jl = ent % LPN;
                 const float xj = FMHIP_EXP_NO_XE_BCAST ? x[g] : slot_bcast<LPN>(x[g], jl);
-                const float ej = PACKED ? 0.f : (FMHIP_EXP_NO_XE_BCAST ? ee[g] : slot_bcast<LPN>(ee[g], jl));
+                const float ej = (PACKED || kEInP) ? 0.f : (FMHIP_EXP_NO_XE_BCAST ? ee[g] : slot_bcast<LPN>(ee[g], jl));
                 if (sbase + ent < w.stop) w.entry(a, sbase + ent, rj[buf][j], pv[buf][j], xj, ej);
             }
         }

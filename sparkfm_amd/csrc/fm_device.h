@@ -100,6 +100,54 @@ __device__ __forceinline__ void p_store(float4 *dst, float4 v) {
 #endif
 }
 
+// ---- the residual rides in the P row (k == Kp: no spare slot) -------------------------------------------------
+// The backward needs e_r for every entry it walks (G_w += e x, G_b += e x^2).  When a P row has a spare slot (k < Kp) e sits
+// there; when it has none (k = 32, 64, 128, 256) the walk used to gather e[row] beside the row — a 64-lane instruction touching
+// up to 64 lines of an L2-resident table: 17-18 us of the 143-us walk at C3 (profiles/r04_experiments.md section 11).  Instead
+// the forward now writes the 32 bits of e into the mantissa LSBs of the row's first 32 floats (lane l < 8 of the slot holds
+// floats 4l .. 4l+3 and carries bits 4l .. 4l+3), and the walk reads them back from the row it has gathered anyway: three
+// DPP moves and a dozen bit operations per entry on a vector ALU that idles 88 % of the time, no memory request at all.
+// e itself is exact; a P element moves by at most one unit in its last place (1.2e-7 relative), deterministically.
+#ifndef FMHIP_E_IN_P
+#define FMHIP_E_IN_P 1      // 0 = the separate gather (A/B builds); forward and backward must agree
+#endif
+constexpr bool kEInP = FMHIP_E_IN_P != 0;
+#ifndef FMHIP_E_BITS
+#define FMHIP_E_BITS 2      // bits of e per carrying float: 1 = all four floats of a lane, one bit each (<= 1 ulp on 32 floats);
+                            // 2 = two floats, two bits each; 4 = one float, four bits (fewer bit operations per entry, a larger nudge)
+#endif
+__device__ __forceinline__ float4 embed_bits4(float4 v, uint32_t bits) {
+    if (FMHIP_E_BITS == 4) {
+        v.x = __uint_as_float((__float_as_uint(v.x) & ~15u) | (bits & 15u));
+    } else if (FMHIP_E_BITS == 2) {
+        v.x = __uint_as_float((__float_as_uint(v.x) & ~3u) | (bits & 3u));
+        v.y = __uint_as_float((__float_as_uint(v.y) & ~3u) | ((bits >> 2) & 3u));
+    } else {
+        v.x = __uint_as_float((__float_as_uint(v.x) & ~1u) | (bits & 1u));
+        v.y = __uint_as_float((__float_as_uint(v.y) & ~1u) | ((bits >> 1) & 1u));
+        v.z = __uint_as_float((__float_as_uint(v.z) & ~1u) | ((bits >> 2) & 1u));
+        v.w = __uint_as_float((__float_as_uint(v.w) & ~1u) | ((bits >> 3) & 1u));
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t extract_bits4(float4 v) {
+    if (FMHIP_E_BITS == 4) return __float_as_uint(v.x) & 15u;
+    if (FMHIP_E_BITS == 2) return (__float_as_uint(v.x) & 3u) | ((__float_as_uint(v.y) & 3u) << 2);
+    return (__float_as_uint(v.x) & 1u) | ((__float_as_uint(v.y) & 1u) << 1) | ((__float_as_uint(v.z) & 1u) << 2) |
+           ((__float_as_uint(v.w) & 1u) << 3);
+}
+// OR over each aligned group of 8 lanes (quad butterfly, then the mirror of the half row), valid in all 8
+__device__ __forceinline__ uint32_t or8(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);     // quad_perm:[1,0,3,2]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);     // quad_perm:[2,3,0,1]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);    // row_half_mirror
+    return v;
+}
+// the residual of the row whose first float4 (per lane of the slot) is `first`; l = the lane's index in its slot
+__device__ __forceinline__ float e_from_row(float4 first, int l) {
+    return __uint_as_float(or8(l < 8 ? extract_bits4(first) << (4 * l) : 0u));
+}
+
 template <int G>
 __device__ __forceinline__ float quad_bcast(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), G * 0x55, 0xf, 0xf, false));   // quad_perm:[G,G,G,G]

@@ -312,6 +312,7 @@ __device__ __forceinline__ void row_finish(const FwdArgs &a, int r, int l, float
         for (int jj = 0; jj < J; ++jj) {
             float4 o = f4mul(q[jj], es);
             if (PACKED && jj == kj && l == kl) f4set(o, kc, e);   // slot k of the P row carries e
+            if (!PACKED && kEInP && jj == 0 && l < 8) o = embed_bits4(o, __float_as_uint(e) >> (4 * l));   // no spare slot: e rides in the LSBs (fm_device.h)
             p_store(pr + jj * LPN, o);
         }
     } else if (MODE == kFwdQ) {

@@ -1232,3 +1232,38 @@ def test_two_ranks_on_one_gpu(fmhip, tmp_path, overlap, k):
     assert np.linalg.norm(r0["v"] - v) <= 1e-5 * np.linalg.norm(v)
     assert np.linalg.norm(r0["w"] - w) <= 1e-5 * np.linalg.norm(w)
     assert float(r0["w0"]) == pytest.approx(w0, rel=1e-5, abs=1e-7)
+
+
+@pytest.mark.parametrize("k,flat", [(32, 0), (32, 1), (64, 0), (128, 0), (256, 0)])
+def test_the_residual_rides_in_the_p_row_exactly(fmhip, k, flat):
+    """k == Kp leaves a P row no spare slot, so the forward writes the 32 bits of e into the low mantissa bits of the row's first
+    floats and the backward reads them back from the row it gathers anyway (fm_device.h: no e gather).  e must arrive EXACTLY:
+    every row gets a feature of its own with x = 1, whose G_w = sum e x is then that row's residual bit for bit — compared with
+    the residuals the scoring pass returns, over values of every sign and magnitude (labels from 1e-30 to 1e+30, zero, negative)."""
+    from sparkfm_amd import _ffi
+    L = _ffi.load()
+    rng = np.random.default_rng(k)
+    n_rows, n_shared = 3000, 40
+    n1 = n_shared + n_rows
+    rows_c, rows_v = [], []
+    for r in range(n_rows):
+        sh = rng.choice(n_shared, size=int(rng.integers(1, 6)), replace=False)
+        rows_c.append(np.concatenate([sh, [n_shared + r]]))
+        rows_v.append(np.concatenate([rng.uniform(0.1, 1.0, len(sh)), [1.0]]))
+    row_ptr = np.concatenate([[0], np.cumsum([len(c) for c in rows_c])]).astype(np.int64)
+    col = np.concatenate(rows_c).astype(np.int32)
+    val = np.concatenate(rows_v)
+    y = rng.normal(0, 1, n_rows) * 10.0 ** rng.integers(-30, 31, n_rows)
+    y[:8] = [0.0, -0.0, 1e-38, -1e-38, 3e38, -3e38, 1.0, -1.0]
+    a = dict(k=k, n1=n1, w0=0.01, w=rng.normal(0, 0.05, n1), v=rng.normal(0, 0.05, (k, n1)), row_ptr=row_ptr, col=col, val=val, y=y)
+    L.fmhip_tune(8, flat)
+    try:
+        ds, fm = make(fmhip, a, batch_rows=0)
+        e = fm.residual(ds).astype(np.float32)
+        _, gw, _, _ = fm.batchGradient(ds, 0)
+    finally:
+        L.fmhip_tune(8, 0)
+    got = gw[n_shared:].astype(np.float32)
+    assert np.array_equal(got.view(np.uint32), e.view(np.uint32)), int((got.view(np.uint32) != e.view(np.uint32)).sum())
+    ds.unpersist()
+    fm.close()
