@@ -384,10 +384,17 @@ def roofline_block(kern, dom, ab, pd, pmc, step_ms, live):
     if traffic is None:           # no profile of this configuration anywhere: our own count of the kernel's loads and stores
         traffic, basis = e.get("requested_bytes_per_launch"), "requested bytes (no counter pass exists for this configuration)"
     achieved = traffic / (avg_ms * 1e-3) / 1e9 if traffic and avg_ms else None
+    requested_only = None
+    if basis != "counters":
+        # our own count of the kernel's loads and stores is what it ASKS of the memory system, caches included — not an HBM-side
+        # figure and no roofline: reported beside the (empty) roofline, never as its `achieved`
+        requested_only = {"requested_bytes": traffic, "requested_GBps": achieved, "note": "no counter pass exists for this configuration: no HBM-side figure is claimed"}
+        achieved = None
     step_traffic = pmc.get("step", {}).get("traffic_bytes")
     alg = e.get("alg_GBps")
     return {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": achieved * 1e9 / HBM_PEAK if achieved else None, "traffic": traffic, "basis": basis,
+            "frac": achieved * 1e9 / HBM_PEAK if achieved else None, "traffic": traffic if basis == "counters" else None, "basis": basis,
+            "requested_only": requested_only,
             "traffic_source": e.get("traffic_source"), "traffic_measured_in_this_run": bool(live),
             "avg_launch_ms": avg_ms, "nnz_per_launch": pd[dom]["nnz"] / max(pd[dom].get("steps") or pd[dom]["launches"], 1),
             "launches_per_step": e.get("launches_per_step", 1),
