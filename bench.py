@@ -49,7 +49,7 @@ MALL_BYTES = 256 << 20
 def alg_bytes(k):
     """SURVEY.md §8(d) algorithmic bytes per stored nonzero, split by kernel (fp32/int32):
     forward  = col 4 + val 4 + V-row read 4k + w read 4      = 4k + 12
-    backward = V-grad row add 4k + w-grad add 4               = 4k + 4
+    backward = V-grad row add 4k + w-grad add 4               = 4k + 4   (SURVEY's figure; the walk itself reads 8 + 4k per entry)
     whole step B_alg(k) = 8k + 16 (plus 16 B/row and 12(n+1)(k+1) B/step for the dense update)."""
     return {"forward": 4 * k + 12, "backward": 4 * k + 4, "step": 8 * k + 16}
 
@@ -64,7 +64,8 @@ def requested_bytes(kp, rows, nnz, nnz_sparse, n_cols, hot, touched_rows, dense_
     if nnz_sparse_bwd is None:
         nnz_sparse_bwd = nnz_sparse
     fwd = nnz_sparse * (8 + row + (0 if packed else 4)) + rows * (8 + 4 + row + 4) + hot_b
-    bwd = nnz_sparse_bwd * (8 + row + (0 if packed else 4)) + n_cols * (row + 8) + (rows * row + hot_b * max(hot_pages, 1) if hot else 0)
+    # (no separate residual read: with a spare slot e sits in the P row, without one it rides in the row's low mantissa bits)
+    bwd = nnz_sparse_bwd * (8 + row) + n_cols * (row + 8) + (rows * row + hot_b * max(hot_pages, 1) if hot else 0)
     apply_rows = n1p if dense_apply else touched_rows
     app = apply_rows * (3 * row + 16)          # V read+write, G read (+ zero store counted with the write)
     return {"forward": fwd, "backward": bwd, "apply": app}

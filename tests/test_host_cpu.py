@@ -355,7 +355,7 @@ def test_bench_roofline_helpers():
     base = bench.requested_bytes(32, 250_000, 10_000_000, 8_000_000, 90_000, True, 90_000, True, 100_001, False)
     paged = bench.requested_bytes(32, 250_000, 10_000_000, 8_000_000, 90_000, True, 90_000, True, 100_001, False, 6_600_000, 4)
     assert paged["forward"] == base["forward"] and paged["apply"] == base["apply"]
-    assert base["backward"] - paged["backward"] == 1_400_000 * (8 + 128 + 4) - 3 * 64 * 250_000
+    assert base["backward"] - paged["backward"] == 1_400_000 * (8 + 128) - 3 * 64 * 250_000
     pmc = bench.committed_pmc("C5", 64, 250_000)
     assert {"k_forward", "k_backward", "step"} <= set(pmc) and 0 < pmc["k_forward"]["l2_hit"] < 1
     assert bench.alg_bytes(32) == {"forward": 140, "backward": 132, "step": 272}
