@@ -148,6 +148,24 @@ __device__ __forceinline__ float e_from_row(float4 first, int l) {
     return __uint_as_float(or8(l < 8 ? extract_bits4(first) << (4 * l) : 0u));
 }
 
+// ---- ... and the linear weight rides in the V row the same way (k == Kp) ---------------------------------------
+// The forward needs w_i for every entry it walks.  With a spare slot (k < Kp) w_i sits in slot k of row i; without one the
+// forward looked it up beside the row — an LDS tile for the 6,144 hottest ids, a 4-byte gather from the table for the rest:
+// 12 us of the 107-us forward at C3 — and now reads it out of the row it has gathered anyway (same carrying floats and bit
+// positions as the residual in a P row; the extraction costs the forward 6.5 us of vector ALU: net -5.6 us, measured by a
+// timing-only build first, profiles/r04_experiments.md section 15).  The w TABLE stays authoritative (updates, get_params, the hot
+// block's staging and every kernel variant that still looks w up read it); EVERY WRITER OF A V ROW re-embeds the row's
+// current stored w (embed_w below: the update kernels through apply_piece, the merged finish, the fused update, the rescale,
+// the device-side init, the upload) — a V element that carries bits moves by <= 3.6e-7 relative when it is written.
+#ifndef FMHIP_W_IN_V
+#define FMHIP_W_IN_V 1      // 0 = V rows carry no weight bits, the forward looks w up (A/B builds; all translation units alike)
+#endif
+constexpr bool kWInV = FMHIP_W_IN_V != 0;
+// float4 piece c (of LPR per row) of a V row about to be stored: pieces 0..7 carry bits 4c..4c+3 of the row's stored w
+__device__ __forceinline__ float4 embed_w(float4 u, int c, float w_stored) {
+    return c < 8 ? embed_bits4(u, __float_as_uint(w_stored) >> (4 * c)) : u;
+}
+
 template <int G>
 __device__ __forceinline__ float quad_bcast(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), G * 0x55, 0xf, 0xf, false));   // quad_perm:[G,G,G,G]
@@ -227,12 +245,20 @@ __device__ __forceinline__ void apply_piece(const ApplyArgs &a, int64_t i, int c
         u.w = v.w - a.eta * fmaf(a.regv, v.w, (g.w - v.w * b) * invb);
     }
     if (has_w) f4set(u, a.pack_k & 3, wslot);
+    // the linear weight's new stored value: formed by every lane that needs it (piece 0 stores it to the table; pieces 0..7
+    // of an unpacked row carry its bits — the lanes of a row share a wave, so these loads precede piece 0's stores below)
+    float w_new = 0.f;
+    const bool carries = kWInV && a.pack_k < 0 && c < 8;
+    if (c == 0 || carries) {
+        const float us = a.w[i], gi = a.Gw[gr] * invb;
+        const float wi = us * a.sw_in;
+        w_new = ROWS ? us - a.eta_w * gi : wi - a.eta * fmaf(a.regw, wi, gi);
+    }
+    if (carries) u = embed_w(u, c, w_new);
     *V4 = u;
     *G4 = f4zero();
     if (c == 0) {
-        const float us = a.w[i], gi = a.Gw[gr] * invb;
-        const float wi = us * a.sw_in;
-        a.w[i] = ROWS ? us - a.eta_w * gi : wi - a.eta * fmaf(a.regw, wi, gi);
+        a.w[i] = w_new;
         a.Gw[gr] = 0.f;
         a.Gb[gr] = 0.f;  // same wave already holds its copy of b (all lanes of a row share a wave)
     }
