@@ -63,9 +63,8 @@ def requested_bytes(kp, rows, nnz, nnz_sparse, n_cols, hot, touched_rows, dense_
     hot_b = 64 * rows if hot else 0
     if nnz_sparse_bwd is None:
         nnz_sparse_bwd = nnz_sparse
-    fwd = nnz_sparse * (8 + row) + rows * (8 + 4 + row + 4) + hot_b
-    # (no separate linear-weight or residual read: with a spare slot w sits in the V row and e in the P row, without one they
-    # ride in the rows' low mantissa bits)
+    fwd = nnz_sparse * (8 + row + (0 if packed else 4)) + rows * (8 + 4 + row + 4) + hot_b
+    # (no separate residual read: with a spare slot e sits in the P row, without one it rides in the row's low mantissa bits)
     bwd = nnz_sparse_bwd * (8 + row) + n_cols * (row + 8) + (rows * row + hot_b * max(hot_pages, 1) if hot else 0)
     apply_rows = n1p if dense_apply else touched_rows
     app = apply_rows * (3 * row + 16)          # V read+write, G read (+ zero store counted with the write)

@@ -173,12 +173,6 @@ int fmhip_model_info(fmhip_model_t m, int64_t *num_attribute, int32_t *num_facto
  * (S/fm/FMModel.scala:17-22; its draw is unseeded — quirk Q2 — here `seed` makes it reproducible: element
  * (f, i) depends only on (seed, f, i)).  For models too wide to stage on the host (2^25 x 64: 17 GB fp64). */
 int fmhip_model_init_normal(fmhip_model_t m, uint64_t seed, double mean, double stdev);
-/* Self-check of the device layout (tests, soaks, a host that wants an assertion after a restore): a factor row without a spare
- * slot (num_factor = 32, 64, 128, 256) carries its feature's linear weight in the low mantissa bits of sixteen of its factors
- * (DESIGN.md section 3), which every kernel that writes a row keeps equal to the weight table, bit for bit.  Counts the rows
- * where the two differ (0 = consistent; always 0 for a padded model, whose spare slot IS the weight).  Synchronises the
- * model's stream. */
-int fmhip_model_verify(fmhip_model_t m, int64_t *mismatched_rows);
 /* w: n+1 doubles, v: k*(n+1) doubles at v[f + i*k]  (FMModel.w0 / .w / .v, S/fm/FMModel.scala:17-19) */
 int fmhip_model_set_params(fmhip_model_t m, double w0, const double *w, const double *v);
 int fmhip_model_get_params(fmhip_model_t m, double *w0, double *w, double *v);

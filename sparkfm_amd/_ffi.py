@@ -26,7 +26,7 @@ SYMBOLS = (
     "fmhip_grad_floats", "fmhip_grad_bind", "fmhip_grad_ptr", "fmhip_grad_layout", "fmhip_step_compute",
     "fmhip_step_forward", "fmhip_step_backward", "fmhip_step_apply",
     "fmhip_step_stats", "fmhip_profile_begin", "fmhip_profile_begin_rotating", "fmhip_profile_begin_sampled", "fmhip_profile_end",
-    "fmhip_rows_create", "fmhip_rows_create_f32", "fmhip_predict_rows", "fmhip_model_init_normal", "fmhip_dataset_layout", "fmhip_dataset_create_opts", "fmhip_model_get_rows", "fmhip_model_verify",
+    "fmhip_rows_create", "fmhip_rows_create_f32", "fmhip_predict_rows", "fmhip_model_init_normal", "fmhip_dataset_layout", "fmhip_dataset_create_opts", "fmhip_model_get_rows",
     "fmhip_comm_unique_id", "fmhip_comm_create", "fmhip_comm_destroy", "fmhip_comm_info", "fmhip_dp_plan",
     "fmhip_dp_step", "fmhip_dp_epoch", "fmhip_comm_profile_begin", "fmhip_comm_profile_end", "fmhip_shard_rows", "fmhip_comm_emulate",
     "fmhip_feature_counts", "fmhip_rank_from_counts", "fmhip_relabel_columns", "fmhip_dataset_hot_pages",
@@ -143,7 +143,6 @@ def load():
     L.fmhip_dataset_create_opts.argtypes = [C.c_int, i64, vp, vp, vp, vp, P(DatasetOpts), P(vp)]
     L.fmhip_dataset_layout.argtypes = [vp, P(i32), vp, P(i64)]
     L.fmhip_model_get_rows.argtypes = [vp, i64, vp, vp, vp]
-    L.fmhip_model_verify.argtypes = [vp, vp]
     L.fmhip_model_init_normal.argtypes = [vp, C.c_uint64, dbl, dbl]
     L.fmhip_rows_create.argtypes = [C.c_int, i64, vp, vp, vp, vp, P(vp)]
     L.fmhip_rows_create_f32.argtypes = [C.c_int, i64, vp, vp, vp, vp, P(vp)]

@@ -85,8 +85,6 @@ __global__ __launch_bounds__(kBlock) void k_init_normal(float *V, float *w, floa
             const float u1 = ((float)(uint32_t)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);         // (0, 1)
             const float u2 = ((float)(uint32_t)((h >> 8) & 0xffffffu)) * (1.0f / 16777216.0f);   // [0, 1)
             v = mean + stdev * sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530718f * u2);
-            // an unpacked row carries its linear weight's bits in the two low bits of floats 4c, 4c+1 (c < 8): w = 0 here
-            if (kWInV && k == kp && f < 32 && (f & 3) < 2) v = __uint_as_float(__float_as_uint(v) & ~3u);
         }
         V[idx] = v;
         if (f == 0) w[i] = 0.f;
@@ -107,27 +105,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_rows(const float *V, const fl
     }
 }
 
-// The bits an unpacked V row carries (fm_device.h) must spell the linear-weight table's entry exactly — counted over the whole
-// model, for fmhip_model_verify.  (A packed row's slot k IS the weight: the table is not kept for such a model.)
-__global__ __launch_bounds__(kBlock) void k_verify_rows(const float *V, const float *w, int64_t n1, int32_t kp, unsigned long long *bad) {
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n1; i += (int64_t)gridDim.x * kBlock) {
-        const float *row = V + i * kp;
-        uint32_t carried = 0;
-        for (int c = 0; c < 8; ++c)
-            for (int h = 0; h < 2; ++h) carried |= (__float_as_uint(row[4 * c + h]) & 3u) << (4 * c + 2 * h);
-        if (carried != __float_as_uint(w[i])) atomicAdd(bad, 1ull);
-    }
-}
-
 }  // namespace
-
-hipError_t launch_verify_rows(int Kp, const float *V, const float *w, int64_t n1, unsigned long long *bad, hipStream_t s) {
-    int64_t blocks = (n1 + kBlock - 1) / kBlock;
-    if (blocks > 8192) blocks = 8192;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_verify_rows, dim3((unsigned)blocks), dim3(kBlock), 0, s, V, w, n1, Kp, bad);
-    return hipGetLastError();
-}
 
 hipError_t launch_gather_rows(int Kp, const float *V, const float *w, const int32_t *ids, int64_t n, float *out_v, float *out_w,
                               hipStream_t s) {

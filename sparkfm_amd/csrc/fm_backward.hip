@@ -20,9 +20,7 @@ __device__ __forceinline__ void store_row(float *dst, int l, const float4 (&acc)
 
 // Fused update of parameter row i from its finished gradient (acc = G_V row, sa = G_w, sb = G_b; the scalars are
 // valid in lane sl of the slot): U_i <- U_i - eta_v*((G_V - (sv*U_i)*G_b)/|B|), w_i likewise — apply_piece<KP, true>
-// of fm_apply.hip, operation for operation.  pack_k >= 0: slot pack_k of the row is the linear weight.  (Unpacked rows carry
-// their weight's bits, fm_device.h, and this path does not re-embed them — ten more registers in the walk cost it 5 us whether
-// the path is taken or not — so plan_fused never chooses the in-walk update for an unpacked model.)
+// of fm_apply.hip, operation for operation.  pack_k >= 0: slot pack_k of the row is the linear weight.
 template <int LPN, int J>
 __device__ __forceinline__ void apply_row(const FusedUpd &u, int pack_k, int i, int l, const float4 (&acc)[J], float sa, float sb, int sl) {
     constexpr int KP = 4 * LPN * J;
@@ -70,10 +68,6 @@ __device__ __forceinline__ void finish_row(const ApplyArgs &f, int i, int l, con
         u.z = v.z - f.eta * fmaf(f.regv, v.z, (g.z - v.z * b) * invb);
         u.w = v.w - f.eta * fmaf(f.regv, v.w, (g.w - v.w * b) * invb);
         if (has_w) f4set(u, f.pack_k & 3, wslot);
-        if (kWInV && f.pack_k < 0 && jj == 0) {      // the row carries its new stored w (the same expression lane sl stores below)
-            const float wi = f.w[i] * f.sw_in;
-            u = embed_w(u, l, wi - f.eta * fmaf(f.regw, wi, gw * invb));
-        }
         V4[jj * LPN] = u;
     }
     if (l == sl) {
@@ -269,10 +263,6 @@ __device__ __forceinline__ void hot_reduce_body(const HotArgs &a, int h, int kp,
             x.z = v.z - fin.eta * fmaf(fin.regv, v.z, (u.z - v.z * b) * invb);
             x.w = v.w - fin.eta * fmaf(fin.regv, v.w, (u.w - v.w * b) * invb);
             if (has_w) f4set(x, fin.pack_k & 3, wslot);
-            if (kWInV && fin.pack_k < 0) {
-                const float wi = fin.w[id] * fin.sw_in;
-                x = embed_w(x, (int)threadIdx.x, wi - fin.eta * fmaf(fin.regw, wi, hf[0] * invb));
-            }
             *V4 = x;
             if (threadIdx.x == 0) {
                 const float wi = fin.w[id] * fin.sw_in;
@@ -308,7 +298,6 @@ __device__ __forceinline__ void hot_reduce_body(const HotArgs &a, int h, int kp,
         x.z -= f.eta_v * ((u.z - v.z * b) * f.invb);
         x.w -= f.eta_v * ((u.w - v.w * b) * f.invb);
         if (has_w) f4set(x, a.pack_k & 3, wslot);
-        if (kWInV && a.pack_k < 0) x = embed_w(x, (int)threadIdx.x, f.w[id] - f.eta_w * (hs[0] * f.invb));
         *V4 = x;
         if (threadIdx.x == 0 && a.pack_k < 0) f.w[id] = f.w[id] - f.eta_w * (hs[0] * f.invb);
     }

@@ -107,7 +107,7 @@ __device__ __forceinline__ void p_store(float4 *dst, float4 v) {
 // the forward now writes the 32 bits of e into the mantissa LSBs of the row's first 32 floats (lane l < 8 of the slot holds
 // floats 4l .. 4l+3 and carries bits 4l .. 4l+3), and the walk reads them back from the row it has gathered anyway: three
 // DPP moves and a dozen bit operations per entry on a vector ALU that idles 88 % of the time, no memory request at all.
-// e itself is exact; a P element moves by at most one unit in its last place (1.2e-7 relative), deterministically.
+// e itself is exact; a carrying P element moves to the nearest float with those low bits (carry_bits below), deterministically.
 #ifndef FMHIP_E_IN_P
 #define FMHIP_E_IN_P 1      // 0 = the separate gather (A/B builds); forward and backward must agree
 #endif
@@ -116,17 +116,35 @@ constexpr bool kEInP = FMHIP_E_IN_P != 0;
 #define FMHIP_E_BITS 2      // bits of e per carrying float: 1 = all four floats of a lane, one bit each (<= 1 ulp on 32 floats);
                             // 2 = two floats, two bits each; 4 = one float, four bits (fewer bit operations per entry, a larger nudge)
 #endif
+// x -> the NEAREST float whose N low mantissa bits are b (ties to the even multiple of 2^N): an unbiased rounding, and half as
+// far as overwriting the bits, which truncates towards a fixed residue (N = 2: <= 2 units in the last place, 2.4e-7 relative,
+// against 3).  Zero, the tiniest denormals, the last floats below infinity and non-finite values get their bits overwritten.
+#ifndef FMHIP_E_ROUND
+#define FMHIP_E_ROUND 1     // 0 = overwrite the bits (A/B builds)
+#endif
+template <int N>
+__device__ __forceinline__ float carry_bits(float x, uint32_t b) {
+    constexpr uint32_t M = (1u << N) - 1u;
+    const uint32_t u = __float_as_uint(x), m = u & 0x7fffffffu;
+    uint32_t r = (m & ~M) | b;
+    if (FMHIP_E_ROUND && m > M && m < 0x7f7ffff0u) {
+        uint32_t y = m - b;
+        y += (M >> 1) + ((y >> N) & 1u);
+        r = (y & ~M) + b;
+    }
+    return __uint_as_float((u & 0x80000000u) | r);
+}
 __device__ __forceinline__ float4 embed_bits4(float4 v, uint32_t bits) {
     if (FMHIP_E_BITS == 4) {
-        v.x = __uint_as_float((__float_as_uint(v.x) & ~15u) | (bits & 15u));
+        v.x = carry_bits<4>(v.x, bits & 15u);
     } else if (FMHIP_E_BITS == 2) {
-        v.x = __uint_as_float((__float_as_uint(v.x) & ~3u) | (bits & 3u));
-        v.y = __uint_as_float((__float_as_uint(v.y) & ~3u) | ((bits >> 2) & 3u));
+        v.x = carry_bits<2>(v.x, bits & 3u);
+        v.y = carry_bits<2>(v.y, (bits >> 2) & 3u);
     } else {
-        v.x = __uint_as_float((__float_as_uint(v.x) & ~1u) | (bits & 1u));
-        v.y = __uint_as_float((__float_as_uint(v.y) & ~1u) | ((bits >> 1) & 1u));
-        v.z = __uint_as_float((__float_as_uint(v.z) & ~1u) | ((bits >> 2) & 1u));
-        v.w = __uint_as_float((__float_as_uint(v.w) & ~1u) | ((bits >> 3) & 1u));
+        v.x = carry_bits<1>(v.x, bits & 1u);
+        v.y = carry_bits<1>(v.y, (bits >> 1) & 1u);
+        v.z = carry_bits<1>(v.z, (bits >> 2) & 1u);
+        v.w = carry_bits<1>(v.w, (bits >> 3) & 1u);
     }
     return v;
 }
@@ -146,24 +164,6 @@ __device__ __forceinline__ uint32_t or8(uint32_t v) {
 // the residual of the row whose first float4 (per lane of the slot) is `first`; l = the lane's index in its slot
 __device__ __forceinline__ float e_from_row(float4 first, int l) {
     return __uint_as_float(or8(l < 8 ? extract_bits4(first) << (4 * l) : 0u));
-}
-
-// ---- ... and the linear weight rides in the V row the same way (k == Kp) ---------------------------------------
-// The forward needs w_i for every entry it walks.  With a spare slot (k < Kp) w_i sits in slot k of row i; without one the
-// forward looked it up beside the row — an LDS tile for the 6,144 hottest ids, a 4-byte gather from the table for the rest:
-// 12 us of the 107-us forward at C3 — and now reads it out of the row it has gathered anyway (same carrying floats and bit
-// positions as the residual in a P row; the extraction costs the forward 6.5 us of vector ALU: net -5.6 us, measured by a
-// timing-only build first, profiles/r04_experiments.md section 15).  The w TABLE stays authoritative (updates, get_params, the hot
-// block's staging and every kernel variant that still looks w up read it); EVERY WRITER OF A V ROW re-embeds the row's
-// current stored w (embed_w below: the update kernels through apply_piece, the merged finish, the fused update, the rescale,
-// the device-side init, the upload) — a V element that carries bits moves by <= 3.6e-7 relative when it is written.
-#ifndef FMHIP_W_IN_V
-#define FMHIP_W_IN_V 1      // 0 = V rows carry no weight bits, the forward looks w up (A/B builds; all translation units alike)
-#endif
-constexpr bool kWInV = FMHIP_W_IN_V != 0;
-// float4 piece c (of LPR per row) of a V row about to be stored: pieces 0..7 carry bits 4c..4c+3 of the row's stored w
-__device__ __forceinline__ float4 embed_w(float4 u, int c, float w_stored) {
-    return c < 8 ? embed_bits4(u, __float_as_uint(w_stored) >> (4 * c)) : u;
 }
 
 template <int G>
@@ -245,20 +245,12 @@ __device__ __forceinline__ void apply_piece(const ApplyArgs &a, int64_t i, int c
         u.w = v.w - a.eta * fmaf(a.regv, v.w, (g.w - v.w * b) * invb);
     }
     if (has_w) f4set(u, a.pack_k & 3, wslot);
-    // the linear weight's new stored value: formed by every lane that needs it (piece 0 stores it to the table; pieces 0..7
-    // of an unpacked row carry its bits — the lanes of a row share a wave, so these loads precede piece 0's stores below)
-    float w_new = 0.f;
-    const bool carries = kWInV && a.pack_k < 0 && c < 8;
-    if (c == 0 || carries) {
-        const float us = a.w[i], gi = a.Gw[gr] * invb;
-        const float wi = us * a.sw_in;
-        w_new = ROWS ? us - a.eta_w * gi : wi - a.eta * fmaf(a.regw, wi, gi);
-    }
-    if (carries) u = embed_w(u, c, w_new);
     *V4 = u;
     *G4 = f4zero();
     if (c == 0) {
-        a.w[i] = w_new;
+        const float us = a.w[i], gi = a.Gw[gr] * invb;
+        const float wi = us * a.sw_in;
+        a.w[i] = ROWS ? us - a.eta_w * gi : wi - a.eta * fmaf(a.regw, wi, gi);
         a.Gw[gr] = 0.f;
         a.Gb[gr] = 0.f;  // same wave already holds its copy of b (all lanes of a row share a wave)
     }

@@ -31,14 +31,11 @@
 #ifndef FMHIP_EXP_NO_HOT
 #define FMHIP_EXP_NO_HOT 0
 #endif
-#ifndef FMHIP_EXP_W_FROM_V
-#define FMHIP_EXP_W_FROM_V 0      // with FMHIP_EXP_NO_W: the vector-ALU cost of reading w_i out of the gathered V row's low bits instead
-#endif
 // ... none of which may reach a library anyone trains with: a build that sets one must say so (FMHIP_ABLATION_BUILD, which
 // tools/build_variant.sh passes for A/B variants), and fmhip_ablation_mask() reports it at run time (tests/test_host_cpu.py
 // asserts the shipped library's mask is 0)
 #define FMHIP_FWD_ABLATIONS ((FMHIP_EXP_NO_STREAM ? 1 : 0) | (FMHIP_EXP_NO_MATH ? 2 : 0) | (FMHIP_EXP_NO_W ? 4 : 0) | (FMHIP_EXP_NO_GATHER ? 8 : 0) | \
-                             (FMHIP_EXP_L1_GATHER ? 16 : 0) | (FMHIP_EXP_NO_HOT ? 32 : 0) | (FMHIP_EXP_W_FROM_V ? 512 : 0))
+                             (FMHIP_EXP_L1_GATHER ? 16 : 0) | (FMHIP_EXP_NO_HOT ? 32 : 0))
 #if FMHIP_FWD_ABLATIONS && !defined(FMHIP_ABLATION_BUILD)
 #error "a result-changing FMHIP_EXP_* ablation is set without FMHIP_ABLATION_BUILD: timing-only variants are built by tools/build_variant.sh"
 #endif
@@ -227,11 +224,9 @@ __device__ __forceinline__ void slot_entries(const int *sc, int c, int c0, int (
 // BUF: V fits a 32-bit buffer view (< 4 GiB): a row's address is ONE 32-bit shift-add per entry (the
 // descriptor lives in scalar registers) instead of a 64-bit multiply-add pair, and the dead entries of a
 // partial step fetch nothing (out-of-range offset).  Wider tables take flat 64-bit addresses.
-// WV: the rows carry their linear weight's bits (k == Kp, fm_device.h): w_j is read out of entry j's gathered row — by all
-// lanes of the slot, so lin_row ends up the same in each of them (lanes 0..7; the others hold 0) and the caller counts it once
-template <int LPN, int J, int CH, bool MASKED, bool BUF, bool WV = false>
+template <int LPN, int J, int CH, bool MASKED, bool BUF>
 __device__ __forceinline__ void fwd_step(const float *V, __amdgpu_buffer_rsrc_t vr, const int *sc, int c, float x, int cnt, int l, float4 (&q)[J],
-                                         float4 (&s)[J], float *lin_row = nullptr) {
+                                         float4 (&s)[J]) {
     constexpr int KP = 4 * LPN * J;
 #pragma unroll
     for (int c0 = 0; c0 < LPN; c0 += CH) {
@@ -274,8 +269,6 @@ __device__ __forceinline__ void fwd_step(const float *V, __amdgpu_buffer_rsrc_t 
                     acc_entry(q[jj], s[jj], t[j][jj], __int_as_float(xi[j]));
                 }
             }
-            if (FMHIP_EXP_W_FROM_V) q[0].w = fmaf(e_from_row(t[j][0], l), 1e-38f * __int_as_float(xi[j]), q[0].w);   // timing only
-            if (WV && (!MASKED || c0 + j < cnt)) *lin_row = fmaf(e_from_row(t[j][0], l), __int_as_float(xi[j]), *lin_row);
         }
     }
 }
@@ -464,7 +457,6 @@ __device__ __forceinline__ void forward_rows(const FwdArgs &a, const float *wt, 
     constexpr int SLOTS = kBlock / LPN;
     constexpr int KPW = 4 * LPN * J;
     constexpr int CH = (LPN * J > 16) ? (16 / J) : LPN;  // entries whose V rows are in flight together
-    constexpr bool WV = !PACKED && kWInV;                // the rows carry their linear weights (fm_device.h): no w lookup, no tile
     const int l = threadIdx.x & (LPN - 1);
     const int slot = threadIdx.x / LPN;
     const float w0 = *a.w0;
@@ -490,7 +482,7 @@ __device__ __forceinline__ void forward_rows(const FwdArgs &a, const float *wt, 
             float4 q[J], s[J];
 #pragma unroll
             for (int jj = 0; jj < J; ++jj) { q[jj] = f4zero(); s[jj] = f4zero(); }
-            float lin = 0.f, lin_row = 0.f;
+            float lin = 0.f;
             if (HOT && !FMHIP_EXP_NO_HOT) {
                 if (hot_plain) hot_prologue<LPN, J, !PACKED, false>(xh, vh, wh, l, q, s, lin);
                 else hot_prologue<LPN, J, !PACKED, true>(xh, vh, wh, l, q, s, lin);
@@ -518,11 +510,10 @@ __device__ __forceinline__ void forward_rows(const FwdArgs &a, const float *wt, 
                     if (pos < p1) { c_n = stream_load(colb + pos); x_n = stream_load(valb + pos); }
                 }
                 float wv = 0.f;
-                if (!PACKED && !WV && !FMHIP_EXP_NO_W && c >= 0) wv = w_lookup<WT, BUF>(a, wr, wt, T, c);
-                fwd_step<LPN, J, CH, false, BUF, WV>(a.V, vr, slot_publish<LPN>(stage, c, x, l), c, x, LPN, l, q, s, &lin_row);
-                if (!PACKED && !WV) lin = fmaf(wv, x, lin);
+                if (!PACKED && !FMHIP_EXP_NO_W && c >= 0) wv = w_lookup<WT, BUF>(a, wr, wt, T, c);
+                fwd_step<LPN, J, CH, false, BUF>(a.V, vr, slot_publish<LPN>(stage, c, x, l), c, x, LPN, l, q, s);
+                if (!PACKED) lin = fmaf(wv, x, lin);
             }
-            if (WV && l == 0) lin += lin_row;
             row_finish<LPN, J, MODE, PACKED>(a, r, l, q, s, lin, w0, st1, st2, stbad);
         }
         block_stats<kBlock>(a.bsum, st1, st2, stbad);
@@ -537,7 +528,7 @@ __device__ __forceinline__ void forward_rows(const FwdArgs &a, const float *wt, 
         float4 q[J], s[J];
 #pragma unroll
         for (int jj = 0; jj < J; ++jj) { q[jj] = f4zero(); s[jj] = f4zero(); }
-        float lin = 0.f, lin_row = 0.f;
+        float lin = 0.f;
         if (HOT && !FMHIP_EXP_NO_HOT) {
             if (hot_plain) hot_prologue<LPN, J, !PACKED, false>(xh, vh, wh, l, q, s, lin);
             else hot_prologue<LPN, J, !PACKED, true>(xh, vh, wh, l, q, s, lin);
@@ -547,9 +538,9 @@ __device__ __forceinline__ void forward_rows(const FwdArgs &a, const float *wt, 
             const int c = FMHIP_EXP_NO_STREAM ? (int)((base + l) & 1023u) : stream_load(colb + (base + l));
             const float x = FMHIP_EXP_NO_STREAM ? 1.f : stream_load(valb + (base + l));
             float wv = 0.f;
-            if (!PACKED && !WV && !FMHIP_EXP_NO_W) wv = w_lookup<WT, BUF>(a, wr, wt, T, c);
-            fwd_step<LPN, J, CH, false, BUF, WV>(a.V, vr, slot_publish<LPN>(stage, c, x, l), c, x, LPN, l, q, s, &lin_row);
-            if (!PACKED && !WV) lin = fmaf(wv, x, lin);       // consumed after the gathers are on their way
+            if (!PACKED && !FMHIP_EXP_NO_W) wv = w_lookup<WT, BUF>(a, wr, wt, T, c);
+            fwd_step<LPN, J, CH, false, BUF>(a.V, vr, slot_publish<LPN>(stage, c, x, l), c, x, LPN, l, q, s);
+            if (!PACKED) lin = fmaf(wv, x, lin);       // consumed after the gathers are on their way
         }
         if (base < p1) {                               // the row's last, partial step
             // Through a buffer view a dead entry is id -1 with value 0: its row offset lies past the end of V (a multiple
@@ -561,12 +552,11 @@ __device__ __forceinline__ void forward_rows(const FwdArgs &a, const float *wt, 
             if (p < p1) {
                 c = stream_load(colb + p);
                 x = stream_load(valb + p);
-                if (!PACKED && !WV && !FMHIP_EXP_NO_W) wv = w_lookup<WT, BUF>(a, wr, wt, T, c);
+                if (!PACKED && !FMHIP_EXP_NO_W) wv = w_lookup<WT, BUF>(a, wr, wt, T, c);
             }
-            fwd_step<LPN, J, CH, !BUF, BUF, WV>(a.V, vr, slot_publish<LPN>(stage, c, x, l), c, x, (int)(p1 - base), l, q, s, &lin_row);
-            if (!PACKED && !WV) lin = fmaf(wv, x, lin);
+            fwd_step<LPN, J, CH, !BUF, BUF>(a.V, vr, slot_publish<LPN>(stage, c, x, l), c, x, (int)(p1 - base), l, q, s);
+            if (!PACKED) lin = fmaf(wv, x, lin);
         }
-        if (WV && l == 0) lin += lin_row;
         row_finish<LPN, J, MODE, PACKED>(a, r, l, q, s, lin, w0, st1, st2, stbad);
     }
     block_stats<kBlock>(a.bsum, st1, st2, stbad);
@@ -591,8 +581,7 @@ __global__ __launch_bounds__(kBlock, (LPN * J <= 8 ? 5 : 1)) void k_forward_wt(F
     extern __shared__ __attribute__((aligned(16))) float wt[];
     __shared__ __attribute__((aligned(16))) float vh[HOT ? kHotT * KP : 4];
     __shared__ float wh[HOT ? kHotT : 1];
-    if (!kWInV)
-        for (int i = threadIdx.x; i < a.wt_rows; i += kBlock) wt[i] = a.w[i];       // (with w in the rows the tile is never read)
+    for (int i = threadIdx.x; i < a.wt_rows; i += kBlock) wt[i] = a.w[i];
     bool hot_plain = false;
     if (HOT) hot_plain = hot_stage<KP>(a, vh, wh);
     else __syncthreads();
@@ -618,10 +607,8 @@ __global__ __launch_bounds__(kBlock) void k_rescale(float *V, float *w, int64_t 
         const float keep = f4pick(v, pack_k & 3);
         v = f4mul(v, sv);
         if (pack_k >= 0 && c == (pack_k >> 2)) f4set(v, pack_k & 3, keep * sw);
-        const float w_new = (c == 0 || (kWInV && pack_k < 0 && c < 8)) ? w[i] * sw : 0.f;     // the lanes of a row share a wave: read before piece 0 writes
-        if (kWInV && pack_k < 0) v = embed_w(v, c, w_new);
         *p = v;
-        if (c == 0) w[i] = w_new;
+        if (c == 0) w[i] *= sw;
     }
 }
 

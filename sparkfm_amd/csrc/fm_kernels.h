@@ -19,10 +19,6 @@ constexpr int kGradHead = 32;      // floats reserved for them at the front of t
 // runtime kernel-variant knobs (diagnostics / A-B benchmarking; fmhip_tune)
 enum { kTuneFwd = 0, kTuneBwd = 1, kTuneTile = 2, kTuneRowBlock = 3, kTuneXcd = 4, kTuneHot = 5, kTuneFwdOcc = 6, kTuneRowOrder = 7,
        kTuneFlat = 8, kTuneLazy = 9, kTuneFused = 10, kTuneMerged = 11, kTuneHotPages = 12, kTuneCount = 13 };
-// V rows of an unpacked model (k == Kp) carry the bits of their stored linear weight in low mantissa bits (fm_device.h)
-#ifndef FMHIP_W_IN_V
-#define FMHIP_W_IN_V 1
-#endif
 constexpr int kHotT = 16;           // slots of one page of the dense hot block (fp32 per row: one 64-B half line)
 // Pages of the dense hot block.  Page 0 (the 16 most frequent features) is dense on BOTH sides: its entries leave the
 // CSR and the CSC streams.  Pages 1.. (the next most frequent ones that still pass the density test) are dense on the
@@ -202,7 +198,6 @@ hipError_t launch_forward(int Kp, FwdMode mode, const FwdArgs &a, hipStream_t s,
 hipError_t launch_init_normal(int Kp, float *V, float *w, float *w0, int64_t n1, int64_t n1p, int32_t k, uint64_t seed, float mean,
                               float stdev, hipStream_t s);
 // out_v[j*Kp + f] = V[ids[j]][f], out_w[j] = w[ids[j]] (raw stored values; the caller applies scales / packed slots)
-hipError_t launch_verify_rows(int Kp, const float *V, const float *w, int64_t n1, unsigned long long *bad, hipStream_t s);
 hipError_t launch_gather_rows(int Kp, const float *V, const float *w, const int32_t *ids, int64_t n, float *out_v, float *out_w,
                               hipStream_t s);
 // dense V *= sv, w *= sw (packed rows: the w slot of a V row by sw): brings lazily decayed tables back to scale 1

@@ -61,20 +61,6 @@ int set_params_impl(fmhip_model_t m, FT w0, const FT *w, const FT *v) {
         hw[(size_t)i] = (float)w[i];
         for (int f = 0; f < m->k; ++f) hV[(size_t)i * m->Kp + f] = (float)v[f + i * (int64_t)m->k];
         if (m->pack_k() >= 0) hV[(size_t)i * m->Kp + m->k] = (float)w[i];   // packed rows: w_i rides in slot k
-        else if (FMHIP_W_IN_V) {
-            // unpacked rows carry the bits of their stored w in the two low mantissa bits of floats 4c, 4c+1, c < 8 (fm_device.h:
-            // what the forward reads instead of looking w up; every writer of a V row keeps them current)
-            uint32_t wb;
-            memcpy(&wb, &hw[(size_t)i], sizeof wb);
-            for (int c = 0; c < 8; ++c)
-                for (int h = 0; h < 2; ++h) {
-                    uint32_t vb;
-                    float *dst = &hV[(size_t)i * m->Kp + 4 * c + h];
-                    memcpy(&vb, dst, sizeof vb);
-                    vb = (vb & ~3u) | ((wb >> (4 * c + 2 * h)) & 3u);
-                    memcpy(dst, &vb, sizeof vb);
-                }
-        }
     }
     const float hw0 = (float)w0;
     m->h_w0 = (double)w0;
@@ -270,23 +256,6 @@ int fmhip_model_get_rows(fmhip_model_t m, int64_t n, const int32_t *ids, double 
         if (v)
             for (int f = 0; f < m->k; ++f) v[f + j * (int64_t)m->k] = (double)hv[(size_t)j * m->Kp + f] * m->sv;
     }
-    return FMHIP_OK;
-}
-
-int fmhip_model_verify(fmhip_model_t m, int64_t *mismatched_rows) {
-    ReadLock lock(m);
-    if (!m || !mismatched_rows) return fail(FMHIP_ERR_INVALID, "NULL argument");
-    *mismatched_rows = 0;
-    if (!FMHIP_W_IN_V || m->pack_k() >= 0) return FMHIP_OK;    // a padded row's spare slot IS the weight (no second copy to agree with)
-    TRY(set_device(m->device));
-    DevBuf<unsigned long long> bad;
-    TRY(bad.alloc(1));
-    HIP_TRY(hipMemsetAsync(bad.p, 0, sizeof(unsigned long long), m->stream));
-    HIP_TRY(launch_verify_rows(m->Kp, m->V.p, m->w.p, m->n1, bad.p, m->stream));
-    unsigned long long h = 0;
-    HIP_TRY(hipMemcpyAsync(&h, bad.p, sizeof h, hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
-    *mismatched_rows = (int64_t)h;
     return FMHIP_OK;
 }
 

@@ -382,8 +382,6 @@ bool plan_fused(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double eta, doubl
         return true;
     }
     if (!m->tv(kTuneFused) || d->rb_rows != 0) return false;
-    // unpacked rows (k == Kp) carry their linear weight's bits and the in-walk update does not re-embed them (fm_backward.hip)
-    if (FMHIP_W_IN_V && m->pack_k() < 0) return false;
     if (!lazy_ok) return false;
     p->mode = 1;
     p->sv_out = m->sv * dv;

@@ -6,7 +6,6 @@ Fortran-ordered, i.e. breeze's column-major DenseMatrix (S/fm/FMModel.scala:19) 
 device-resident fp32 twin behind the C ABI.  Host and device copies are synchronised lazily.
 """
 import ctypes as C
-import os
 
 import numpy as np
 
@@ -142,13 +141,6 @@ class FMModel(Model):
         _ffi.check(_ffi.load().fmhip_model_get_rows(self.handle, len(ids), _ffi.ptr(ids), _ffi.ptr(w), _ffi.ptr(v)))
         return w, v.reshape((self.num_factor, len(ids)), order="F")
 
-    def verify(self):
-        """Rows of the device layout whose carried linear weight differs from the weight table (0 = consistent):
-        fmhip_model_verify."""
-        bad = C.c_int64(-1)
-        _ffi.check(_ffi.load().fmhip_model_verify(self.handle, C.byref(bad)))
-        return int(bad.value)
-
     def touch(self):
         """Declare that the host arrays were modified in place."""
         self._pull()
@@ -185,11 +177,6 @@ class FMModel(Model):
         says so: `fm.w` / `fm.v` / `predict` raise until new parameters are assigned — it does not quietly hand back stale
         host arrays or re-draw the initial ones.  Pull them first (`fm.v`, `fm.rows(ids)`) if they are wanted."""
         if self._h is not None:
-            if self._dev_fresh and os.environ.get("FMHIP_VERIFY_ON_CLOSE"):     # the suite and the soaks: every model that is
-                bad = C.c_int64(-1)                                              # closed is checked (fmhip_model_verify)
-                _ffi.check(_ffi.load().fmhip_model_verify(self._h, C.byref(bad)))
-                if bad.value:
-                    raise AssertionError("%d factor rows carry a linear weight that differs from the weight table" % bad.value)
             if not discard and not (self._init_on_device and self._v is None):
                 self._pull()
             elif not self._host_fresh:

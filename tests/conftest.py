@@ -9,7 +9,6 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
-    os.environ.setdefault("FMHIP_VERIFY_ON_CLOSE", "1")      # FMModel.close checks the device layout's invariant (fmhip_model_verify)
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: full-size runs (tens of seconds each); part of -m gpu, deselect with -m 'gpu and not slow'")
 

@@ -187,9 +187,8 @@ def test_c5_criteo_shape_sgd(fmhip, c5, regs, flat, lazy):
 def test_lazy_decay_long_run_and_refold(fmhip, k):
     """Lazy weight decay over many steps: 300 steps with strong decay on a wide model (the scale drops far
     enough to be folded back into the tables at least once) track the oracle's eager update; switching to a
-    dense step (another dataset whose batch touches most rows) folds the scale and stays on track.  k = 32: rows without a
-    spare slot, whose low mantissa bits carry the linear weight — the fold rewrites every row and must re-embed it
-    (checked when the model is closed: fmhip_model_verify)."""
+    dense step (another dataset whose batch touches most rows) folds the scale and stays on track.  k = 16: rows with a spare
+    slot that carries the linear weight (its own scale); k = 32: rows without one."""
     from helpers import random_problem
     a = random_problem(77, 600, 5000, k, 2, 12)
     ds = fmhip.DataSet(a["row_ptr"], a["col"], a["val"], a["y"], batch_rows=100).cache()
@@ -205,7 +204,6 @@ def test_lazy_decay_long_run_and_refold(fmhip, k):
     assert np.abs(fm.v - v).max() <= 2e-4 * scale and np.abs(fm.w - w).max() <= 2e-4 * max(np.abs(w).max(), 1e-30)
     assert fm.w0 == pytest.approx(w0, rel=1e-4, abs=1e-6)
     assert fm.computeRMSE(ds) == pytest.approx(oracle.rmse(w0, w, v, a["row_ptr"], a["col"], a["val"], a["y"]), rel=1e-4)
-    assert fm.verify() == 0
     ds.unpersist()
     fm.close()
 

@@ -723,23 +723,7 @@ def test_rows_only_apply_for_wide_models(fmhip, k):
     assert np.linalg.norm(fm.v - v) <= 1e-4 * np.linalg.norm(v)
     assert np.linalg.norm(fm.w - w) <= 1e-4 * max(np.linalg.norm(w), 1e-12)
     untouched = np.setdiff1d(np.arange(a["n1"]), a["col"])
-    # an untouched row keeps its bits — all of them but the weight-carrying ones of an unpacked row (k == Kp: the two low
-    # mantissa bits of factors 4c, 4c+1, c < 8 hold the row's stored w: fm_device.h), which the upload wrote once
-    got = fm.v[:, untouched].astype(np.float32).view(np.uint32).copy()
-    want = a["v"][:, untouched].astype(np.float32).view(np.uint32).copy()
-    if k in (32, 64, 128, 256):
-        carrying = [f for f in range(32) if (f & 3) < 2]
-        got[carrying] &= ~np.uint32(3)
-        want[carrying] &= ~np.uint32(3)
-    np.testing.assert_array_equal(got, want)
-    # ... and those bits spell the row's linear weight exactly
-    if k in (32, 64, 128, 256):
-        raw = fm.v[:, untouched].astype(np.float32).view(np.uint32)
-        wbits = np.zeros(len(untouched), np.uint32)
-        for c in range(8):
-            for h in range(2):
-                wbits |= (raw[4 * c + h] & np.uint32(3)) << np.uint32(4 * c + 2 * h)
-        np.testing.assert_array_equal(wbits, fm.w[untouched].astype(np.float32).view(np.uint32))
+    np.testing.assert_array_equal(fm.v[:, untouched], a["v"][:, untouched].astype(np.float32))
     ds.unpersist()
     fm.close()
     fm2.close()

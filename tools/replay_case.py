@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Replays one case of the random-shapes property test (tests/test_gpu_parity.py: _random_shapes) and prints where the GPU's
-SGD epoch leaves the oracle's.   python3 tools/replay_case.py SEED CASE [flat] [k values]"""
+SGD epoch leaves the oracle's.   python3 tools/replay_case.py SEED CASE [flat] [k values] [regs:r0,rw,rv] [tune:KEY=VALUE] [gtune:KEY=VALUE]
+QUICK=1 in the environment stops after the epoch's comparison."""
 import os
 import sys
 
@@ -47,6 +48,9 @@ regs = (0.01, 0.01, 0.01) if want % 4 else (0.0, 0.0, 0.0)
 for extra in sys.argv[5:]:                                           # regs:r0,rw,rv   tune:KEY=VALUE (per model, after creation)
     if extra.startswith("regs:"):
         regs = tuple(float(x) for x in extra[5:].split(","))
+for extra in sys.argv[5:]:                                           # gtune:KEY=VALUE: process-wide, before the dataset is built
+    if extra.startswith("gtune:"):
+        _ffi.check(L.fmhip_tune(int(extra[6:].split("=")[0]), int(extra.split("=")[1])))
 ds, fm = make(fmhip, a, batch_rows=batch_rows)
 for extra in sys.argv[5:]:
     if extra.startswith("tune:"):
@@ -94,6 +98,12 @@ bad = np.argwhere(dv > 1e-6)
 print("entries off by > 1e-6:", len(bad), bad[:10].tolist(), "features in the data:", sorted(set(a["col"].tolist()))[:20])
 for f_, i in bad[:6]:
     print("  v[%d,%d]: gpu %.9g oracle %.9g initial %.9g" % (f_, i, fm.v[f_, i], v[f_, i], a["v"][f_, i]))
+per_feature = np.linalg.norm(fm.v - v, axis=0)
+lay = ds.layout()
+print("deviation by feature (largest 12):", [(int(i), "%.2e" % per_feature[i], "dense" if i in lay.get("hot_ids_all", []) else "sparse", int((a["col"] == i).sum()))
+                                              for i in np.argsort(-per_feature)[:12]])
+if os.environ.get("QUICK"):
+    sys.exit(0)
 
 # is a deviation from the oracle an error or the amplification of fp32 rounding by the training dynamics?  The same epoch with
 # the dense hot block off (another summation order, same arithmetic otherwise): if two GPU runs differ from each other as much

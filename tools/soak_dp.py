@@ -16,7 +16,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("FMHIP_VERIFY_ON_CLOSE", "1")     # every model closed is checked: fmhip_model_verify
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import dp_cases  # noqa: E402
 
