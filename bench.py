@@ -8,9 +8,11 @@ synthetic workload, all inputs resident in HBM before the timed region.
 
   N = 1   BASELINE config 3 (1M rows x 100k features, k=32): the configuration the metric is quoted on.
   N > 1   BASELINE config 4 (10M rows x 1M features, k=32) sharded by rows: every rank owns a shard of
-          the same virtual dataset and steps through mini-batches of 625k rows; the packed gradient
+          the same virtual dataset; ONE job whatever N — a global mini-batch of 5M rows per step (the same
+          SGD trajectory on 2, 4 or 8 GPUs), 5M / N rows of it on every rank; the packed gradient
           (136 MB) is all-reduced over RCCL/xGMI every step INSIDE the library (fmhip_dp_step:
-          overlapped with the feature-chunked backward).  Per-GPU work per step is fixed -> "weak".
+          overlapped with the feature-chunked backward).  Total work per step is fixed -> "strong"
+          (the one-GPU denominator of the same job is `extra.c4_one_gpu` of the N = 1 record).
           Started either by the driver (python -m torch.distributed.run ... bench.py --gpus N) or by
           `python bench.py --gpus N` alone: with WORLD_SIZE unset the parent spawns the N ranks itself —
           before it has touched the GPU — and forwards rank 0's JSON line.  `--transport threads` runs the N
@@ -36,6 +38,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+DP_GLOBAL_BATCH_ROWS = 5_000_000     # rows per data-parallel step over ALL ranks (C4's 10M rows: two steps per epoch)
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md); measured streaming copy ~6.3e12
 # Ceilings for gathers of whole 128-B-multiple rows by where the table lives (MI355X_MICROARCH.md,
 # "Indexed rows"): the XCD's own L2, the Infinity Cache, HBM (measured sweep / spec peak)
@@ -579,10 +582,11 @@ def hbm_resident_leg(device, steps=48, rows=6_000_000, batch_rows=250_000, hashe
     return out
 
 
-def c4_one_gpu_leg(device, eta, regs, rows=10_000_000, batch_rows=625_000, passes=3):
-    """BASELINE config 4 — ALL of its 10M rows x 1M features, k=32 — on ONE GPU with the data-parallel runs' batch of
-    625k rows and the plain step: the denominator the N > 1 lines (C4 sharded over N GPUs) are to be divided by, in the
-    driver-run N = 1 record."""
+def c4_one_gpu_leg(device, eta, regs, rows=10_000_000, batch_rows=DP_GLOBAL_BATCH_ROWS, passes=3):
+    """BASELINE config 4 — ALL of its 10M rows x 1M features, k=32 — on ONE GPU with the data-parallel runs' GLOBAL batch
+    (5M rows: the same job, the same SGD trajectory) and the plain step: the denominator the N > 1 lines (C4 sharded over
+    N GPUs) are to be divided by, in the driver-run N = 1 record.  (One GPU's rate hardly depends on the batch: 31.5 / 35.6 /
+    32.7 / 31.9 G nnz/s at 625k / 1.25M / 2.5M / 5M rows, tools/c4_batch_sweep.sh.)"""
     from sparkfm_amd import DataSet, FMModel, _ffi, synth
     L = _ffi.load()
     cfg = synth.CONFIGS["C4"]
@@ -717,8 +721,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default=None, choices=["C1", "C2", "C3", "C4", "C5"],
                     help="default: C3 on one GPU (the metric's configuration), C4 on several (BASELINE's 8-GPU config)")
-    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the config's rows / N, capped at 2.5M)")
-    ap.add_argument("--batch-rows", type=int, default=0, help="mini-batch rows per GPU (default 250000; 625000 data-parallel)")
+    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the config's rows / N, capped at 5M — two global batches; 1.25M on one GPU)")
+    ap.add_argument("--batch-rows", type=int, default=0, help="mini-batch rows per GPU (default 250000; data-parallel: 5M / N, the global batch is fixed)")
     ap.add_argument("--eta", type=float, default=0.02)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the sustained / HBM-resident / ALS legs")
@@ -824,9 +828,13 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
 
     config = args.config or ("C4" if world > 1 else "C3")
     cfg = synth.CONFIGS[config]
-    rows = args.rows or min(cfg["rows"] // world, 2_500_000 if world > 1 else 1_250_000)
+    # Data-parallel runs are ONE job whatever N: a GLOBAL mini-batch of DP_GLOBAL_BATCH_ROWS rows per step (the same SGD
+    # trajectory on 2, 4 or 8 GPUs), every rank taking 1/N of it.  dp_world: the ranks of that job (an emulated run plays rank
+    # 0 of the emulated count).
+    dp_world = int(args.emulate_allreduce.split(":")[0]) if (use_dp and args.emulate_allreduce) else world
+    rows = args.rows or min(cfg["rows"] // max(dp_world, 1), 5_000_000 if use_dp else 1_250_000)
     k, n1 = cfg["k"], cfg["features"]
-    batch_rows = min(args.batch_rows or (625_000 if use_dp else 250_000), rows)
+    batch_rows = min(args.batch_rows or (max(DP_GLOBAL_BATCH_ROWS // max(dp_world, 1), 1) if use_dp else 250_000), rows)
     regs = (0.0, 1e-4, 1e-4)
 
     if args.hot_pages:
@@ -1113,7 +1121,7 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
             # batch, cuts and exchange mode through the library's own data-parallel step with a one-rank communicator whose
             # collectives are the identity (tools/pmc_leg.py c4) — measured now, on rank 0's GPU, while the other ranks wait
             fr = ",".join(str(f) for f in dp.upper_fractions) or "none"
-            live = live_pmc([os.path.join(ROOT, "tools", "pmc_leg.py"), "c4", "--rows", str(min(rows, 2 * batch_rows)), "--batch-rows", str(batch_rows),
+            live = live_pmc([os.path.join(ROOT, "tools", "pmc_leg.py"), "c4", "--rows", str(min(rows, 2 * batch_rows, max(batch_rows, 2_500_000))), "--batch-rows", str(batch_rows),
                              "--upper-fractions", fr, "--dp-exchange", dp.exchange, "--steps", "8", "--warmup", "4"], per_step=(4, 8))
             for kn, e in (live or {}).items():
                 pmc.setdefault(kn, {}).update(e, traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py invocation on "
@@ -1146,13 +1154,14 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
         out = {
             "metric": "nnz_per_sec_fm_sgd_training", "value": value, "unit": "nnz/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": step_ms, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d rows x %d features per GPU, k=%d, %s, fp32 mini-batch SGD" %
                                    (config, rows, n1, k, ("39 hashed Criteo-shaped fields" + (", ids relabelled by frequency at load" if relabelled else ""))
                                     if cfg.get("criteo") else
                                     "nnz/row U{%d..%d}, ids Zipf(%.2f)" % (cfg["nnz_lo"], cfg["nnz_hi"], cfg["zipf_s"])),
                        "rows_per_gpu": rows, "features": n1, "k": k, "batch_rows_per_gpu": batch_rows,
+                       "global_batch": batch_rows * dp_world,
                        "batches_per_gpu": nb, "nnz_per_gpu": int(d["row_ptr"][-1]), "eta": args.eta, "regs": regs,
                        "dense_hot_block": {"pages": lay["hot_pages"], "features_forward_and_backward": len(lay["hot_ids"]),
                                            "features_backward": len(lay["hot_ids_all"]),
