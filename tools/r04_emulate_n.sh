@@ -13,9 +13,10 @@ run() { # ranks busbw batch_rows rows
   echo "$tag rc=$rc"
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMED OUT: stopping"; exit 1; fi
 }
+# (rows = 2 batches at least: a dataset of ONE batch has no dense hot block)
 run 2 43 625000 1250000
-run 2 43 2500000 2500000
-run 2 65 2500000 2500000
+run 2 43 2500000 5000000
+run 2 65 2500000 5000000
 run 4 129 625000 1250000
 run 4 129 1250000 2500000
 run 4 194 1250000 2500000
