@@ -504,7 +504,8 @@ int fmhip_als_epoch(fmhip_model_t m, fmhip_dataset_t d, double reg0, double regw
     TRY(check_train(m, d));
     if (d->batches.size() > 1 || (d->nnz > 0 && !d->val64.p))
         return fail(FMHIP_ERR_UNSUPPORTED, "ALS walks the whole-dataset transpose: create the dataset with batch_rows <= 0 "
-                                           "(single batch, at most 2^27 stored nonzeros)");
+                                           "(single batch, at most 2^27 stored nonzeros) and without asking for the dense hot "
+                                           "block (fmhip_dataset_opts::hot_block <= 0)");
     if (d->rb_rows > 0) return fail(FMHIP_ERR_UNSUPPORTED, "ALS needs a dataset without row blocks (fmhip_tune key 3 = 0)");
     if (d->als_dup)
         return fail(FMHIP_ERR_UNSUPPORTED, "ALS: a row stores the same feature index twice; the column walk updates every row of a "

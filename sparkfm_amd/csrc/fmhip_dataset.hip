@@ -297,8 +297,10 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     // up to `max_pages` pages of kHotT slots; x_rh sits in xhot[page][r][slot].  Page 0's entries leave the sparse
     // streams altogether; the entries of pages 1.. stay in the CSR stream (the forward walks them like any other entry)
     // and leave only the transposes (fm_kernels.h, kHotPages).  A feature that occurs twice in a row, or is stored with
-    // an explicit zero, keeps the sparse path.  Single-batch datasets (the ALS learner walks their whole transpose) and
-    // row-blocked ones (gradient-side pages) are never split.
+    // an explicit zero, keeps the sparse path.  A single-batch dataset the ALS learner could walk (its whole transpose, at most
+    // kAlsMaxNnz nonzeros) is split only when the caller asks for the block by name (fmhip_dataset_opts::hot_block >= 1: such a
+    // dataset is for SGD, fmhip_als_epoch refuses it); larger single-batch datasets — full-batch SGD — are split like any other.
+    // Row-blocked ones keep page 0 only.
     const int64_t *orig_row_ptr = row_ptr;
     std::vector<int64_t> sp_ptr;
     std::unique_ptr<int32_t[]> sp_col_buf;
@@ -307,7 +309,7 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     std::vector<int64_t> bwd_out;          // per batch: entries of the gradient-side pages (in the CSR, not in the CSC)
     std::vector<uint32_t> drop_bits;       // bitmap over feature ids: the gradient-side pages' features
     bool split = false;
-    if (want_hot && nb > 1 && nnz > 0 && !scoring) {
+    if (want_hot && (nb > 1 || nnz > kAlsMaxNnz || hot_opt > 0) && nnz > 0 && !scoring) {
         // Frequencies: exact for datasets of up to 8 M nonzeros; beyond that from every s-th row (the
         // choice of hot features is a layout decision — any set that passes the checks below is valid —
         // and a feature in >= 10 % of the rows cannot hide from a sample of millions of entries).

@@ -763,6 +763,39 @@ def test_per_dataset_layout_options(fmhip):
     check_grad(grads[0][0], grads[0][1], grads[1][0], grads[1][1], np.abs(a["v"]).max())
 
 
+def test_a_single_batch_dataset_takes_the_hot_block_when_asked(fmhip):
+    """Full-batch SGD: a dataset of ONE batch is what the ALS learner walks, so by default its transpose stays whole (no dense
+    hot block); asked for by name (fmhip_dataset_opts::hot_block >= 1) the block is built, full-batch SGD steps track the oracle
+    on it, and fmhip_als_epoch refuses that dataset — the default one still serves both learners."""
+    from test_gpu_parity import hot_problem
+    a, hot_ids = hot_problem(909, 2500, 400, 32, 10)
+    regs = (0.0, 1e-3, 1e-3)
+    w0, w, v = a["w0"], a["w"], a["v"]
+    for _ in range(3):
+        w0, w, v, _ = oracle.sgd_epoch(w0, w, v, 0, a["row_ptr"], a["col"], a["val"], a["y"], 0.05, *regs)
+    for hb in (None, 4):
+        ds = fmhip.DataSet(a["row_ptr"], a["col"], a["val"], a["y"], batch_rows=0, hot_block=hb).cache()
+        assert ds.n_batches == 1
+        lay = ds.layout()
+        assert (len(lay["hot_ids"]) > 0) == (hb is not None) and (lay["nnz_sparse"] < ds.nnz) == (hb is not None)
+        fm = fmhip.FMModel(a["n1"] - 1, a["k"])
+        fm.w0, fm.w, fm.v = a["w0"], a["w"], a["v"]
+        sgd = fmhip.HipSGD(eta=0.05, reg0=regs[0], regw=regs[1], regv=regs[2])
+        for _ in range(3):
+            sgd.learn(fm, ds)
+        assert rel(fm.v, v) <= 1e-5 and rel(fm.w, w) <= 1e-5 and fm.w0 == pytest.approx(w0, rel=1e-5, abs=1e-7)
+        from sparkfm_amd._ffi import FmhipError
+        als = fmhip.HipALS()
+        fm.reg0, fm.regw, fm.regv = 0.0, 0.01, 0.01
+        if hb is None:
+            als.learn(fm, ds)                                           # the whole transpose is there
+        else:
+            with pytest.raises(FmhipError, match="hot block"):
+                als.learn(fm, ds)
+        ds.unpersist()
+        fm.close()
+
+
 def test_permutation_of_a_rows_nonzeros(fmhip):
     """SURVEY §4's property: a row is a set of (index, value) pairs — storing them in another order (the reference's
     loader neither sorts nor reorders, S/fm/FMUtils.scala:28-36) changes the prediction and the gradient only by fp32
