@@ -210,7 +210,8 @@ def test_bench_with_eight_thread_ranks():
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["steps"] == 4 and out["warmup"] == 2
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["steps"] == 4 and out["warmup"] == 2
+    assert out["config"]["global_batch"] == 8 * out["config"]["batch_rows_per_gpu"]        # one job: the global batch is what is fixed
     assert out["metric"] == "nnz_per_sec_fm_sgd_training" and out["value"] > 0 and out["ms_per_step"] > 0
     assert out["config"]["workload"].startswith("C4") and out["config"]["rows_per_gpu"] == 100000
     x = out["exchange"]
