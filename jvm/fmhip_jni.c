@@ -1,7 +1,9 @@
 /*
  * fmhip_jni.c — JNI shim between jvm/HipSGD.scala and libfmhip.so (include/fmhip.h).
  *
- * SOURCE ONLY: the build image has no JDK (no jni.h), so this file has never been compiled here.  It is
+ * The build image has no JDK (no jni.h): here this file is compiled (-Wall -Wextra -Werror) against the stand-in
+ * tests/jni_stub/jni.h and its natives are driven, without a JVM, by tests/jni_harness.c through an in-memory JNIEnv that
+ * copies arrays and poisons them on release; what that cannot cover is the real jni.h's ABI.  The file is
  * deliberately nothing but marshalling: every function obtains the Java arrays, calls ONE entry point of the
  * C ABI with plain pointers and sizes, releases them, and turns a non-zero status into a RuntimeException that
  * carries fmhip_last_error().

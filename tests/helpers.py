@@ -53,3 +53,19 @@ def random_problem(seed, n_rows, n1, k, nnz_lo, nnz_hi, empty_rows=(), scale=0.1
     y = rng.normal(0, 1.0, n_rows)
     return dict(k=k, n1=n1, w0=w0, w=w, v=v, row_ptr=row_ptr, col=col.astype(np.int32),
                 val=val.astype(np.float64), y=y)
+
+
+def build_jni_harness(tmp_path):
+    """Compiles jvm/fmhip_jni.c (the JNI shim: source-only, the image has no JDK) together with tests/jni_harness.c against
+    the stand-in tests/jni_stub/jni.h, warnings as errors — every call of the shim into include/fmhip.h is type-checked — and
+    returns the executable (`host` / `gpu`: tests/jni_harness.c)."""
+    import os
+    import subprocess
+    from sparkfm_amd import _build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "jni_harness")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Werror",
+                           "-I" + os.path.join(root, "tests", "jni_stub"), "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "jni_harness.c"), os.path.join(root, "jvm", "fmhip_jni.c"),
+                           "-L" + _build.LIBDIR, "-lfmhip", "-Wl,-rpath," + _build.LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    return exe

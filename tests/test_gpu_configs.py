@@ -764,6 +764,19 @@ def test_per_dataset_layout_options(fmhip):
     check_grad(grads[0][0], grads[0][1], grads[1][0], grads[1][1], np.abs(a["v"]).max())
 
 
+def test_jni_shim_end_to_end_without_a_jvm(fmhip, tmp_path):
+    """The JNI shim's model / dataset / training / scoring / communicator natives, driven by tests/jni_harness.c through an
+    in-memory JNIEnv (copying arrays, poisoned on release) on the GPU: two SGD epochs, parameters, RMSE, predictions over a
+    dataset and over loose rows, a scoring-only dataset, and a one-rank RCCL communicator's plan, epoch and ordered epoch —
+    each bit for bit what the same calls through the C ABI give; library errors arrive as RuntimeException with
+    fmhip_last_error()'s text."""
+    import subprocess
+    from helpers import build_jni_harness
+    r = subprocess.run([build_jni_harness(tmp_path), "gpu"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert "jni_harness gpu:" in r.stdout.decode() and "checks ok" in r.stdout.decode()
+
+
 def test_a_single_batch_dataset_takes_the_hot_block_when_asked(fmhip):
     """Full-batch SGD: a dataset of ONE batch is what the ALS learner walks, so by default its transpose stays whole (no dense
     hot block); asked for by name (fmhip_dataset_opts::hot_block >= 1) the block is built, full-batch SGD steps track the oracle

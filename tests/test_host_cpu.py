@@ -221,6 +221,18 @@ def test_plain_c_consumer_of_the_header(tmp_path):
     assert "c_abi_smoke ok" in out
 
 
+def test_jni_shim_compiles_and_marshals_like_the_c_abi(tmp_path):
+    """jvm/fmhip_jni.c has never met a JDK here.  Compiled against a stand-in jni.h (tests/jni_stub: the JNI specification's
+    signatures for the entries the shim uses) with warnings as errors, every call into include/fmhip.h is checked for argument
+    count and type; tests/jni_harness.c then drives the natives that are host arithmetic through an in-memory JNIEnv that
+    hands out COPIES of the arrays and poisons them on release (the least convenient VM the specification allows) and
+    compares each with the same call through the C ABI.  (The GPU natives: test_gpu_configs.py.)"""
+    import subprocess
+    from helpers import build_jni_harness
+    out = subprocess.check_output([build_jni_harness(tmp_path), "host"]).decode()
+    assert "jni_harness host:" in out and "checks ok" in out
+
+
 def test_nnz_balanced_shards():
     """fmhip_shard_rows: contiguous, covering, balanced by stored nonzeros — on skewed rows a
     row-count split would be badly off."""
@@ -450,13 +462,3 @@ def test_jvm_class_has_no_duplicate_members():
     assert len(every) == len(set(every)), sorted(n for n in every if every.count(n) > 1)
     code = re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", scala, flags=re.S))      # comments may hold "[lo, hi)"
     assert code.count("{") == code.count("}") and code.count("(") == code.count(")") and code.count("[") == code.count("]")
-
-
-def test_jni_shim_type_checks_against_a_stub_header():
-    """No JDK here: `gcc -fsyntax-only` against tests/jni_stub/jni.h (a test stub of the names the shim uses) at least
-    type-checks every call the shim makes into include/fmhip.h."""
-    import subprocess
-    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Werror", "-fsyntax-only",
-                        "-I" + os.path.join(ROOT, "tests", "jni_stub"), "-I" + os.path.join(ROOT, "include"),
-                        os.path.join(ROOT, "jvm", "fmhip_jni.c")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert r.returncode == 0, r.stderr.decode()
