@@ -55,7 +55,7 @@ def random_problem(seed, n_rows, n1, k, nnz_lo, nnz_hi, empty_rows=(), scale=0.1
                 val=val.astype(np.float64), y=y)
 
 
-def build_jni_harness(tmp_path):
+def build_jni_harness(tmp_path, sanitize=False):
     """Compiles jvm/fmhip_jni.c (the JNI shim: source-only, the image has no JDK) together with tests/jni_harness.c against
     the stand-in tests/jni_stub/jni.h, warnings as errors — every call of the shim into include/fmhip.h is type-checked — and
     returns the executable (`host` / `gpu`: tests/jni_harness.c)."""
@@ -63,8 +63,10 @@ def build_jni_harness(tmp_path):
     import subprocess
     from sparkfm_amd import _build
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "jni_harness")
-    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Werror",
+    exe = str(tmp_path / ("jni_harness_asan" if sanitize else "jni_harness"))
+    # sanitize: AddressSanitizer + UBSan over the shim and the harness (CPU build only; libfmhip.so itself is not instrumented)
+    san = ["-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if sanitize else []
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Werror"] + san + [
                            "-I" + os.path.join(root, "tests", "jni_stub"), "-I" + os.path.join(root, "include"),
                            os.path.join(root, "tests", "jni_harness.c"), os.path.join(root, "jvm", "fmhip_jni.c"),
                            "-L" + _build.LIBDIR, "-lfmhip", "-Wl,-rpath," + _build.LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])

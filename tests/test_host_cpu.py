@@ -231,6 +231,13 @@ def test_jni_shim_compiles_and_marshals_like_the_c_abi(tmp_path):
     from helpers import build_jni_harness
     out = subprocess.check_output([build_jni_harness(tmp_path), "host"]).decode()
     assert "jni_harness host:" in out and "checks ok" in out
+    # the same under AddressSanitizer + UBSan (the shim's pin / release bookkeeping is exactly what they watch)
+    try:
+        exe = build_jni_harness(tmp_path, sanitize=True)
+    except subprocess.CalledProcessError:
+        pytest.skip("no sanitizer runtime for gcc in this image")
+    r = subprocess.run([exe, "host"], env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and b"checks ok" in r.stdout, r.stderr.decode()[-3000:]
 
 
 def test_nnz_balanced_shards():
