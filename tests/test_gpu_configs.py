@@ -764,6 +764,22 @@ def test_per_dataset_layout_options(fmhip):
     check_grad(grads[0][0], grads[0][1], grads[1][0], grads[1][1], np.abs(a["v"]).max())
 
 
+def test_bench_fallback_exchange_over_torch_distributed():
+    """`bench.py --exchange torch`: the exchange the bench falls back to when the library's own RCCL communicator cannot be
+    created on a node (bench.py: "fell back to torch.distributed") — the split step (fmhip_step_compute / fmhip_step_apply) with
+    the packed gradient all-reduced by torch.distributed's nccl backend on the library's stream.  One rank here (a one-rank nccl
+    group is what the test box can form): the flow, the line and a finite training are what is tested."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dp", "--exchange", "torch", "--config", "C4",
+           "--rows", "200000", "--batch-rows", "100000", "--steps", "4", "--warmup", "2", "--no-extra", "--no-pmc", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.strip()][-1])
+    assert out["config"]["exchange"] == "torch" and "torch.distributed" in out["config"]["allreduce"]
+    assert out["value"] > 0 and out["train"]["nonfinite"] == 0 and out["config"]["batch_rows_per_gpu"] == 100000
+
+
 def test_jni_shim_end_to_end_without_a_jvm(fmhip, tmp_path):
     """The JNI shim's model / dataset / training / scoring / communicator natives, driven by tests/jni_harness.c through an
     in-memory JNIEnv (copying arrays, poisoned on release) on the GPU: two SGD epochs, parameters, RMSE, predictions over a
