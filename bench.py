@@ -1242,10 +1242,27 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
             out["cpu_baseline"] = cpu_baseline(d, k, n1, batch_rows, args.eta, regs, w0, w, v, args.cpu_budget)
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
         if world == 1 and not args.no_extra and not use_dp:
+            scoring = None
+            try:
+                # the scoring calls of the path (FMModel.predict / computeRMSE) on the line's own
+                # dataset: fmhip_rmse = the forward over every batch + the statistics, nothing leaves the device but one double
+                r_ = C.c_double(0.0)
+                _ffi.check(L.fmhip_rmse(hm, hd, C.byref(r_), None))
+                _ffi.check(L.fmhip_synchronize(hm))
+                n_pass, t0s = 0, time.perf_counter()
+                while n_pass < 5 or time.perf_counter() - t0s < 0.5:
+                    _ffi.check(L.fmhip_rmse(hm, hd, C.byref(r_), None))
+                    n_pass += 1
+                dts = time.perf_counter() - t0s
+                nnz_all = int(d["row_ptr"][-1])
+                scoring = {"what": "fmhip_rmse over the whole dataset (%d rows, %d nonzeros): forward + statistics per batch, %d passes" % (rows, nnz_all, n_pass),
+                           "value": nnz_all * n_pass / dts, "unit": "nnz/s", "ms_per_pass": dts / n_pass * 1e3, "rmse": r_.value}
+            except Exception as ex:   # noqa: BLE001
+                scoring = {"error": repr(ex)}
             ds.unpersist()
             fm.close(discard=True)
             del d
-            extra = {}
+            extra = {"scoring": scoring}
             try:
                 extra["hbm_resident"] = hbm_resident_leg(local_rank, with_pmc=not args.no_pmc)
             except Exception as ex:   # noqa: BLE001
