@@ -274,3 +274,67 @@ def test_a_rank_that_brings_the_wrong_model_keeps_the_step_alive():
                                     0.05, 0.0, 1e-3, 1e-3)
     assert np.linalg.norm(r0[2] - ov) <= 1e-5 * np.linalg.norm(ov) and np.linalg.norm(r0[1] - ow) <= 1e-5 * np.linalg.norm(ow)
     assert np.isfinite(v0_after).all() and np.isfinite(v1_after).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["dense", "sharded", "touched"])
+def test_a_transport_that_fails_in_mid_step_is_an_error_not_a_crash(exchange):
+    """fmhip_comm_create_external: the caller's collective may fail (a peer died, a socket closed).  Whichever collective of a
+    step it is — the row count, a slice of the gradient, an all-gather — the step returns FMHIP_ERR_COMM with the callback's code
+    in the message, nothing crashes or hangs, the handles can still be destroyed, and a NEW communicator on the same model and
+    dataset plans and steps again (the model's values after a failed step are unspecified: the caller restores them)."""
+    import ctypes as C
+    from helpers import random_problem
+    from sparkfm_amd import DataSet, FMModel, _ffi
+    L = _ffi.load()
+    a = random_problem(31, 1500, 2003, 32, 4, 30)
+    ds = DataSet(a["row_ptr"], a["col"], a["val"], a["y"], batch_rows=500, device=0).cache()
+    mode = {"dense": 0, "touched": 1, "sharded": 2}[exchange]
+    state = {"calls": 0, "fail_at": -1}
+
+    def collective(_ctx, _dev, _count, _kind, _stream):      # a world of one: every collective is the identity
+        state["calls"] += 1
+        return 7 if state["calls"] == state["fail_at"] else 0
+
+    fn = _ffi.CollectiveFn(collective)
+
+    def fresh():
+        fm = FMModel(a["n1"] - 1, 32, device=0)
+        fm.w0, fm.w, fm.v = a["w0"], a["w"], a["v"]
+        h = C.c_void_p()
+        _ffi.check(L.fmhip_comm_create_external(fm.handle, 0, 1, fn, None, C.byref(h)))
+        _ffi.check(L.fmhip_dp_exchange(h, mode))
+        fr = (C.c_double * 2)(0.12, 0.4)
+        state["calls"], state["fail_at"] = 0, -1
+        _ffi.check(L.fmhip_dp_plan(fm.handle, ds.handle, h, 2, fr, None))
+        return fm, h
+
+    # how many collectives does a clean step make?  Then fail each of them in turn.
+    fm, h = fresh()
+    before = state["calls"]
+    _ffi.check(L.fmhip_dp_step_at(fm.handle, ds.handle, 0, h, 0.05, 0.0, 1e-3, 1e-3))
+    _ffi.check(L.fmhip_synchronize(fm.handle))
+    per_step = state["calls"] - before
+    assert per_step >= 2
+    fm._device_updated()
+    want_v = fm.v.copy()
+    assert np.isfinite(want_v).all() and not np.array_equal(want_v, a["v"])
+    _ffi.check(L.fmhip_comm_destroy(h))
+    fm.close(discard=True)
+    for k in range(1, per_step + 1):
+        fm, h = fresh()
+        state["fail_at"] = state["calls"] + k
+        rc = L.fmhip_dp_step_at(fm.handle, ds.handle, 0, h, 0.05, 0.0, 1e-3, 1e-3)
+        msg = L.fmhip_last_error().decode()
+        assert rc == -6 and "returned 7" in msg, (k, rc, msg)                   # FMHIP_ERR_COMM, the callback's own code
+        _ffi.check(L.fmhip_synchronize(fm.handle))
+        _ffi.check(L.fmhip_comm_destroy(h))
+        fm.close(discard=True)
+    # ... and the model / dataset are still good for a new communicator: the same step, the same result
+    fm, h = fresh()
+    _ffi.check(L.fmhip_dp_step_at(fm.handle, ds.handle, 0, h, 0.05, 0.0, 1e-3, 1e-3))
+    fm._device_updated()
+    np.testing.assert_array_equal(fm.v, want_v)
+    _ffi.check(L.fmhip_comm_destroy(h))
+    fm.close(discard=True)
+    ds.unpersist()
