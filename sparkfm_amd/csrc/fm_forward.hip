@@ -576,7 +576,10 @@ __global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
 // the persistent grid of forward_blocks_wt is sized for 5, and a register count that admits only 4 would
 // run it in two rounds.)
 template <int LPN, int J, int MODE, bool HOT, bool BUF>
-__global__ __launch_bounds__(kBlock, (LPN * J <= 8 ? 5 : 1)) void k_forward_wt(FwdArgs a) {
+#ifndef FMHIP_FWD_WGS
+#define FMHIP_FWD_WGS 5       // resident workgroups per CU the compiler budgets registers for (Kp = 32); 6 was measured: see r04_experiments.md
+#endif
+__global__ __launch_bounds__(kBlock, (LPN * J <= 8 ? FMHIP_FWD_WGS : 1)) void k_forward_wt(FwdArgs a) {
     constexpr int KP = 4 * LPN * J;
     extern __shared__ __attribute__((aligned(16))) float wt[];
     __shared__ __attribute__((aligned(16))) float vh[HOT ? kHotT * KP : 4];
