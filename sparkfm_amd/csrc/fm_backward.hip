@@ -521,8 +521,11 @@ __global__ __launch_bounds__(kBlock) void k_backward(BwdArgs a) {
 #ifndef FMHIP_BWD_WAVES
 #define FMHIP_BWD_WAVES 3
 #endif
+#ifndef FMHIP_BWD_WAVES8
+#define FMHIP_BWD_WAVES8 4    // the same bound for the 8-lane slots (Kp = 32) alone: four, with the 4-entry gather chunks below
+#endif
 template <int LPN, int J, bool PACKED, bool HOT>
-__global__ __launch_bounds__(kBlock, (HOT && J == 1 ? FMHIP_BWD_WAVES : 1)) void k_backward_p(BwdArgs a) {
+__global__ __launch_bounds__(kBlock, (HOT && J == 1 ? (LPN == 8 ? FMHIP_BWD_WAVES8 : FMHIP_BWD_WAVES) : 1)) void k_backward_p(BwdArgs a) {
     constexpr int KP = 4 * LPN * J;
     if (HOT && (int)blockIdx.x >= a.hot_first && (int)blockIdx.x < a.hot_first + a.hot_blocks) {
         hot_backward_body<KP / 16>(a.hot, (int)blockIdx.x - a.hot_first, a.hot_blocks);
@@ -532,7 +535,16 @@ __global__ __launch_bounds__(kBlock, (HOT && J == 1 ? FMHIP_BWD_WAVES : 1)) void
 #define FMHIP_BWD_SG 8
 #endif
     constexpr int SG = (kRangeLen / LPN) < FMHIP_BWD_SG ? (kRangeLen / LPN) : FMHIP_BWD_SG;   // lane-groups per super-group
-    constexpr int CHB = (LPN * J > 8) ? ((8 / J) > 0 ? (8 / J) : 1) : LPN;   // entries per gather chunk
+    // entries per gather chunk (two chunks are in flight).  8-lane slots (Kp = 32): 4 — with 8 the double buffer alone held 64
+    // registers and the kernel three waves per SIMD; 4 fits four waves (127 registers) and the walk gained 3 % at C3, 5 % at
+    // C2 (r04_experiments.md section 19; the same bits: only the grouping of the loads changed).  16-lane slots: FMHIP_BWD_CHB16.
+#ifndef FMHIP_BWD_CHB
+#define FMHIP_BWD_CHB 4
+#endif
+#ifndef FMHIP_BWD_CHB16
+#define FMHIP_BWD_CHB16 0     // 0 = 8 / J
+#endif
+    constexpr int CHB = (LPN * J <= 8) ? FMHIP_BWD_CHB : ((J == 1 && FMHIP_BWD_CHB16 > 0) ? FMHIP_BWD_CHB16 : ((8 / J) > 0 ? (8 / J) : 1));
     constexpr int NCH = SG * LPN / CHB;                                       // chunks per super-group
     RangeWalk<LPN, J, PACKED> w;
     if (!w.setup(a, (HOT && (int)blockIdx.x >= a.hot_first) ? (int)blockIdx.x - a.hot_blocks : (int)blockIdx.x)) return;
