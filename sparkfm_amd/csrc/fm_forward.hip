@@ -562,8 +562,14 @@ __device__ __forceinline__ void forward_rows(const FwdArgs &a, const float *wt, 
     block_stats<kBlock>(a.bsum, st1, st2, stbad);
 }
 
+// (Second launch bound, Kp = 32 with the hot-block prologue: left to itself the compiler takes 100 registers — four waves per
+// SIMD; budgeted for five it needs 94 and C2's forward, k = 16 in packed rows, goes from 98.3 to 93.0 us with the same bits.
+// Without the prologue the kernel sits at five already and the bound only perturbs it: r04_experiments.md section 20.)
+#ifndef FMHIP_FWD_PLAIN_WGS
+#define FMHIP_FWD_PLAIN_WGS 5
+#endif
 template <int LPN, int J, int MODE, bool PACKED, bool HOT, bool BUF>
-__global__ __launch_bounds__(kBlock) void k_forward(FwdArgs a) {
+__global__ __launch_bounds__(kBlock, (LPN * J <= 8 && HOT ? FMHIP_FWD_PLAIN_WGS : 1)) void k_forward(FwdArgs a) {
     constexpr int KP = 4 * LPN * J;
     __shared__ __attribute__((aligned(16))) float vh[HOT ? kHotT * KP : 4];
     __shared__ float wh[HOT ? kHotT : 1];
