@@ -581,10 +581,10 @@ __global__ __launch_bounds__(kBlock, (LPN * J <= 8 && HOT ? FMHIP_FWD_PLAIN_WGS 
 // k_forward with an LDS-resident tile of the hot linear weights.  (Second launch bound = waves per SIMD:
 // the persistent grid of forward_blocks_wt is sized for 5, and a register count that admits only 4 would
 // run it in two rounds.)
-template <int LPN, int J, int MODE, bool HOT, bool BUF>
 #ifndef FMHIP_FWD_WGS
-#define FMHIP_FWD_WGS 5       // resident workgroups per CU the compiler budgets registers for (Kp = 32); 6 was measured: see r04_experiments.md
+#define FMHIP_FWD_WGS 5       // waves per SIMD the compiler budgets registers for (Kp = 32); 6 was measured: r04_experiments.md section 18
 #endif
+template <int LPN, int J, int MODE, bool HOT, bool BUF>
 __global__ __launch_bounds__(kBlock, (LPN * J <= 8 ? FMHIP_FWD_WGS : 1)) void k_forward_wt(FwdArgs a) {
     constexpr int KP = 4 * LPN * J;
     extern __shared__ __attribute__((aligned(16))) float wt[];
