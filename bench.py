@@ -622,6 +622,20 @@ def c4_one_gpu_leg(device, eta, regs, rows=10_000_000, batch_rows=DP_GLOBAL_BATC
     return out
 
 
+_PG_GENERATION = [0]
+
+
+def init_process_group(dist, backend, **kw):
+    """torch.distributed's rendezvous: the launcher's env:// (torch.distributed.run sets MASTER_*), or — ranks spawned by this file —
+    a file store, one file per process group this run creates (the fallback exchange makes a second one)."""
+    rdzv = os.environ.get("FMHIP_BENCH_RDZV")
+    if rdzv:
+        _PG_GENERATION[0] += 1
+        return dist.init_process_group(backend, init_method="%s.%d" % (rdzv, _PG_GENERATION[0]), rank=int(os.environ["RANK"]),
+                                       world_size=int(os.environ["WORLD_SIZE"]), **kw)
+    return dist.init_process_group(backend, **kw)
+
+
 class TorchCtl:
     """The bench's control plane over torch.distributed (gloo; nccl when the exchange itself is torch's): barriers and
     reductions of a few timers — never the gradients."""
@@ -677,17 +691,15 @@ class NoCtl:
 def spawn_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (this process
     has not touched the GPU and never will), forward rank 0's JSON line, exit with the worst exit code."""
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     import tempfile
     procs = []
     out0 = tempfile.TemporaryFile()
+    # the ranks meet through a file store in a fresh directory: a port found by binding to 0 and closing it can be taken by
+    # someone else before rank 0 binds it again (EADDRINUSE, seen once on a GPU box)
+    rdzv = "file://" + os.path.join(tempfile.mkdtemp(prefix="fmhip_bench_rdzv_"), "store")
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), FMHIP_BENCH_RDZV=rdzv,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=out0 if r == 0 else subprocess.DEVNULL))
     # a rank that dies (no such GPU, out of memory ...) must not leave the others waiting in a collective
@@ -807,9 +819,9 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         if args.exchange == "rccl":
             # control plane only (unique id, barriers, the max over ranks): the gradients never pass through it
-            dist.init_process_group("gloo")
+            init_process_group(dist, "gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            init_process_group(dist, "nccl", device_id=torch.device("cuda", local_rank))
         ctl = TorchCtl(dist, torch, args.exchange == "torch")
     run_rank(args, rank, world, local_rank, ctl, json_fd, torch)
     if use_dp:
@@ -872,7 +884,7 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
     binfo = [ds.batch_info(b) for b in range(nb)]
     bnnz = [bi["nnz"] for bi in binfo]
     comm = dp = eng = None
-    comm_note = None
+    comm_note = selftest_note = None
     if exchange == "rccl":
         try:
             comm = (ThreadStagedComm(fm, rank, group) if group is not None else
@@ -882,6 +894,10 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
             dp_mode = args.dp_exchange if args.dp_exchange != "auto" else ("touched" if cfg.get("criteo") else "dense")
             dp = HipDataParallelSGD(comm, eta=args.eta, reg0=regs[0], regw=regs[1], regv=regs[2], exchange=dp_mode,
                                     upper_fractions=fixed if fixed is not None else (0.05, 0.15, 0.3, 0.55))
+            # before anything is trusted to it: known patterns through every collective kind, with the step's own calls (all ranks
+            # get the same verdict; a failure takes the fallback below on every rank alike)
+            comm.selftest()
+            selftest_note = "fmhip_comm_selftest passed on %d ranks (all six collective kinds)" % world
             dp.plan(fm, ds)
             if args.emulate_allreduce:
                 if world != 1:
@@ -900,9 +916,13 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
             # Python-orchestrated exchange over torch.distributed
             comm_note = "library-side RCCL exchange unavailable (%r): fell back to torch.distributed" % (ex,)
             sys.stderr.write("[bench] rank %d: %s\n" % (rank, comm_note))
+            if comm is not None:          # created, then failed its self-test or the plan: not used again
+                comm.close()
+                comm = None
+            selftest_note = None
             exchange = "torch"
             dist.destroy_process_group()
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            init_process_group(dist, "nccl", device_id=torch.device("cuda", local_rank))
             ctl = TorchCtl(dist, torch, True)
             fm.close()
             fm = FMModel(n1 - 1, k, device=local_rank, stream=torch_stream_handle(local_rank), init_on_device=wide,
@@ -1021,6 +1041,23 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
         s_nnz = float(sum(bnnz[j % nb] for j in range(n_done)))
         s_nnz = ctl.allreduce([s_nnz], "sum")[0]
         sustained = {"seconds": dt, "steps": n_done, "value": s_nnz / dt, "unit": "nnz/s", "ms_per_step": dt / n_done * 1e3}
+
+    # ---- do the replicas still agree?  Every rank has taken the same steps up to here (rank 0's legs below are its own): 4,160
+    # parameter rows spread over every feature interval, and w0, must be the SAME BITS on all ranks — a collective that moved the
+    # wrong elements, or an update that differed, shows here and not as a throughput number from models that have drifted apart
+    replicas = None
+    if use_dp:
+        ids = np.unique(np.concatenate([np.arange(min(64, n1)), np.linspace(0, n1 - 1, 4096).astype(np.int64)])).astype(np.int32)
+        rw, rv = fm.rows(ids)
+        wts = np.cos(np.arange(rv.size, dtype=np.float64) * 0.7310585786)           # fixed weights: a permutation of rows shows too
+        sums = [float(fm.w0), float(rw.sum()), float(rv.sum()), float(np.dot(rv.ravel(order="F"), wts))]
+        hi_ = ctl.allreduce(sums, "max")
+        lo_ = ctl.allreduce([-x for x in sums], "max")
+        finite = all(np.isfinite(x) for x in sums)
+        replicas = {"identical": bool(finite and all(a == -b for a, b in zip(hi_, lo_))), "rows_compared": int(len(ids)), "finite": bool(finite),
+                    "note": "w0 and %d parameter rows spread over all feature intervals: plain and weighted fp64 sums, max == min over the ranks" % len(ids)}
+        if not replicas["identical"]:
+            sys.stderr.write("[bench] rank %d: REPLICAS DIFFER after the timed steps: max %r, -min %r\n" % (rank, hi_, lo_))
 
     # ---- the same shard and batch WITHOUT the exchange (what one GPU of the job does alone)
     no_exchange = one_gpu_plain = None
@@ -1229,6 +1266,10 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
                 xc["scaling_vs_%s_one_gpu" % config.lower()] = value / one_gpu_plain["value"]
             if comm_note:
                 xc["note"] = comm_note
+            if selftest_note:
+                xc["selftest"] = selftest_note
+            if replicas:
+                xc["replicas"] = replicas
             if tuning:
                 xc["cut_tuning"] = tuning
             if args.emulate_allreduce:

@@ -322,6 +322,14 @@ int fmhip_comm_unique_id(void *id /* FMHIP_UNIQUE_ID_BYTES out */);
 int fmhip_comm_create(fmhip_model_t m, const void *id, int rank, int world, fmhip_comm_t *out);
 int fmhip_comm_destroy(fmhip_comm_t c);
 int fmhip_comm_info(fmhip_comm_t c, int *rank, int *world);
+/* Collective (every rank calls it): known patterns through each collective kind the plan and the step issue, on the
+ * communicator's own stream with the step's own calls (the grouped three-region all-reduce of a gradient slice, the
+ * in-place reduce-scatter / all-gathers of the sharded update, the plan's int64 maximum / broadcast and id all-gather).
+ * All ranks get the same verdict: FMHIP_OK, or FMHIP_ERR_COMM with bit FMHIP_COLL_* of *failed_kinds (may be NULL) set for
+ * every kind that left wrong elements on ANY rank.  A caller runs it once after fmhip_comm_create — a transport that moves
+ * the wrong elements fails here and not as replicas that quietly drift apart (the reference's reductions cannot go wrong
+ * this way: S/fm/lib/ALS.scala:153 is a JVM-side reduce). */
+int fmhip_comm_selftest(fmhip_comm_t c, int *failed_kinds);
 /* The same communicator over a transport of the caller's own instead of RCCL (MPI, UCX, a JVM-side channel; the
  * two-ranks-on-one-GPU test of this repo stages through the host and torch.distributed/gloo).  `fn` is called from
  * fmhip_dp_step / _plan / _epoch on the calling thread and must leave in EVERY rank's `device_buf` the result over all

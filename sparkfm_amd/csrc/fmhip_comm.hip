@@ -149,6 +149,45 @@ __global__ __launch_bounds__(256) void k_comm_traffic(f32x4_t *buf, size_t n4, u
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
+// ---- fmhip_comm_selftest: known patterns through every collective kind the step uses
+// pattern value of element i on rank r (small integers: every sum below is exact in fp32)
+__device__ __forceinline__ float st_pat(int r, size_t i) { return (float)((r + 1) * (int)(1 + i % 7)); }
+
+// what = 0: this rank's contribution to a sum (SUM_F32, REDUCE_SCATTER_F32); 1: its own segment of an all-gather of floats
+// (the others' poisoned); 2: the same for int32
+__global__ __launch_bounds__(256) void k_st_fill(void *buf, size_t n, size_t seg, int rank, int what) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (what == 0) { static_cast<float *>(buf)[i] = st_pat(rank, i); return; }
+    const bool mine = i / seg == (size_t)rank;
+    if (what == 1) static_cast<float *>(buf)[i] = mine ? (float)rank + 0.5f + (float)(i % 3) : -1.0f;
+    else static_cast<int32_t *>(buf)[i] = mine ? (int32_t)(rank * 100000 + (int32_t)(i % seg)) : -1;
+}
+
+// counts the elements of [lo, hi) that differ from what the collective must have left there
+__global__ __launch_bounds__(256) void k_st_check(const void *buf, size_t lo, size_t hi, size_t seg, int world, int what, unsigned *bad) {
+    const size_t i = lo + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= hi) return;
+    bool ok;
+    if (what == 0) {
+        ok = static_cast<const float *>(buf)[i] == (float)(world * (world + 1) / 2 * (int)(1 + i % 7));
+    } else if (what == 1) {
+        ok = static_cast<const float *>(buf)[i] == (float)(i / seg) + 0.5f + (float)(i % 3);
+    } else {
+        ok = static_cast<const int32_t *>(buf)[i] == (int32_t)((i / seg) * 100000 + i % seg);
+    }
+    if (!ok) atomicAdd(bad, 1u);
+}
+
+__global__ void k_st_i64(int64_t *p, int rank) {
+    p[0] = rank; p[1] = -(int64_t)rank; p[2] = 5;        // MAX -> world - 1, 0, 5
+    p[4] = 10 * (int64_t)rank + 3; p[5] = 77 - rank;     // BCAST0 -> 3, 77
+}
+__global__ void k_st_i64_check(const int64_t *p, int world, unsigned *bad_max, unsigned *bad_bcast) {
+    if (p[0] != world - 1 || p[1] != 0 || p[2] != 5) atomicAdd(bad_max, 1u);
+    if (p[4] != 3 || p[5] != 77) atomicAdd(bad_bcast, 1u);
+}
+
 // the row count of this rank's mini-batch travels as a kernel argument (a host buffer would have to outlive the
 // asynchronous copy, and the host runs steps ahead of the stream)
 __global__ void k_set_float(float *p, float v) { *p = v; }
@@ -972,6 +1011,90 @@ int fmhip_comm_destroy(fmhip_comm_t c) {
     if (c->cs) (void)hipStreamDestroy(c->cs);
     if (c->scratch) (void)hipFree(c->scratch);
     delete c;
+    return FMHIP_OK;
+}
+
+// Known patterns through every collective kind a step or a plan issues, on the communicator's own stream and with the
+// same calls (the grouped three-region all-reduce of a gradient slice included): a binding that moves the wrong
+// elements, counts bytes for elements or scatters to the wrong segment shows up HERE, on every rank alike, and not as
+// a model that quietly diverges.  With one rank every collective is the identity and the test still runs the calls.
+int fmhip_comm_selftest(fmhip_comm_t c, int *failed_kinds) {
+    if (failed_kinds) *failed_kinds = 0;
+    if (!c) return fail(FMHIP_ERR_INVALID, "communicator is NULL");
+    TRY(set_device(c->device));
+    const int W = c->world;
+    constexpr size_t kSeg = 4099;                         // elements per rank's segment (odd on purpose)
+    const size_t n = kSeg * (size_t)W;
+    constexpr int kKinds = 6;
+    float *fb = nullptr;
+    int64_t *ib = nullptr;
+    unsigned *bad = nullptr;
+    // regions of the grouped all-reduce: one word, a long run, a short odd run (as G_b's head, G_V rows, G_w of an interval)
+    const size_t r0 = 0, n0 = 1, r1 = 32, n1 = n - 32 - 64, r2 = n - 37, n2 = 37;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&fb), 3 * n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ib), 8 * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&bad), 8 * sizeof(unsigned));
+    int rc = e == hipSuccess ? FMHIP_OK : fail(FMHIP_ERR_HIP, "self-test buffers: %s", hipGetErrorString(e));
+    unsigned h_bad[8] = {};
+    auto body = [&]() -> int {
+        hipStream_t s = c->cs;
+        const dim3 b(256), g((unsigned)((n + 255) / 256));
+        float *sum = fb, *rs = fb + n, *ag = fb + 2 * n;
+        HIP_TRY(hipMemsetAsync(bad, 0, 8 * sizeof(unsigned), s));
+        hipLaunchKernelGGL(k_st_fill, g, b, 0, s, sum, n, kSeg, c->rank, 0);
+        hipLaunchKernelGGL(k_st_fill, g, b, 0, s, rs, n, kSeg, c->rank, 0);
+        hipLaunchKernelGGL(k_st_fill, g, b, 0, s, ag, n, kSeg, c->rank, 1);
+        hipLaunchKernelGGL(k_st_i64, dim3(1), dim3(1), 0, s, ib, c->rank);
+        HIP_TRY(hipGetLastError());
+        // 0: SUM_F32, three regions in one group (exactly reduce_regions' calls)
+        const bool group = !c->ext;
+        if (group) NCCL_TRY(rccl().GroupStart());
+        TRY(collective(c, sum + r0, n0, FMHIP_COLL_SUM_F32, s));
+        TRY(collective(c, sum + r1, n1, FMHIP_COLL_SUM_F32, s));
+        TRY(collective(c, sum + r2, n2, FMHIP_COLL_SUM_F32, s));
+        if (group) NCCL_TRY(rccl().GroupEnd());
+        TRY(collective(c, ib, 3, FMHIP_COLL_MAX_I64, s));
+        TRY(collective(c, ib + 4, 2, FMHIP_COLL_BCAST0_I64, s));
+        TRY(collective(c, rs, kSeg, FMHIP_COLL_REDUCE_SCATTER_F32, s));
+        TRY(collective(c, ag, kSeg, FMHIP_COLL_ALLGATHER_F32, s));
+        for (auto r : {std::pair<size_t, size_t>(r0, n0), std::pair<size_t, size_t>(r1, n1), std::pair<size_t, size_t>(r2, n2)})
+            hipLaunchKernelGGL(k_st_check, dim3((unsigned)((r.second + 255) / 256)), b, 0, s, sum, r.first, r.first + r.second, kSeg, W, 0,
+                               bad + FMHIP_COLL_SUM_F32);
+        hipLaunchKernelGGL(k_st_i64_check, dim3(1), dim3(1), 0, s, ib, W, bad + FMHIP_COLL_MAX_I64, bad + FMHIP_COLL_BCAST0_I64);
+        hipLaunchKernelGGL(k_st_check, dim3((unsigned)((kSeg + 255) / 256)), b, 0, s, rs, kSeg * c->rank, kSeg * (c->rank + 1), kSeg, W, 0,
+                           bad + FMHIP_COLL_REDUCE_SCATTER_F32);
+        hipLaunchKernelGGL(k_st_check, g, b, 0, s, ag, (size_t)0, n, kSeg, W, 1, bad + FMHIP_COLL_ALLGATHER_F32);
+        // 3: ALLGATHER_I32 reuses the all-gather buffer once the float check has read it (same stream)
+        hipLaunchKernelGGL(k_st_fill, g, b, 0, s, ag, n, kSeg, c->rank, 2);
+        HIP_TRY(hipGetLastError());
+        TRY(collective(c, ag, kSeg, FMHIP_COLL_ALLGATHER_I32, s));
+        hipLaunchKernelGGL(k_st_check, g, b, 0, s, ag, (size_t)0, n, kSeg, W, 2, bad + FMHIP_COLL_ALLGATHER_I32);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_bad, bad, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        // every rank learns every rank's verdict: the mask travels through MAX_I64 bit by bit (a broken MAX shows in its own bit
+        // on the rank that saw it; that rank still reports)
+        int64_t mask[kKinds];
+        for (int k = 0; k < kKinds; ++k) mask[k] = h_bad[k] ? 1 : 0;
+        HIP_TRY(hipMemcpyAsync(ib, mask, sizeof mask, hipMemcpyHostToDevice, s));
+        TRY(collective(c, ib, kKinds, FMHIP_COLL_MAX_I64, s));
+        HIP_TRY(hipMemcpyAsync(mask, ib, sizeof mask, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (int k = 0; k < kKinds; ++k)
+            if (mask[k] != 0 || h_bad[k]) h_bad[k] = h_bad[k] ? h_bad[k] : 1u;
+        return FMHIP_OK;
+    };
+    if (rc == FMHIP_OK) rc = body();
+    if (fb) (void)hipFree(fb);
+    if (ib) (void)hipFree(ib);
+    if (bad) (void)hipFree(bad);
+    if (rc != FMHIP_OK) return rc;
+    int failed = 0;
+    for (int k = 0; k < kKinds; ++k) failed |= h_bad[k] ? 1 << k : 0;
+    if (failed_kinds) *failed_kinds = failed;
+    if (failed)
+        return fail(FMHIP_ERR_COMM, "communicator self-test: wrong results from collective kinds 0x%x on some rank (rank %d of %d saw %u / %u / %u / %u / %u / %u wrong elements)",
+                    failed, c->rank, W, h_bad[0], h_bad[1], h_bad[2], h_bad[3], h_bad[4], h_bad[5]);
     return FMHIP_OK;
 }
 

@@ -241,6 +241,15 @@ class RcclComm:
     def handle(self):
         return self._h
 
+    def selftest(self):
+        """Collective: known patterns through every collective kind the plan and the step issue (fmhip_comm_selftest).
+        Raises on EVERY rank alike if any rank saw wrong elements; `.failed_kinds` then holds the FMHIP_COLL_* bit mask."""
+        mask = C.c_int(0)
+        rc = _ffi.load().fmhip_comm_selftest(self._h, C.byref(mask))
+        self.failed_kinds = mask.value
+        _ffi.check(rc)
+        return self
+
     def close(self):
         if self._h:
             _ffi.load().fmhip_comm_destroy(self._h)

@@ -20,7 +20,7 @@ def main():
     from sparkfm_amd import DataSet, FMModel, synth
     from sparkfm_amd.distributed import DataParallelSGD, torch_stream_handle
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % port, rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=(port if "://" in str(port) else "tcp://127.0.0.1:%s" % port), rank=rank, world_size=world)
     # the same virtual dataset as the single-process reference: rank r owns rows [r*3000, (r+1)*3000)
     # uneven shards: rank 1 has 2 batches (1000 + 700 rows) against rank 0's 3, so its last step contributes zeros
     d = synth.make_zipf(77, 3000 if rank == 0 else 1700, 800, 4, 24, zipf_s=1.05, row_begin=rank * 3000)

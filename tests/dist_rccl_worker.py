@@ -21,7 +21,7 @@ def main():
     import torch.distributed as dist
     from sparkfm_amd import DataSet, FMModel, synth
     from sparkfm_amd.distributed import HipDataParallelSGD, HostStagedComm, RcclComm
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % port, rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=(port if "://" in str(port) else "tcp://127.0.0.1:%s" % port), rank=rank, world_size=world)
     # uneven shards: rank 1 has 2 batches against rank 0's 3; a third rank has no rows at all
     if rank < 2:
         d = synth.make_zipf(77, 3000 if rank == 0 else 1700, 800, 4, 24, zipf_s=1.05, row_begin=rank * 3000)

@@ -53,7 +53,7 @@ def main():
     import torch.distributed as dist
     from sparkfm_amd.distributed import DataParallelSGD, shard_rows
     from helpers import random_problem
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % port, rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=(port if "://" in str(port) else "tcp://127.0.0.1:%s" % port), rank=rank, world_size=world)
     a = random_problem(2024, 230, 60, 5, 0, 12, empty_rows=(4,))
     lo, hi = shard_rows(230, rank, world)
     if rank == world - 1:

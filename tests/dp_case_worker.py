@@ -31,7 +31,7 @@ def main():
     rank = int(sys.argv[1])
     import torch.distributed as dist
     from sparkfm_amd.distributed import HostStagedComm
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % cfg["port"], rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=(cfg["port"] if "://" in str(cfg["port"]) else "tcp://127.0.0.1:%s" % cfg["port"]), rank=rank, world_size=world)
     r = dp_cases.run_rank(cfg, rank, lambda fm: HostStagedComm(fm, rank, world), dist.barrier)
     np.savez(cfg["out"] + ".%d.npz" % rank, w0=r["w0"], w=r["w"], v=r["v"], calls=r["calls"], cuts=r["cuts"])
     dist.destroy_process_group()

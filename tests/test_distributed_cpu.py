@@ -16,11 +16,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A rendezvous for torch.distributed that cannot collide: a file store in a fresh directory (a port found by binding to 0
+    and closing can be taken by someone else before the ranks bind it again — seen once on a GPU box: EADDRINUSE)."""
+    import tempfile
+    return "file://" + os.path.join(tempfile.mkdtemp(prefix="fmhip_rdzv_"), "store")
 
 
 def test_two_ranks_equal_one_process(tmp_path):
