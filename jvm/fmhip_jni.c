@@ -165,7 +165,14 @@ JNIEXPORT jlong JNI_FN(commCreate)(JNIEnv *env, jobject o, jlong m, jbyteArray i
         return 0;
     }
     (*env)->GetByteArrayRegion(env, id, 0, FMHIP_UNIQUE_ID_BYTES, buf);
-    raise(env, fmhip_comm_create(H_MODEL(m), buf, rank, world, &c));
+    int rc = fmhip_comm_create(H_MODEL(m), buf, rank, world, &c);
+    /* collective, like the creation: known patterns through every collective kind before a gradient is trusted to it */
+    if (rc == FMHIP_OK && (rc = fmhip_comm_selftest(c, NULL)) != FMHIP_OK) {
+        raise(env, rc);                  /* (the library's message first: destroying the communicator does not replace it) */
+        fmhip_comm_destroy(c);
+        return 0;
+    }
+    raise(env, rc);
     return (jlong)(intptr_t)c;
 }
 
