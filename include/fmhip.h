@@ -284,7 +284,9 @@ int fmhip_step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t batch);
  *   fmhip_step_backward(.., lo, hi, finish)  gradient rows of the features lo <= id < hi; call it for
  *                                            disjoint intervals covering [0, n+1) in DESCENDING order
  *                                            (the cold, high-id features first: most of the gradient
- *                                            volume, least of the work), finish = 1 on the last one
+ *                                            volume, least of the work) or, starting at feature 0, in
+ *                                            ASCENDING order (same gradient, bit for bit); finish = 1 on
+ *                                            the interval that starts at feature 0
  * After a call returns, floats [gv_offset + lo*row_floats, gv_offset + hi*row_floats) of the packed
  * buffer are final and can be all-reduced while the next interval computes; the head, floats
  * [0, gv_offset) (scalars | G_w | G_b), is final after the call with finish = 1. */

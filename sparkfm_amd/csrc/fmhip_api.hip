@@ -615,13 +615,23 @@ int fmhip_step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, int64
     TRY(check_train(m, d));
     TRY(check_batch(d, batch));
     if (feat_lo < 0 || feat_hi < feat_lo) return fail(FMHIP_ERR_INVALID, "bad feature interval [%lld, %lld)", (long long)feat_lo, (long long)feat_hi);
-    // intervals must come in DESCENDING order and tile [0, n+1): a range straddling two intervals is
-    // walked with the upper one, whose partials the lower one's fixup then reads
+    // intervals tile [0, n+1) in DESCENDING order (a range straddling two intervals is walked with the upper one, whose
+    // partials the lower one's fixup then reads) or, from feature 0 up, in ASCENDING order (the mirror rule); the first call
+    // after the forward says which: it ends at n+1 or starts at 0
     if (m->bw_next_hi < 0) return fail(FMHIP_ERR_INVALID, "fmhip_step_backward without fmhip_step_forward");
-    if (m->bw_next_hi == INT64_MAX ? feat_hi < m->n1 : feat_hi != m->bw_next_hi)
-        return fail(FMHIP_ERR_INVALID, "feature intervals must tile [0, n+1) in descending order (expected hi = %lld, got %lld)",
-                    (long long)(m->bw_next_hi == INT64_MAX ? m->n1 : m->bw_next_hi), (long long)feat_hi);
     if (finish && feat_lo != 0) return fail(FMHIP_ERR_INVALID, "finish = 1 belongs to the interval that starts at feature 0");
+    if (m->bw_next_hi == INT64_MAX) m->bw_up = feat_hi < m->n1 && feat_lo == 0;
+    if (m->bw_up) {
+        const int64_t want = m->bw_next_hi == INT64_MAX ? 0 : m->bw_next_hi;
+        if (feat_lo != want)
+            return fail(FMHIP_ERR_INVALID, "feature intervals must tile [0, n+1) in ascending order (expected lo = %lld, got %lld)", (long long)want, (long long)feat_lo);
+        TRY(step_backward(m, d, batch, feat_lo, feat_hi, finish != 0, nullptr, nullptr, true));
+        m->bw_next_hi = feat_hi >= m->n1 ? -1 : feat_hi;
+        return FMHIP_OK;
+    }
+    if (m->bw_next_hi == INT64_MAX ? feat_hi < m->n1 : feat_hi != m->bw_next_hi)
+        return fail(FMHIP_ERR_INVALID, "feature intervals must tile [0, n+1) in descending order (expected hi = %lld, got %lld), or start at feature 0 and ascend",
+                    (long long)(m->bw_next_hi == INT64_MAX ? m->n1 : m->bw_next_hi), (long long)feat_hi);
     TRY(step_backward(m, d, batch, feat_lo, feat_hi, finish != 0, nullptr, nullptr));
     m->bw_next_hi = feat_lo == 0 ? -1 : feat_lo;
     return FMHIP_OK;

@@ -207,6 +207,7 @@ struct fmhip_model {
     // scale itself accumulates no fp32 rounding from step to step.
     double sv = 1.0, sw = 1.0;
     int64_t bw_next_hi = -1;      // feature-chunked backward: the next interval must end here (-1: none pending)
+    bool bw_up = false;           // ... ascending intervals instead (the next one must START here)
     // fp64 master copy of the parameters (reference layout): exact round trip of what the caller set,
     // and the state the fp64 ALS learner trains; stale once an fp32 SGD step has run
     std::vector<double> h_w, h_v;
@@ -267,7 +268,7 @@ struct FusedPlan {
     FusedUpd upd{};
 };
 int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo, int64_t feat_hi, bool finish, double *acc,
-                  const FusedPlan *fused = nullptr);
+                  const FusedPlan *fused = nullptr, bool ascending = false);
 // forward + backward + fixup of one batch into the packed gradient (fused: straight into the parameters)
 int step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double *acc, const FusedPlan *fused = nullptr);
 // can this step's update run inside the fixup launch / the column walk?  (fills *p; false: a launch of its own, step_apply)

@@ -439,14 +439,15 @@ def test_dense_hot_block_chunked_backward(fmhip):
         torch.cuda.synchronize()
         _ffi.check(L.fmhip_grad_bind(fm.handle, C.c_void_p(eng.grad.data_ptr())))   # marks the zeroed buffer clean
         for cuts in ([0, 600], [0, 37, 300, 301, 600], [0, int(hot_ids[3]), int(hot_ids[3]) + 1, 600]):
-            eng.forward(batch)
-            for i in range(len(cuts) - 1, 0, -1):
-                eng.backward(batch, cuts[i - 1], cuts[i], finish=(i == 1))
-            torch.cuda.synchronize()
-            assert torch.equal(eng.grad, want), cuts
-            eng.grad.zero_()
-            torch.cuda.synchronize()
-            _ffi.check(L.fmhip_grad_bind(fm.handle, C.c_void_p(eng.grad.data_ptr())))
+            for ascending in (False, True):      # ascending: the hot rows ride in the FIRST call (it starts at feature 0)
+                eng.forward(batch)
+                for i in (range(1, len(cuts)) if ascending else range(len(cuts) - 1, 0, -1)):
+                    eng.backward(batch, cuts[i - 1], cuts[i], finish=(i == 1))
+                torch.cuda.synchronize()
+                assert torch.equal(eng.grad, want), (cuts, ascending)
+                eng.grad.zero_()
+                torch.cuda.synchronize()
+                _ffi.check(L.fmhip_grad_bind(fm.handle, C.c_void_p(eng.grad.data_ptr())))
     eng.close()
     ds.unpersist()
     fm.close()
@@ -526,14 +527,15 @@ def test_band_affine_placement_with_feature_intervals(fmhip):
     fm_h = fm.handle
     _ffi.check(L.fmhip_grad_bind(fm_h, C.c_void_p(eng.grad.data_ptr())))
     for cuts in ([0, 3000], [0, 70, 3000], [0, 3, 64, 65, 700, 2999, 3000], [0, 1500, 1500, 3000]):
-        eng.forward(1)
-        for i in range(len(cuts) - 1, 0, -1):
-            eng.backward(1, cuts[i - 1], cuts[i], finish=(i == 1))
-        torch.cuda.synchronize()
-        assert torch.equal(eng.grad, want), cuts
-        eng.grad.zero_()
-        torch.cuda.synchronize()
-        _ffi.check(L.fmhip_grad_bind(fm_h, C.c_void_p(eng.grad.data_ptr())))
+        for ascending in (False, True):
+            eng.forward(1)
+            for i in (range(1, len(cuts)) if ascending else range(len(cuts) - 1, 0, -1)):
+                eng.backward(1, cuts[i - 1], cuts[i], finish=(i == 1))
+            torch.cuda.synchronize()
+            assert torch.equal(eng.grad, want), (cuts, ascending)
+            eng.grad.zero_()
+            torch.cuda.synchronize()
+            _ffi.check(L.fmhip_grad_bind(fm_h, C.c_void_p(eng.grad.data_ptr())))
     eng.close()
     ds.unpersist()
     fm.close()
@@ -833,18 +835,27 @@ def test_feature_chunked_backward_equals_whole_backward(fmhip):
         fm_h = fm.handle
         _ffi.check(L.fmhip_grad_bind(fm_h, C.c_void_p(eng.grad.data_ptr())))   # marks the zeroed buffer clean
         for cuts in ([0, 400], [0, 1, 400], [0, 7, 50, 51, 399, 400], [0, 200, 200, 400]):
-            eng.forward(batch)
-            for i in range(len(cuts) - 1, 0, -1):
-                eng.backward(batch, cuts[i - 1], cuts[i], finish=(i == 1))
-            torch.cuda.synchronize()
-            assert torch.equal(eng.grad, want), cuts
-            eng.grad.zero_()
-            torch.cuda.synchronize()
-            _ffi.check(L.fmhip_grad_bind(fm_h, C.c_void_p(eng.grad.data_ptr())))
-    # order is enforced
+            for ascending in (False, True):      # from the top down, or from feature 0 up (the straddling range goes with the other side)
+                eng.forward(batch)
+                order = range(1, len(cuts)) if ascending else range(len(cuts) - 1, 0, -1)
+                for i in order:
+                    eng.backward(batch, cuts[i - 1], cuts[i], finish=(i == 1))
+                torch.cuda.synchronize()
+                assert torch.equal(eng.grad, want), (cuts, ascending)
+                eng.grad.zero_()
+                torch.cuda.synchronize()
+                _ffi.check(L.fmhip_grad_bind(fm_h, C.c_void_p(eng.grad.data_ptr())))
+    # order is enforced: the first interval ends at n+1 or starts at 0, the others follow it
     eng.forward(0)
-    assert L.fmhip_step_backward(fm.handle, ds.handle, 0, 0, 100, 0) == -1
+    assert L.fmhip_step_backward(fm.handle, ds.handle, 0, 50, 100, 0) == -1
     assert b"descending" in L.fmhip_last_error()
+    assert L.fmhip_step_backward(fm.handle, ds.handle, 0, 0, 100, 1) == 0          # ascending it is
+    assert L.fmhip_step_backward(fm.handle, ds.handle, 0, 200, 401, 0) == -1
+    assert b"ascending" in L.fmhip_last_error()
+    assert L.fmhip_step_backward(fm.handle, ds.handle, 0, 100, 401, 0) == 0
+    torch.cuda.synchronize()
+    eng.grad.zero_()
+    torch.cuda.synchronize()
     eng.close()
     ds.unpersist()
     fm.close()
