@@ -291,6 +291,14 @@ int fmhip_step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t batch);
  * buffer are final and can be all-reduced while the next interval computes; the head, floats
  * [0, gv_offset) (scalars | G_w | G_b), is final after the call with finish = 1. */
 int fmhip_step_forward(fmhip_model_t m, fmhip_dataset_t d, int64_t batch);
+/* The same forward in TWO passes over every row's entries — pass 0: the features below a cut, pass 1: the others and the row's
+ * finish — so that pass 0 can run while the rows of V at or above the cut are still being exchanged (the pipelined
+ * data-parallel schedule, FMHIP_EXCHANGE_PIPELINED).  fmhip_dataset_partition_rows(d, cut) prepares the dataset: a stable
+ * partition of each row's stored entries at feature id `cut` (the order of a row's entries is all that changes; not while
+ * another thread uses the dataset).  Pass 0 then pass 1 = fmhip_step_forward up to the order of the fp32 sums; models of up
+ * to 64 padded factors.  (FMModel.predict's sum over a row's entries, S/fm/FMModel.scala:41-46,57-63, taken in two parts.) */
+int fmhip_dataset_partition_rows(fmhip_dataset_t d, int64_t cut_feature);
+int fmhip_step_forward_pass(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, int pass);
 int fmhip_step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, int64_t feat_lo, int64_t feat_hi,
                         int finish);
 int fmhip_grad_layout(fmhip_model_t m, int64_t *row_floats, int64_t *gv_offset);

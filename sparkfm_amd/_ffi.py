@@ -34,6 +34,7 @@ SYMBOLS = (
     "fmhip_dp_exchange", "fmhip_dp_exchange_info", "fmhip_comm_emulate_ranks", "fmhip_model_tune", "fmhip_dataset_band_plan",
     "fmhip_dp_step_at", "fmhip_dp_epoch_order", "fmhip_dp_plan_info", "fmhip_dataset_als_levels",
     "fmhip_feature_counts_gpu", "fmhip_rank_from_counts_gpu", "fmhip_relabel_columns_gpu", "fmhip_comm_emulate_load", "fmhip_comm_selftest",
+    "fmhip_dataset_partition_rows", "fmhip_step_forward_pass",
 )
 UNIQUE_ID_BYTES = 128
 
@@ -152,6 +153,8 @@ def load():
     L.fmhip_comm_destroy.argtypes = [vp]
     L.fmhip_comm_info.argtypes = [vp, P(C.c_int), P(C.c_int)]
     L.fmhip_comm_selftest.argtypes = [vp, P(C.c_int)]
+    L.fmhip_dataset_partition_rows.argtypes = [vp, i64]
+    L.fmhip_step_forward_pass.argtypes = [vp, vp, i64, C.c_int]
     L.fmhip_dp_plan.argtypes = [vp, vp, vp, C.c_int, vp, vp]
     L.fmhip_dp_step.argtypes = [vp, vp, i64, vp, dbl, dbl, dbl, dbl]
     L.fmhip_dp_epoch.argtypes = [vp, vp, vp, dbl, dbl, dbl, dbl, P(Stats)]

@@ -286,6 +286,24 @@ __device__ __forceinline__ void row_finish(const FwdArgs &a, int r, int l, float
     // accumulated sum w_i x_i — the linear term — and there was no separate w gather; slot k of the P row
     // carries e to the backward the same way.
     const int kl = PACKED ? (a.pack_k >> 2) & (LPN - 1) : 0, kj = PACKED ? (a.pack_k >> 2) / LPN : 0, kc = a.pack_k & 3;
+    if (MODE == kFwdPartA) {
+        // pass A of a two-pass forward: the row's raw sums go out as they are — q (slot k of a packed row: the linear term so
+        // far) into the P row, sum_f s_f and the lanes' linear terms, each summed over the slot, into part_sl
+        float sp = 0.f, lp = lin;
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) {
+            float4 sj = s[jj];
+            if (PACKED && jj == kj && l == kl) f4set(sj, kc, 0.f);        // slot k is not a factor
+            sp += (sj.x + sj.y) + (sj.z + sj.w);
+        }
+#pragma unroll
+        for (int m = LPN >> 1; m >= 1; m >>= 1) { sp += __shfl_xor(sp, m, LPN); lp += __shfl_xor(lp, m, LPN); }
+        float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) pr[jj * LPN] = q[jj];
+        if (l == 0) { a.part_sl[2 * (size_t)r] = sp; a.part_sl[2 * (size_t)r + 1] = lp; }
+        return;
+    }
     float lin_all = 0.f;   // packed: the complete linear term, identical in every lane of the slot
     if (PACKED) {
         float lk = 0.f;
@@ -301,11 +319,13 @@ __device__ __forceinline__ void row_finish(const FwdArgs &a, int r, int l, float
 #pragma unroll
     for (int jj = 0; jj < J; ++jj) u += f4sqminus(q[jj], s[jj]);
     float tot = fmaf(0.5f * a.sv * a.sv, u, a.sw * lin);
+    // pass B: q already holds pass A's share (the row started from it); its sum_f s_f and linear term enter once, through lane 0
+    if (MODE == kFwdPartB && l == 0) tot += fmaf(-0.5f * a.sv * a.sv, a.part_sl[2 * (size_t)r], a.sw * a.part_sl[2 * (size_t)r + 1]);
 #pragma unroll
     for (int m = LPN >> 1; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, LPN);
     const float yhat = w0 + (tot + lin_all);
     const float e = yhat - a.y[a.row0 + r];
-    if (MODE == kFwdTrain) {
+    if (MODE == kFwdTrain || MODE == kFwdPartB) {
         float4 *pr = reinterpret_cast<float4 *>(a.P + (size_t)r * KP) + l;
         const float es = e * a.sv;
 #pragma unroll
@@ -478,10 +498,14 @@ __device__ __forceinline__ void forward_rows(const FwdArgs &a, const float *wt, 
             const int r = a.order ? a.order[ri] : ri;
             float4 xh = f4zero();
             if (HOT) xh = hot_load(a, r, l);
-            const uint32_t p0 = (uint32_t)(a.row_ptr[a.row0 + r] - a.nz0), p1 = (uint32_t)(a.row_ptr[a.row0 + r + 1] - a.nz0);
+            const uint32_t p0 = (uint32_t)((MODE == kFwdPartB ? a.row_split[a.row0 + r] : a.row_ptr[a.row0 + r]) - a.nz0),
+                           p1 = (uint32_t)((MODE == kFwdPartA ? a.row_split[a.row0 + r] : a.row_ptr[a.row0 + r + 1]) - a.nz0);
             float4 q[J], s[J];
 #pragma unroll
-            for (int jj = 0; jj < J; ++jj) { q[jj] = f4zero(); s[jj] = f4zero(); }
+            for (int jj = 0; jj < J; ++jj) {
+                q[jj] = MODE == kFwdPartB ? reinterpret_cast<const float4 *>(a.P + (size_t)r * KPW)[jj * LPN + l] : f4zero();
+                s[jj] = f4zero();
+            }
             float lin = 0.f;
             if (HOT && !FMHIP_EXP_NO_HOT) {
                 if (hot_plain) hot_prologue<LPN, J, !PACKED, false>(xh, vh, wh, l, q, s, lin);
@@ -524,10 +548,14 @@ __device__ __forceinline__ void forward_rows(const FwdArgs &a, const float *wt, 
         float4 xh = f4zero();
         if (HOT) xh = hot_load(a, r, l);
         // entry positions relative to the batch's first entry: 32-bit walk state (a batch holds < 2^31 entries)
-        const uint32_t p0 = (uint32_t)(a.row_ptr[a.row0 + r] - a.nz0), p1 = (uint32_t)(a.row_ptr[a.row0 + r + 1] - a.nz0);
+        const uint32_t p0 = (uint32_t)((MODE == kFwdPartB ? a.row_split[a.row0 + r] : a.row_ptr[a.row0 + r]) - a.nz0),
+                       p1 = (uint32_t)((MODE == kFwdPartA ? a.row_split[a.row0 + r] : a.row_ptr[a.row0 + r + 1]) - a.nz0);
         float4 q[J], s[J];
 #pragma unroll
-        for (int jj = 0; jj < J; ++jj) { q[jj] = f4zero(); s[jj] = f4zero(); }
+        for (int jj = 0; jj < J; ++jj) {
+            q[jj] = MODE == kFwdPartB ? reinterpret_cast<const float4 *>(a.P + (size_t)r * KPW)[jj * LPN + l] : f4zero();
+            s[jj] = f4zero();
+        }
         float lin = 0.f;
         if (HOT && !FMHIP_EXP_NO_HOT) {
             if (hot_plain) hot_prologue<LPN, J, !PACKED, false>(xh, vh, wh, l, q, s, lin);
@@ -670,11 +698,62 @@ hipError_t fwd_launch(const FwdArgs &a, hipStream_t s, int *n_partials) {
     return hipGetLastError();
 }
 
+// The two passes of the pipelined schedule's forward (Kp <= 64).  Pass A is the training forward's own choice of kernel (w-tile
+// or plain, with the hot-block prologue) minus the LDS V-tile variant; pass B — the few cold entries of a row — is the plain
+// kernel without a prologue (the dense hot block's ids are the most frequent ones: all below any cut).
+template <int LPN, int J, int MODE>
+hipError_t fwd_launch_pass(const FwdArgs &a0, hipStream_t s, int *n_partials) {
+    if constexpr (LPN * J > 16) {
+        return hipErrorInvalidValue;
+    } else {
+        FwdArgs a = a0;
+        if (MODE == kFwdPartB) { a.hot_T = 0; a.variant = 0; }
+        if (a.variant == 20) a.variant = a.hot_T ? 60 : 0;
+        const FwdPlan pl = fwd_plan<LPN, J>(a);
+        if (n_partials) *n_partials = pl.blocks;
+        const dim3 g((unsigned)pl.blocks), b(kBlock);
+        const bool buf = a.v_bytes != 0;
+        if constexpr (MODE == kFwdPartA) {
+            if (pl.var == 60) {
+                const size_t lds_bytes = (size_t)a.wt_rows * sizeof(float);
+                if (a.hot_T) {
+                    if (buf) hipLaunchKernelGGL((k_forward_wt<LPN, J, MODE, true, true>), g, b, lds_bytes, s, a);
+                    else hipLaunchKernelGGL((k_forward_wt<LPN, J, MODE, true, false>), g, b, lds_bytes, s, a);
+                } else {
+                    if (buf) hipLaunchKernelGGL((k_forward_wt<LPN, J, MODE, false, true>), g, b, lds_bytes, s, a);
+                    else hipLaunchKernelGGL((k_forward_wt<LPN, J, MODE, false, false>), g, b, lds_bytes, s, a);
+                }
+                return hipGetLastError();
+            }
+            if (a.hot_T) {
+                if (a.pack_k >= 0) {
+                    if (buf) hipLaunchKernelGGL((k_forward<LPN, J, MODE, true, true, true>), g, b, 0, s, a);
+                    else hipLaunchKernelGGL((k_forward<LPN, J, MODE, true, true, false>), g, b, 0, s, a);
+                } else {
+                    if (buf) hipLaunchKernelGGL((k_forward<LPN, J, MODE, false, true, true>), g, b, 0, s, a);
+                    else hipLaunchKernelGGL((k_forward<LPN, J, MODE, false, true, false>), g, b, 0, s, a);
+                }
+                return hipGetLastError();
+            }
+        }
+        if (a.pack_k >= 0) {
+            if (buf) hipLaunchKernelGGL((k_forward<LPN, J, MODE, true, false, true>), g, b, 0, s, a);
+            else hipLaunchKernelGGL((k_forward<LPN, J, MODE, true, false, false>), g, b, 0, s, a);
+        } else {
+            if (buf) hipLaunchKernelGGL((k_forward<LPN, J, MODE, false, false, true>), g, b, 0, s, a);
+            else hipLaunchKernelGGL((k_forward<LPN, J, MODE, false, false, false>), g, b, 0, s, a);
+        }
+        return hipGetLastError();
+    }
+}
+
 template <int LPN, int J>
 hipError_t fwd_dispatch(FwdMode mode, const FwdArgs &a, hipStream_t s, int *n_partials) {
     switch (mode) {
         case kFwdTrain: return fwd_launch<LPN, J, kFwdTrain>(a, s, n_partials);
         case kFwdResidual: return fwd_launch<LPN, J, kFwdResidual>(a, s, n_partials);
+        case kFwdPartA: return fwd_launch_pass<LPN, J, kFwdPartA>(a, s, n_partials);
+        case kFwdPartB: return fwd_launch_pass<LPN, J, kFwdPartB>(a, s, n_partials);
         default: return fwd_launch<LPN, J, kFwdQ>(a, s, n_partials);
     }
 }

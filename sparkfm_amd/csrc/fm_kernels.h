@@ -40,7 +40,12 @@ int forward_blocks(int Kp, int64_t n_rows);
 int forward_blocks_lds(int64_t n_rows);           // grid of the LDS V-tile forward
 int forward_blocks_wt(int Kp, int64_t n_rows, int occ_cap = 0);    // grid of the w-tile forward
 
-enum FwdMode { kFwdTrain = 0, kFwdResidual = 1, kFwdQ = 2 };
+// kFwdPartA / kFwdPartB: the training forward in two passes over a row's entries [row_ptr, row_split) and [row_split, row_end)
+// (the pipelined data-parallel schedule, fmhip_comm.hip: the rows' entries are partitioned at the top cut of the plan; pass A —
+// every feature below the cut — runs while the coldest slice of the previous step is still on the wire, pass B adds the cold
+// features' terms once their rows are final and finishes the row).  A leaves the row's raw q in its P row and {sum_f s_f, linear
+// term} in part_sl; B starts from them.  Kp <= 64 only.
+enum FwdMode { kFwdTrain = 0, kFwdResidual = 1, kFwdQ = 2, kFwdPartA = 3, kFwdPartB = 4 };
 
 struct FwdArgs {
     const int64_t *row_ptr;  // global CSR offsets (device), indexed row0 + r
@@ -53,6 +58,8 @@ struct FwdArgs {
     const float *w0;  // [1]
     int64_t row0;
     int64_t nz0;           // row_ptr[row0]: the batch's first entry (k_forward / k_forward_wt walk 32-bit positions relative to it)
+    const int64_t *row_split;  // kFwdPartA / kFwdPartB: where a row's entries of features >= the cut begin (global offsets, indexed row0 + r)
+    float *part_sl;            // kFwdPartA writes, kFwdPartB reads: [rows][2] = {sum over factors of s_f, linear term} of pass A
     const int32_t *order;  // [n_rows] batch-local row ids, longest row first (NULL = 0, 1, 2, ..)
     int32_t n_rows;
     float *P;     // train: [rows][Kp] = e*q ; q-mode: [rows][Kp] = q

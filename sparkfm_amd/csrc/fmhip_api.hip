@@ -610,6 +610,14 @@ int fmhip_step_forward(fmhip_model_t m, fmhip_dataset_t d, int64_t batch) {
     return step_forward(m, d, batch);
 }
 
+int fmhip_step_forward_pass(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, int pass) {
+    WriteLock lock(m);
+    TRY(check_train(m, d));
+    TRY(check_batch(d, batch));
+    if (pass != 0 && pass != 1) return fail(FMHIP_ERR_INVALID, "pass must be 0 (features below the cut) or 1 (the others, and the row's finish)");
+    return step_forward_pass(m, d, batch, pass);
+}
+
 int fmhip_step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, int64_t feat_lo, int64_t feat_hi, int finish) {
     WriteLock lock(m);
     TRY(check_train(m, d));

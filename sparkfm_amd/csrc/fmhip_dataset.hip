@@ -964,6 +964,47 @@ int fmhip_dataset_hot_pages(fmhip_dataset_t d, int32_t *n_pages, int32_t *n_ids,
     return FMHIP_OK;
 }
 
+// one thread per row: the entries of features below `cut` first, then the others, each group in its stored order
+__global__ __launch_bounds__(256) void k_row_partition(const int64_t *row_ptr, int64_t n_rows, const int32_t *col, const float *val, int32_t cut,
+                                                       int32_t *col_out, float *val_out, int64_t *split) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    const int64_t p0 = row_ptr[r], p1 = row_ptr[r + 1];
+    int64_t h = p0;
+    for (int64_t p = p0; p < p1; ++p)
+        if (col[p] < cut) { col_out[h] = col[p]; val_out[h] = val[p]; ++h; }
+    split[r] = h;
+    for (int64_t p = p0; p < p1; ++p)
+        if (col[p] >= cut) { col_out[h] = col[p]; val_out[h] = val[p]; ++h; }
+}
+
+// Stable partition of every row's stored entries at feature id `cut` (the two-pass forward, fm_kernels.h kFwdPartA / B).  Only
+// the order of a row's entries in the CSR stream changes — the transposes, the dense hot block and every result up to the order
+// of the forward's fp32 sums stay what they were.  Not to be called while another thread trains or scores with this dataset.
+int fmhip_dataset_partition_rows(fmhip_dataset_t d, int64_t cut_feature) {
+    if (!d) return fail(FMHIP_ERR_INVALID, "dataset is NULL");
+    if (cut_feature < 0) return fail(FMHIP_ERR_INVALID, "negative feature id");
+    TRY(set_device(d->device));
+    const int32_t cut = (int32_t)std::min<int64_t>(cut_feature, INT32_MAX);
+    if (d->split_cut == cut) return FMHIP_OK;
+    const int64_t nnz_s = d->nnz_sparse;
+    int rc = d->row_split.ensure((size_t)std::max<int64_t>(d->n_rows, 1));
+    if (rc) return rc;
+    DevBuf<int32_t> col2;
+    DevBuf<float> val2;
+    if ((rc = col2.alloc((size_t)std::max<int64_t>(nnz_s, 1))) || (rc = val2.alloc((size_t)std::max<int64_t>(nnz_s, 1)))) return rc;
+    if (d->n_rows > 0) {
+        hipLaunchKernelGGL(k_row_partition, dim3((unsigned)((d->n_rows + 255) / 256)), dim3(256), 0, nullptr, d->row_ptr.p, d->n_rows, d->col.p, d->val.p,
+                           cut, col2.p, val2.p, d->row_split.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(d->col.p, col2.p, (size_t)nnz_s * sizeof(int32_t), hipMemcpyDeviceToDevice, nullptr));
+        HIP_TRY(hipMemcpyAsync(d->val.p, val2.p, (size_t)nnz_s * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+    }
+    d->split_cut = cut;
+    return FMHIP_OK;
+}
+
 int fmhip_dataset_band_plan(fmhip_dataset_t d, int64_t *n_ranges, int64_t *planned_ranges, int64_t *band_affine_ranges) {
     if (!d) return fail(FMHIP_ERR_INVALID, "dataset is NULL");
     int64_t all = 0, planned = 0, affine = 0;

@@ -135,6 +135,10 @@ struct fmhip_dataset {
     DevBuf<uint32_t> crow;
     DevBuf<float> cval;
     DevBuf<int32_t> row_order;   // per batch: its rows' local ids sorted by stored length, longest first (forward walk order)
+    // two-pass forward (fmhip_dataset_partition_rows): every row's stored entries stably partitioned at feature id
+    // split_cut — [row_ptr[r], row_split[r]) hold the features below it, [row_split[r], row_ptr[r+1]) the others
+    DevBuf<int64_t> row_split;
+    int64_t split_cut = -1;      // -1: not partitioned
     DevBuf<int32_t> cfeat, cptr, range_seg, split_seg, split_short, cdst, mp_feat, mp_ptr;
     // per batch: bitmap over the feature ids [0, dimension] of the rows whose gradient the FIXUP launch assembles (cut
     // columns, hot block) — the merged finish lets those update themselves and skips them in its dense pass
@@ -197,6 +201,7 @@ struct fmhip_model {
     const fmhip::host::GradView *view = nullptr;   // set around a backward that writes elsewhere (see GradView)
     bool grad_dirty = false;      // holds a gradient that has not been applied/zeroed
     DevBuf<float> P, e, part, pieces, hot_part;
+    DevBuf<float> part_sl;        // two-pass forward: pass A's {sum_f s_f, linear term} per row
     bool hot_pending = false;   // the dense hot block's gradient of the current step is still to be formed
     DevBuf<double> acc;           // {sum e, sum e^2, rows, nonfinite}
     DevBuf<double> bsum;          // k_forward's per-block statistic partials
@@ -267,6 +272,8 @@ struct FusedPlan {
     double sv_out = 1.0, sw_out = 1.0;    // the tables' scales after the step
     FusedUpd upd{};
 };
+// the training forward in two passes (pass 0 = A: features below the dataset's split cut; pass 1 = B: the others + the row's finish)
+int step_forward_pass(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int pass);
 int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo, int64_t feat_hi, bool finish, double *acc,
                   const FusedPlan *fused = nullptr, bool ascending = false);
 // forward + backward + fixup of one batch into the packed gradient (fused: straight into the parameters)

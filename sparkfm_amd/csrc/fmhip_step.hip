@@ -195,6 +195,41 @@ int step_forward(fmhip_model_t m, fmhip_dataset_t d, int64_t b) {
     return FMHIP_OK;
 }
 
+// The training forward in two passes over every row's entries (FwdMode kFwdPartA / kFwdPartB; the dataset's rows are partitioned
+// at split_cut).  Pass A touches nothing but P / part_sl — in the pipelined data-parallel schedule the coldest slice of the
+// previous step's gradient is still being exchanged in place while it runs — pass B is where the step's state changes as after
+// step_forward.  A then B = the forward, up to the order of the fp32 sums (A's terms first).
+int step_forward_pass(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int pass) {
+    const BatchMeta &bm = d->batches[(size_t)b];
+    if (d->split_cut < 0) return fail(FMHIP_ERR_INVALID, "the dataset's rows are not partitioned (fmhip_dataset_partition_rows)");
+    if (m->Kp > 64) return fail(FMHIP_ERR_UNSUPPORTED, "the two-pass forward serves models of up to 64 padded factors (this one: %d)", m->Kp);
+    TRY(ensure_workspace(m, d));
+    TRY(m->part_sl.ensure((size_t)std::max<int64_t>(d->max_rows, 1) * 2));
+    FwdArgs a = fwd_args(m, d, bm);
+    a.row_split = d->row_split.p;
+    a.part_sl = m->part_sl.p;
+    if (pass == 0) {
+        a.bsum = nullptr;
+        ProfScope ps(m, FMHIP_K_FORWARD, bm.nnz_total, bm.rows);
+        HIP_TRY(launch_forward(m->Kp, kFwdPartA, a, m->stream, nullptr));
+        return FMHIP_OK;
+    }
+    if (m->grad_dirty) {
+        HIP_TRY(hipMemsetAsync(m->grad, 0, m->grad_floats() * sizeof(float), m->stream));
+        m->grad_dirty = false;
+    }
+    {
+        ProfScope ps(m, FMHIP_K_FORWARD, 0, bm.rows);
+        HIP_TRY(launch_forward(m->Kp, kFwdPartB, a, m->stream, &m->fwd_parts));
+    }
+    m->grad_dirty = true;
+    m->last_nnz = bm.nnz_total;
+    m->last_rows = bm.rows;
+    m->bw_next_hi = INT64_MAX;
+    m->hot_pending = d->hot_T > 0;
+    return FMHIP_OK;
+}
+
 // gradient rows of the dense hot block (whole batch; they do not depend on the feature interval, so
 // the first backward call of a step forms them and every later interval finds them complete): the
 // work rides in that call's backward and fixup launches

@@ -1278,3 +1278,61 @@ def test_the_residual_rides_in_the_p_row_exactly(fmhip, k, flat):
     assert np.array_equal(got.view(np.uint32), e.view(np.uint32)), int((got.view(np.uint32) != e.view(np.uint32)).sum())
     ds.unpersist()
     fm.close()
+
+
+@pytest.mark.parametrize("k,hot", [(32, 1), (32, 0), (16, 1), (64, 1), (5, 0)])
+def test_two_pass_forward_equals_the_forward(fmhip, k, hot):
+    """fmhip_dataset_partition_rows + fmhip_step_forward_pass (pass 0: the features below a cut, pass 1: the others and the row's
+    finish) against fmhip_step_forward: the same residual statistics and the same gradient up to the order of the forward's fp32
+    sums, for a cut in the middle, a cut at 0 (everything in pass 1), a cut above every id (everything in pass 0), padded and
+    unpadded and packed rows, with and without the dense hot block — and against the fp64 oracle."""
+    import ctypes as C
+    import torch
+    from sparkfm_amd import _ffi, synth
+    from sparkfm_amd.distributed import HipEngine
+    L = _ffi.load()
+    _ffi.check(L.fmhip_tune(5, hot))
+    try:
+        n1 = 900
+        d = synth.make_zipf(515 + k, 6000, n1, 3, 28, zipf_s=1.05)
+        rng = np.random.default_rng(k)
+        a = dict(n1=n1, k=k, row_ptr=d["row_ptr"], col=d["col"], val=d["val"].astype(np.float64), y=d["y"].astype(np.float64),
+                 w0=0.1, w=rng.normal(0, 0.05, n1), v=rng.normal(0, 0.05, (k, n1)))
+        ds, fm = make(fmhip, a, batch_rows=3000, stream=torch_stream())
+        assert (ds.layout()["hot_pages"] > 0) == bool(hot)
+        eng = HipEngine(fm, ds)
+        ogv, ogw, og0, osse, _ = oracle.batch_grad(a["w0"], a["w"], a["v"], 3000, 6000, a["row_ptr"], a["col"], a["val"], a["y"], threads=8)
+        head = 32
+
+        def grad_of(run):
+            eng.grad.zero_()
+            torch.cuda.synchronize()
+            _ffi.check(L.fmhip_grad_bind(fm.handle, C.c_void_p(eng.grad.data_ptr())))
+            run()
+            torch.cuda.synchronize()
+            return eng.grad.clone().cpu().numpy().astype(np.float64)
+
+        def two_pass():
+            _ffi.check(L.fmhip_step_forward_pass(fm.handle, ds.handle, 1, 0))
+            _ffi.check(L.fmhip_step_forward_pass(fm.handle, ds.handle, 1, 1))
+            eng.backward(1, 0, n1, finish=True)
+
+        want = grad_of(lambda: eng.compute(1))
+        assert L.fmhip_step_forward_pass(fm.handle, ds.handle, 1, 0) != 0 and b"not partitioned" in L.fmhip_last_error()
+        for cut in (120, 0, n1, 7):
+            _ffi.check(L.fmhip_dataset_partition_rows(ds.handle, cut))
+            plain = grad_of(lambda: eng.compute(1))                  # the plain forward over the re-ordered rows: the same sums, another order
+            got = grad_of(two_pass)
+            scale = np.abs(want[head:]).max()
+            for name, g in (("plain", plain), ("two-pass", got)):
+                assert np.abs(g[head:] - want[head:]).max() <= 2e-5 * scale, (name, cut, float(np.abs(g[head:] - want[head:]).max() / scale))
+                np.testing.assert_allclose(g[:2], want[:2], rtol=2e-5, atol=1e-4, err_msg="%s %d" % (name, cut))   # sum e, sum e^2
+                assert g[2] == 3000.0
+            assert abs(got[1] - osse) <= 1e-5 * osse
+        gv, gw, _, _ = fm.batchGradient(ds, 1)
+        check_grad(gv, gw, ogv, ogw, np.abs(a["v"]).max())
+        eng.close()
+        ds.unpersist()
+        fm.close()
+    finally:
+        _ffi.check(L.fmhip_tune(5, 1))
