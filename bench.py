@@ -744,7 +744,7 @@ def main():
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"],
                     help="rccl: the library's own communicator (fmhip_dp_step); torch: torch.distributed all-reduce "
                          "orchestrated from Python (sparkfm_amd.distributed.DataParallelSGD)")
-    ap.add_argument("--dp-exchange", default="auto", choices=["auto", "dense", "sharded", "touched"],
+    ap.add_argument("--dp-exchange", default="auto", choices=["auto", "dense", "sharded", "touched", "pipelined"],
                     help="what a data-parallel step exchanges (fmhip_dp_exchange): dense = the whole packed gradient all-reduced in "
                          "overlapped slices, every rank updates every row; sharded = the slices reduce-scattered, every rank updates its "
                          "1/N share, the updated rows all-gathered; touched = only the rows some rank touched; auto = touched for C5 "
@@ -945,6 +945,16 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
         else:
             _ffi.check(L.fmhip_sgd_step(hm, hd, j % nb, args.eta, regs[0], regs[1], regs[2], None))
 
+    def steps_run(j0, n):
+        """Steps j0 .. j0 + n - 1.  The pipelined exchange takes them in ONE call (fmhip_dp_steps: it overlaps each step's last
+        slice with the next position's forward and has to know that position); everything else steps one by one."""
+        if exchange == "rccl" and dp.exchange == "pipelined" and n > 0:
+            pos = np.ascontiguousarray([(j0 + j) % nb for j in range(n)], np.int64)
+            _ffi.check(L.fmhip_dp_steps(hm, hd, _ffi.ptr(pos), n, comm.handle, args.eta, regs[0], regs[1], regs[2]))
+        else:
+            for j in range(j0, j0 + n):
+                step(j)
+
     def sync():
         _ffi.check(L.fmhip_synchronize(hm))
         torch.cuda.synchronize()
@@ -952,8 +962,7 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
     def barrier():
         ctl.barrier()
 
-    for j in range(args.warmup):
-        step(j)
+    steps_run(0, args.warmup)
     sync()
     barrier()
     tuning = None
@@ -961,7 +970,7 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
         # measure, don't guess: the best cut — and whether the sharded update pays — depends on the collectives' real
         # bandwidth on this node.  Candidates are timed for 4 steps each; the ranks agree through a max-reduce.
         tuning = []
-        modes = ("dense", "sharded") if args.dp_exchange == "auto" and dp.exchange != "touched" else (dp.exchange,)
+        modes = ("dense", "sharded", "pipelined") if args.dp_exchange == "auto" and dp.exchange != "touched" else (dp.exchange,)
         cands = ((0.3,), (0.2,), (0.12, 0.4), (0.08, 0.25, 0.5), (0.05, 0.15, 0.3, 0.55), (0.04, 0.1, 0.2, 0.35, 0.6), ())
         if dp.exchange == "touched":
             # the compact gradient's slices overlap the backward as the dense one's do; with one rank there is nothing to hide
@@ -978,8 +987,7 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
                 sync()
                 barrier()
                 t0 = time.perf_counter()
-                for j in range(4):
-                    step(j)
+                steps_run(0, 4)
                 sync()
                 tt = ctl.allreduce([time.perf_counter() - t0], "max")
                 tuning.append({"exchange": mode, "upper_fractions": list(cand), "cuts": list(dp.cuts), "ms_per_step": tt[0] / 4 * 1e3})
@@ -997,8 +1005,7 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
     sync()
     barrier()
     t0 = time.perf_counter()
-    for j in range(args.warmup, args.warmup + args.steps):
-        step(j)
+    steps_run(args.warmup, args.steps)
     enqueue_s = time.perf_counter() - t0          # what the HOST needed to queue the steps (it must stay ahead of the GPU)
     sync()
     barrier()
@@ -1009,8 +1016,7 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
     if comm is not None:
         # the exchange's own timers (a dozen event records per step) run in a short pass of their own, not in the timed region
         _ffi.check(L.fmhip_comm_profile_begin(comm.handle))
-        for j in range(12):
-            step(j)
+        steps_run(0, 12)
         sync()
         cp = _ffi.CommProfile()
         _ffi.check(L.fmhip_comm_profile_end(comm.handle, C.byref(cp)))
@@ -1029,8 +1035,7 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
         sync()
         n_done, t0 = 0, time.perf_counter()
         while True:
-            for j in range(4 * nb):
-                step(n_done + j)
+            steps_run(n_done, 4 * nb)
             n_done += 4 * nb
             sync()
             dt = time.perf_counter() - t0

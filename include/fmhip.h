@@ -391,6 +391,15 @@ int fmhip_device_write(void *device_dst, const void *host_src, size_t bytes, voi
 #define FMHIP_EXCHANGE_DENSE 0
 #define FMHIP_EXCHANGE_TOUCHED 1
 #define FMHIP_EXCHANGE_SHARDED 2
+/*   FMHIP_EXCHANGE_PIPELINED the dense exchange, CONSECUTIVE STEPS OVERLAPPED: the intervals go from feature 0 up — the small hot
+ *                           slices leave first and are updated as they arrive, the large cold slice leaves last — and while that one
+ *                           travels the NEXT position's forward runs over every feature below the top cut (the two-pass forward,
+ *                           fmhip_step_forward_pass; fmhip_dp_plan's top cut is where the run partitions the rows' entries).  When the
+ *                           slice has arrived its rows are updated and the second pass finishes the rows.  The same sums and the same
+ *                           update as the dense mode (the forward's fp32 sums in another order); needs at least one cut and a model of
+ *                           up to 64 padded factors (else: the dense step).  The overlap needs the next position: fmhip_dp_epoch /
+ *                           _epoch_order / fmhip_dp_steps have it, a single fmhip_dp_step(_at) is the same step without it. */
+#define FMHIP_EXCHANGE_PIPELINED 3
 int fmhip_dp_exchange(fmhip_comm_t c, int mode);
 int fmhip_dp_exchange_info(fmhip_comm_t c, int *mode, int64_t *id_slots_per_rank, double *mean_union_rows);
 /* Chooses the feature ids that cut the backward into intervals and broadcasts them from rank 0 (collective).
@@ -421,6 +430,11 @@ int fmhip_dp_epoch_order(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, dou
 /* what the last fmhip_dp_plan agreed over all ranks: the lock-step steps of an epoch (the largest batch count of any rank)
  * and the largest mini-batch (rows) */
 int fmhip_dp_plan_info(fmhip_comm_t c, int64_t *steps, int64_t *max_batch_rows);
+/* `n` steps in one call, at the named positions of the lock-step schedule (every rank the same list): what a caller that knows
+ * its next steps hands the pipelined exchange, which overlaps each step's last slice with the next position's forward; in the
+ * other modes the same as n calls of fmhip_dp_step_at. */
+int fmhip_dp_steps(fmhip_model_t m, fmhip_dataset_t d, const int64_t *positions, int64_t n, fmhip_comm_t c, double eta, double reg0,
+                   double regw, double regv);
 /* device time of the exchange as the compute stream saw it (HIP events, summed over the steps since
  * _begin): exposed_ms = time the update waited for the last collective after the backward had finished;
  * comm_ms = busy time of the collectives on their own stream; bytes = payload all-reduced per rank */

@@ -34,7 +34,7 @@ SYMBOLS = (
     "fmhip_dp_exchange", "fmhip_dp_exchange_info", "fmhip_comm_emulate_ranks", "fmhip_model_tune", "fmhip_dataset_band_plan",
     "fmhip_dp_step_at", "fmhip_dp_epoch_order", "fmhip_dp_plan_info", "fmhip_dataset_als_levels",
     "fmhip_feature_counts_gpu", "fmhip_rank_from_counts_gpu", "fmhip_relabel_columns_gpu", "fmhip_comm_emulate_load", "fmhip_comm_selftest",
-    "fmhip_dataset_partition_rows", "fmhip_step_forward_pass",
+    "fmhip_dataset_partition_rows", "fmhip_step_forward_pass", "fmhip_dp_steps",
 )
 UNIQUE_ID_BYTES = 128
 
@@ -64,7 +64,8 @@ class DatasetOpts(C.Structure):
 CollectiveFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 COLL_SUM_F32, COLL_MAX_I64, COLL_BCAST0_I64, COLL_ALLGATHER_I32, COLL_REDUCE_SCATTER_F32, COLL_ALLGATHER_F32 = 0, 1, 2, 3, 4, 5
 EXCHANGE_DENSE, EXCHANGE_TOUCHED, EXCHANGE_SHARDED = 0, 1, 2
-EXCHANGE_MODES = {"dense": EXCHANGE_DENSE, "touched": EXCHANGE_TOUCHED, "sharded": EXCHANGE_SHARDED}
+EXCHANGE_PIPELINED = 3
+EXCHANGE_MODES = {"dense": EXCHANGE_DENSE, "touched": EXCHANGE_TOUCHED, "sharded": EXCHANGE_SHARDED, "pipelined": EXCHANGE_PIPELINED}
 
 
 class CommProfile(C.Structure):
@@ -155,6 +156,7 @@ def load():
     L.fmhip_comm_selftest.argtypes = [vp, P(C.c_int)]
     L.fmhip_dataset_partition_rows.argtypes = [vp, i64]
     L.fmhip_step_forward_pass.argtypes = [vp, vp, i64, C.c_int]
+    L.fmhip_dp_steps.argtypes = [vp, vp, vp, i64, vp, dbl, dbl, dbl, dbl]
     L.fmhip_dp_plan.argtypes = [vp, vp, vp, C.c_int, vp, vp]
     L.fmhip_dp_step.argtypes = [vp, vp, i64, vp, dbl, dbl, dbl, dbl]
     L.fmhip_dp_epoch.argtypes = [vp, vp, vp, dbl, dbl, dbl, dbl, P(Stats)]

@@ -240,6 +240,8 @@ constexpr int kProfColl = 2 * (kMaxCuts + 1) + 2;     // sharded mode: a reduce-
 constexpr int kProfSteps = 32;                        // steps a profiling pass can record (later ones go unrecorded)
 struct CommProf {
     hipEvent_t wait_a = nullptr, wait_b = nullptr;   // compute stream: around its wait for the last collective
+    hipEvent_t top_a = nullptr, top_b = nullptr;     // pipelined mode: around the wait for the PREVIOUS step's top slice (has_top)
+    bool has_top = false;
     hipEvent_t c0[kProfColl] = {}, c1[kProfColl] = {};         // comm stream: around each collective
     hipEvent_t a0[kMaxCuts + 1] = {}, a1[kMaxCuts + 1] = {};   // compute stream: around each interval's update
     int n_coll = 0, n_apply = 0;
@@ -299,7 +301,7 @@ struct fmhip_comm {
 namespace {
 
 void destroy_events(CommProf &p) {
-    for (hipEvent_t e : {p.wait_a, p.wait_b})
+    for (hipEvent_t e : {p.wait_a, p.wait_b, p.top_a, p.top_b})
         if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < kProfColl; ++i)
         for (hipEvent_t e : {p.c0[i], p.c1[i]})
@@ -313,6 +315,8 @@ void destroy_events(CommProf &p) {
 int create_events(CommProf &p) {
     hipError_t e = hipEventCreate(&p.wait_a);
     if (e == hipSuccess) e = hipEventCreate(&p.wait_b);
+    if (e == hipSuccess) e = hipEventCreate(&p.top_a);
+    if (e == hipSuccess) e = hipEventCreate(&p.top_b);
     for (int i = 0; i < kProfColl && e == hipSuccess; ++i) {
         e = hipEventCreate(&p.c0[i]);
         if (e == hipSuccess) e = hipEventCreate(&p.c1[i]);
@@ -330,6 +334,7 @@ CommProf *next_prof(fmhip_comm_t c) {
     if (!c->profiling || c->prof_next >= c->prof.size()) return nullptr;
     CommProf *p = &c->prof[c->prof_next++];
     p->used = true;
+    p->has_top = false;
     p->n_coll = p->n_apply = 0;
     return p;
 }
@@ -750,6 +755,92 @@ int dp_step_dense(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_
     return FMHIP_OK;
 }
 
+// ---- FMHIP_EXCHANGE_PIPELINED: the dense exchange with the NEXT step's forward under the coldest slice
+// The dense schedule leaves the wire idle while the forward runs (no gradient row exists before every row's residual does) and
+// the GPU idle while the last slices travel.  Here the intervals go from feature 0 UP: the small hot slices leave first and are
+// applied as they arrive, the large cold slice (most of the bytes, a few per cent of the nonzeros) leaves last — and while it
+// travels the forward of the NEXT position runs over every feature below the top cut (pass A of the two-pass forward, fm_kernels.h;
+// the rows' entries are partitioned at that cut).  When the slice has arrived its rows are updated, pass B adds the cold
+// features' terms and finishes the rows, and the next backward starts.  Same sums, same update as the dense mode; the forward's
+// fp32 sums in another order.  The run knows its positions (an epoch, fmhip_dp_steps); a single fmhip_dp_step is the same step
+// without the overlap.
+//   compute  A(t0) | B | bwd 0 | bwd 1 .. | bwd T | wait 0 apply 0 .. | A(t1) | wait T apply T | B | bwd 0 ...
+//   comm           |B|      | slice 0 | slice 1 ..      | slice T ...............|       |B| | slice 0 ..
+int dp_run_pipelined(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, const int64_t *batches, int64_t n, double eta, double reg0, double regw,
+                     double regv) {
+    std::vector<int64_t> edge{0};
+    for (int64_t x : c->cuts)
+        if (x > edge.back() && x < m->n1) edge.push_back(x);
+    edge.push_back(m->n1);
+    const int n_int = (int)edge.size() - 1, T = n_int - 1;
+    if (n_int < 2 || m->Kp > 64) {      // nothing to pipeline: the dense step (the same collectives on every rank: cuts and width are agreed)
+        for (int64_t t = 0; t < n; ++t) TRY(dp_step_dense(m, d, batches[t], c, eta, reg0, regw, regv));
+        return FMHIP_OK;
+    }
+    bool any_live = false;
+    for (int64_t t = 0; t < n; ++t) any_live = any_live || batches[t] >= 0;
+    if (any_live && d->split_cut != edge[(size_t)T]) TRY(fmhip_dataset_partition_rows(d, edge[(size_t)T]));   // local: no collective inside
+    TRY(fold_scales(m));                 // pass A of the next step runs before the last interval's update: the tables stay at scale 1
+    for (int64_t t = 0; t < n; ++t) {
+        const int64_t b = batches[t];
+        const bool live = b >= 0;
+        float *rows_t = c->rows_dev + (t & 1);          // |B| of this step (the previous step's is still needed by its last update)
+        CommProf *pr = next_prof(c);
+        if (t == 0 && live) TRY(step_forward_pass(m, d, b, 0));
+        if (t > 0) {
+            // the coldest slice of the previous step: arrived -> its rows, and w0 (the statistics came with slice 0)
+            if (pr) HIP_TRY(hipEventRecord(pr->top_a, m->stream));
+            HIP_TRY(hipStreamWaitEvent(m->stream, c->ev_done[T], 0));
+            if (pr) { HIP_TRY(hipEventRecord(pr->top_b, m->stream)); pr->has_top = true; }
+            TRY(step_apply_interval(m, eta, reg0, regw, regv, edge[(size_t)T], edge[(size_t)T + 1], c->rows_dev + ((t - 1) & 1), true));
+        }
+        hipLaunchKernelGGL(k_set_float, dim3(1), dim3(1), 0, m->stream, rows_t, live ? (float)d->batches[(size_t)b].rows : 0.f);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev_rows, m->stream));
+        HIP_TRY(hipStreamWaitEvent(c->cs, c->ev_rows, 0));
+        TRY(collective(c, rows_t, 1, FMHIP_COLL_SUM_F32, c->cs));
+        if (live) {
+            TRY(step_forward_pass(m, d, b, 1));
+        } else {
+            HIP_TRY(hipMemsetAsync(m->grad, 0, m->grad_floats() * sizeof(float), m->stream));
+            m->grad_dirty = true;
+            m->last_nnz = m->last_rows = 0;
+        }
+        for (int i = 0; i < n_int; ++i) {
+            const int64_t lo = edge[(size_t)i], hi = edge[(size_t)i + 1];
+            const bool head = i == 0;                    // the lowest interval carries the statistics scalars
+            if (live) TRY(step_backward(m, d, b, lo, hi, head, nullptr, nullptr, true));
+            const Region reg[3] = {{m->GV() + (size_t)lo * m->Kp, (size_t)(hi - lo) * m->Kp},
+                                   {head ? m->grad : m->Gw() + lo, (size_t)(hi - lo) + (head ? (size_t)kGradHead : 0)},
+                                   {m->Gb() + lo, (size_t)(hi - lo)}};
+            TRY(reduce_regions(m, c, reg, 3, c->ev_ready[i], c->ev_done[i], pr));
+        }
+        m->bw_next_hi = -1;
+        if (pr) HIP_TRY(hipEventRecord(pr->wait_a, m->stream));
+        // every interval but the top one is updated as its slice arrives (small ones share the next one's launch)
+        int64_t pend_lo = -1;
+        for (int i = 0; i < T; ++i) {
+            const int64_t lo = edge[(size_t)i], hi = edge[(size_t)i + 1];
+            if (pend_lo < 0) pend_lo = lo;
+            HIP_TRY(hipStreamWaitEvent(m->stream, c->ev_done[i], 0));
+            if (i < T - 1 && (hi - pend_lo) * 8 < m->n1) continue;
+            if (pr) HIP_TRY(hipEventRecord(pr->a0[pr->n_apply++], m->stream));
+            TRY(step_apply_interval(m, eta, reg0, regw, regv, pend_lo, hi, rows_t, false));
+            if (pr) HIP_TRY(hipEventRecord(pr->a1[pr->n_apply - 1], m->stream));
+            pend_lo = -1;
+        }
+        if (pr) HIP_TRY(hipEventRecord(pr->wait_b, m->stream));
+        if (t + 1 < n) {
+            // ... and the next position's pass A beside the top slice (its rows are the only ones not final yet)
+            if (batches[t + 1] >= 0) TRY(step_forward_pass(m, d, batches[t + 1], 0));
+        } else {
+            HIP_TRY(hipStreamWaitEvent(m->stream, c->ev_done[T], 0));
+            TRY(step_apply_interval(m, eta, reg0, regw, regv, edge[(size_t)T], edge[(size_t)T + 1], rows_t, true));
+        }
+    }
+    return FMHIP_OK;
+}
+
 // rounds the shares of [0, n+1) for `world` ranks: every interval edge is a multiple of world, the top one rounded UP
 // (into the zero rows kept behind the tables, fmhip_model::kSlackRows)
 inline int64_t shard_top(fmhip_model_t m, int W) { return (m->n1 + W - 1) / W * W; }
@@ -881,6 +972,7 @@ int dp_step_mode(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t
     switch (c->exchange) {
         case FMHIP_EXCHANGE_TOUCHED: return dp_step_touched(m, d, batch, c, eta, reg0, regw, regv, position);
         case FMHIP_EXCHANGE_SHARDED: return dp_step_sharded(m, d, batch, c, eta, reg0, regw, regv);
+        case FMHIP_EXCHANGE_PIPELINED: return dp_run_pipelined(m, d, c, &batch, 1, eta, reg0, regw, regv);
         default: return dp_step_dense(m, d, batch, c, eta, reg0, regw, regv);
     }
 }
@@ -895,6 +987,30 @@ int dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, d
     const int rc = dp_step_mode(m, d, -1, c, eta, reg0, regw, regv, position);     // keep in step with the peers: contribute zeros
     if (rc != FMHIP_OK) return rc;
     return fail(pre, "%s (this rank contributed zeros to the step)", why.c_str());
+}
+
+// `n` positions of the lock-step schedule in one call.  The pipelined mode overlaps consecutive steps; the other modes step one
+// by one.  A position whose batch fails a local check contributes zeros (as in dp_step) and the error is reported afterwards.
+int dp_run(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, const int64_t *positions, int64_t n, double eta, double reg0, double regw, double regv) {
+    const int64_t nb = (int64_t)d->batches.size();
+    if (c->exchange != FMHIP_EXCHANGE_PIPELINED) {
+        for (int64_t j = 0; j < n; ++j) TRY(dp_step(m, d, positions[j] < nb ? positions[j] : -1, c, eta, reg0, regw, regv, positions[j]));
+        return FMHIP_OK;
+    }
+    std::vector<int64_t> batches((size_t)n);
+    int pre = FMHIP_OK;
+    std::string why;
+    for (int64_t j = 0; j < n; ++j) {
+        batches[(size_t)j] = positions[j] < nb ? positions[j] : -1;
+        const int rc = local_checks(m, d, batches[(size_t)j], c, false);
+        if (rc != FMHIP_OK) {
+            if (pre == FMHIP_OK) { pre = rc; why = fmhip_last_error(); }
+            batches[(size_t)j] = -1;
+        }
+    }
+    TRY(dp_run_pipelined(m, d, c, batches.data(), n, eta, reg0, regw, regv));
+    if (pre != FMHIP_OK) return fail(pre, "%s (this rank contributed zeros to those steps)", why.c_str());
+    return FMHIP_OK;
 }
 
 }  // namespace
@@ -1122,7 +1238,7 @@ int fmhip_comm_emulate_ranks(fmhip_comm_t c, int ranks) {
 
 int fmhip_dp_exchange(fmhip_comm_t c, int mode) {
     if (!c) return fail(FMHIP_ERR_INVALID, "communicator is NULL");
-    if (mode != FMHIP_EXCHANGE_DENSE && mode != FMHIP_EXCHANGE_TOUCHED && mode != FMHIP_EXCHANGE_SHARDED)
+    if (mode != FMHIP_EXCHANGE_DENSE && mode != FMHIP_EXCHANGE_TOUCHED && mode != FMHIP_EXCHANGE_SHARDED && mode != FMHIP_EXCHANGE_PIPELINED)
         return fail(FMHIP_ERR_INVALID, "unknown exchange mode %d", mode);
     if (mode == FMHIP_EXCHANGE_SHARDED && c->world > fmhip_model::kSlackRows)
         return fail(FMHIP_ERR_UNSUPPORTED, "the sharded exchange supports up to %d ranks", fmhip_model::kSlackRows);
@@ -1234,6 +1350,17 @@ int fmhip_dp_step_at(fmhip_model_t m, fmhip_dataset_t d, int64_t position, fmhip
     return dp_step(m, d, position < (int64_t)d->batches.size() ? position : -1, c, eta, reg0, regw, regv, position);
 }
 
+int fmhip_dp_steps(fmhip_model_t m, fmhip_dataset_t d, const int64_t *positions, int64_t n, fmhip_comm_t c, double eta, double reg0, double regw,
+                   double regv) {
+    WriteLock lock(m);
+    TRY(check_comm(m, c));
+    TRY(check_train(m, d));
+    if (n < 0 || (n > 0 && !positions)) return fail(FMHIP_ERR_INVALID, "positions is NULL or n < 0");
+    for (int64_t j = 0; j < n; ++j)
+        if (positions[j] < 0) return fail(FMHIP_ERR_INVALID, "positions[%lld] = %lld: a position is >= 0", (long long)j, (long long)positions[j]);
+    return dp_run(m, d, c, positions, n, eta, reg0, regw, regv);
+}
+
 static int dp_epoch(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double eta, double reg0, double regw, double regv,
                     const int64_t *order, int64_t n_order, fmhip_stats *stats) {
     TRY(check_comm(m, c));
@@ -1270,9 +1397,10 @@ static int dp_epoch(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double e
                         c->tsteps.size(), (long long)steps);
         c->t_cursor = 0;
     }
-    for (int64_t j = 0; j < steps; ++j) {
-        const int64_t p = order ? order[j] : j;
-        TRY(dp_step(m, d, p < nb ? p : -1, c, eta, reg0, regw, regv, p));
+    {
+        std::vector<int64_t> pos((size_t)steps);
+        for (int64_t j = 0; j < steps; ++j) pos[(size_t)j] = order ? order[j] : j;
+        TRY(dp_run(m, d, c, pos.data(), steps, eta, reg0, regw, regv));
     }
     if (stats) {
         memset(stats, 0, sizeof *stats);
@@ -1337,6 +1465,7 @@ int fmhip_comm_profile_end(fmhip_comm_t c, fmhip_comm_profile *p) {
         // what the compute stream spent between its last backward and the end of the step, minus the updates themselves
         // (dense mode; the sharded mode's updates run on a stream of their own and what is left of them counts as exposed)
         if (hipEventElapsedTime(&ms, r.wait_a, r.wait_b) == hipSuccess) p->exposed_ms += ms;
+        if (r.has_top && hipEventElapsedTime(&ms, r.top_a, r.top_b) == hipSuccess) p->exposed_ms += ms;   // pipelined: the previous step's top slice
         for (int i = 0; i < r.n_apply; ++i)
             if (hipEventElapsedTime(&ms, r.a0[i], r.a1[i]) == hipSuccess) p->exposed_ms -= ms;
         for (int i = 0; i < r.n_coll; ++i)

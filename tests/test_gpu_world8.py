@@ -69,6 +69,22 @@ def test_eight_ranks_dense_and_sharded(tmp_path, exchange, fractions):
             assert seg.reshape(steps, -1).sum(axis=1).tolist() == [101 * 32] * steps
 
 
+@pytest.mark.parametrize("fractions,shuffle,stepwise,k", [([0.3], None, False, 32), ([0.05, 0.15, 0.3, 0.55], 11, False, 32), ([0.2, 0.5], None, True, 16),
+                                                       ([0.3], 5, False, 64), ([], None, False, 32)])
+def test_eight_ranks_pipelined(tmp_path, fractions, shuffle, stepwise, k):
+    """FMHIP_EXCHANGE_PIPELINED with 8 ranks: intervals from feature 0 up, every step's top slice exchanged beside the next
+    position's pass-A forward (fmhip_dp_epoch / _epoch_order), a rank without rows, ranks that run out of batches at different
+    steps, a permuted order, step by step through fmhip_dp_step_at (the same step without the overlap), no cut at all (the dense
+    step) — replicas bit-identical, the same collectives on all 8 ranks, the fp64 oracle matched (S/fm/lib/ALS.scala:153)."""
+    s = run_case(case8(exchange="pipelined", fractions=fractions, shuffle_seed=shuffle, stepwise=stepwise, k=k), tmp_path)
+    assert s["world"] == 8 and s["steps"] == 4
+    assert s["rel_err_v"] <= 1e-5 and s["rel_err_w"] <= 1e-5
+    calls = np.array(s["calls"], np.int64).reshape(-1, 2)
+    n_int = len([c for c in s["cuts"] if c > 0]) + 1
+    sums = calls[calls[:, 0] == 0]
+    assert len(sums) == 2 * 4 * (1 + (1 if n_int == 1 else 3 * n_int))        # per step: |B|, then three regions per interval
+
+
 @pytest.mark.parametrize("n1", [803, 50_003])
 def test_eight_ranks_touched_rows(tmp_path, n1):
     """The touched-rows exchange with 8 ranks: cap x 8 id slots per planned step, the union of eight batches' rows, one compact

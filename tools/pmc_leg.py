@@ -25,7 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("workload", choices=["c3", "c2", "c5hbm", "c4"])
     ap.add_argument("--upper-fractions", default="0.05,0.15,0.3,0.55", help="c4: the cuts of the backward ('none' = one interval)")
-    ap.add_argument("--dp-exchange", default="dense", choices=["dense", "sharded"])
+    ap.add_argument("--dp-exchange", default="dense", choices=["dense", "sharded", "pipelined"])
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--rows", type=int, default=0)
