@@ -968,7 +968,7 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
     tuning = None
     if exchange == "rccl" and args.upper_fractions == "auto" and (world > 1 or args.emulate_allreduce or dp.exchange == "touched"):
         # measure, don't guess: the best cut — and whether the sharded update pays — depends on the collectives' real
-        # bandwidth on this node.  Candidates are timed for 4 steps each; the ranks agree through a max-reduce.
+        # bandwidth on this node.  Candidates are timed for 8 steps each; the ranks agree through a max-reduce.
         tuning = []
         modes = ("dense", "sharded", "pipelined") if args.dp_exchange == "auto" and dp.exchange != "touched" else (dp.exchange,)
         cands = ((0.3,), (0.2,), (0.12, 0.4), (0.08, 0.25, 0.5), (0.05, 0.15, 0.3, 0.55), (0.04, 0.1, 0.2, 0.35, 0.6), ())
@@ -980,17 +980,21 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
             cands = ((0.12, 0.4), ())        # a rehearsal of the flow: every step moves the whole gradient through the host
         for mode in modes:
             dp.set_exchange(mode)
-            for cand in cands:
+            mode_cands = cands
+            if mode == "pipelined" and args.transport == "rccl":
+                # the pipelined schedule likes finer cuts (its wire idles only until the first, cheapest interval is walked)
+                mode_cands = tuple(c_ for c_ in cands if len(c_) >= 2) + ((0.03, 0.07, 0.13, 0.22, 0.35, 0.6), (0.02, 0.05, 0.1, 0.17, 0.27, 0.4, 0.6))
+            for cand in mode_cands:
                 dp.upper_fractions = cand
                 dp.plan(fm, ds)
                 step(0)
                 sync()
                 barrier()
                 t0 = time.perf_counter()
-                steps_run(0, 4)
+                steps_run(0, 8)          # (8: a pipelined run's first forward pass and last slice are not overlapped with anything)
                 sync()
                 tt = ctl.allreduce([time.perf_counter() - t0], "max")
-                tuning.append({"exchange": mode, "upper_fractions": list(cand), "cuts": list(dp.cuts), "ms_per_step": tt[0] / 4 * 1e3})
+                tuning.append({"exchange": mode, "upper_fractions": list(cand), "cuts": list(dp.cuts), "ms_per_step": tt[0] / 8 * 1e3})
         best = min(tuning, key=lambda x: x["ms_per_step"])
         dp.set_exchange(best["exchange"])
         dp.upper_fractions = tuple(best["upper_fractions"])

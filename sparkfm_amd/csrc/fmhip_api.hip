@@ -633,7 +633,7 @@ int fmhip_step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, int64
         const int64_t want = m->bw_next_hi == INT64_MAX ? 0 : m->bw_next_hi;
         if (feat_lo != want)
             return fail(FMHIP_ERR_INVALID, "feature intervals must tile [0, n+1) in ascending order (expected lo = %lld, got %lld)", (long long)want, (long long)feat_lo);
-        TRY(step_backward(m, d, batch, feat_lo, feat_hi, finish != 0, nullptr, nullptr, true));
+        TRY(step_backward(m, d, batch, feat_lo, feat_hi, finish != 0, nullptr, nullptr, kOwnUpper));
         m->bw_next_hi = feat_hi >= m->n1 ? -1 : feat_hi;
         return FMHIP_OK;
     }

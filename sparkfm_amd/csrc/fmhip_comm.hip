@@ -757,15 +757,15 @@ int dp_step_dense(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_
 
 // ---- FMHIP_EXCHANGE_PIPELINED: the dense exchange with the NEXT step's forward under the coldest slice
 // The dense schedule leaves the wire idle while the forward runs (no gradient row exists before every row's residual does) and
-// the GPU idle while the last slices travel.  Here the intervals go from feature 0 UP: the small hot slices leave first and are
-// applied as they arrive, the large cold slice (most of the bytes, a few per cent of the nonzeros) leaves last — and while it
-// travels the forward of the NEXT position runs over every feature below the top cut (pass A of the two-pass forward, fm_kernels.h;
-// the rows' entries are partitioned at that cut).  When the slice has arrived its rows are updated, pass B adds the cold
+// the GPU idle while the last slices travel.  Here the COLDEST interval (most of the bytes, a few per cent of the nonzeros) is
+// walked and sent LAST, the others before it from the second-coldest down to feature 0 and updated as they arrive — and while
+// the coldest slice travels the forward of the NEXT position runs over every feature below the top cut (pass A of the two-pass
+// forward, fm_kernels.h; the rows' entries are partitioned at that cut).  When the slice has arrived its rows are updated, pass B adds the cold
 // features' terms and finishes the rows, and the next backward starts.  Same sums, same update as the dense mode; the forward's
 // fp32 sums in another order.  The run knows its positions (an epoch, fmhip_dp_steps); a single fmhip_dp_step is the same step
 // without the overlap.
-//   compute  A(t0) | B | bwd 0 | bwd 1 .. | bwd T | wait 0 apply 0 .. | A(t1) | wait T apply T | B | bwd 0 ...
-//   comm           |B|      | slice 0 | slice 1 ..      | slice T ...............|       |B| | slice 0 ..
+//   compute  A(t0) | B | bwd T-1 | .. bwd 0 | bwd T | wait, apply T-1 .. 0 | A(t1) | wait T apply T | B | bwd T-1 ...
+//   comm           |B|        | slice T-1 | .. slice 0    | slice T ............|       |B|   | slice T-1 ..
 int dp_run_pipelined(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, const int64_t *batches, int64_t n, double eta, double reg0, double regw,
                      double regv) {
     std::vector<int64_t> edge{0};
@@ -806,10 +806,14 @@ int dp_run_pipelined(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, const i
             m->grad_dirty = true;
             m->last_nnz = m->last_rows = 0;
         }
-        for (int i = 0; i < n_int; ++i) {
+        // the order of the intervals: the second-coldest first (little work, many bytes: the wire starts early), down to feature
+        // 0, the coldest last (it travels beside the next position's pass A).  Who walks a straddling range: whoever comes first
+        for (int o = 0; o < n_int; ++o) {
+            const int i = o < T ? T - 1 - o : T;
             const int64_t lo = edge[(size_t)i], hi = edge[(size_t)i + 1];
             const bool head = i == 0;                    // the lowest interval carries the statistics scalars
-            if (live) TRY(step_backward(m, d, b, lo, hi, head, nullptr, nullptr, true));
+            const int own = i == T ? 0 : (i == T - 1 ? (kOwnLower | kOwnUpper) : kOwnLower);
+            if (live) TRY(step_backward(m, d, b, lo, hi, head, nullptr, nullptr, own));
             const Region reg[3] = {{m->GV() + (size_t)lo * m->Kp, (size_t)(hi - lo) * m->Kp},
                                    {head ? m->grad : m->Gw() + lo, (size_t)(hi - lo) + (head ? (size_t)kGradHead : 0)},
                                    {m->Gb() + lo, (size_t)(hi - lo)}};
@@ -818,16 +822,16 @@ int dp_run_pipelined(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, const i
         m->bw_next_hi = -1;
         if (pr) HIP_TRY(hipEventRecord(pr->wait_a, m->stream));
         // every interval but the top one is updated as its slice arrives (small ones share the next one's launch)
-        int64_t pend_lo = -1;
-        for (int i = 0; i < T; ++i) {
+        int64_t pend_hi = -1;
+        for (int i = T - 1; i >= 0; --i) {
             const int64_t lo = edge[(size_t)i], hi = edge[(size_t)i + 1];
-            if (pend_lo < 0) pend_lo = lo;
+            if (pend_hi < 0) pend_hi = hi;
             HIP_TRY(hipStreamWaitEvent(m->stream, c->ev_done[i], 0));
-            if (i < T - 1 && (hi - pend_lo) * 8 < m->n1) continue;
+            if (i > 0 && (pend_hi - lo) * 8 < m->n1) continue;
             if (pr) HIP_TRY(hipEventRecord(pr->a0[pr->n_apply++], m->stream));
-            TRY(step_apply_interval(m, eta, reg0, regw, regv, pend_lo, hi, rows_t, false));
+            TRY(step_apply_interval(m, eta, reg0, regw, regv, lo, pend_hi, rows_t, false));
             if (pr) HIP_TRY(hipEventRecord(pr->a1[pr->n_apply - 1], m->stream));
-            pend_lo = -1;
+            pend_hi = -1;
         }
         if (pr) HIP_TRY(hipEventRecord(pr->wait_b, m->stream));
         if (t + 1 < n) {

@@ -272,10 +272,14 @@ struct FusedPlan {
     double sv_out = 1.0, sw_out = 1.0;    // the tables' scales after the step
     FusedUpd upd{};
 };
+// Which of the two ranges that straddle a feature interval's edges a step_backward call walks: a straddling range belongs to
+// whichever of its two intervals is walked FIRST (the other one's fixup then finds its partials).  Descending calls own their
+// lower edge, ascending calls their upper one; a schedule that mixes the orders says so per call.
+enum { kOwnLower = 1, kOwnUpper = 2 };
 // the training forward in two passes (pass 0 = A: features below the dataset's split cut; pass 1 = B: the others + the row's finish)
 int step_forward_pass(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int pass);
 int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo, int64_t feat_hi, bool finish, double *acc,
-                  const FusedPlan *fused = nullptr, bool ascending = false);
+                  const FusedPlan *fused = nullptr, int own = kOwnLower);
 // forward + backward + fixup of one batch into the packed gradient (fused: straight into the parameters)
 int step_compute(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double *acc, const FusedPlan *fused = nullptr);
 // can this step's update run inside the fixup launch / the column walk?  (fills *p; false: a launch of its own, step_apply)

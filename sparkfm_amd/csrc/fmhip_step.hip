@@ -260,12 +260,12 @@ void hot_attach(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm, BwdArgs
 // in it produce G rows / head partials that the call covering them consumes later), the range
 // holding the first entry of feat_hi is left to the call that covers feat_hi.  `finish` adds the
 // residual-statistics reduction (once per step, with the last interval).
-// `ascending`: the caller's intervals come from feature 0 UP (the hot ids first: the pipelined data-parallel schedule sends the
-// small hot slices first and the large cold one last, beside the next forward).  A range that straddles two intervals is then
-// walked with the LOWER one — the mirror of the rule above; what a range does never depends on which call walks it, so the
-// gradient is the same bits in either order.
+// `own` (kOwnLower | kOwnUpper): which straddling ranges this call walks.  A range that straddles two intervals goes with the
+// one walked FIRST — descending callers own their lower edge (the rule above), ascending callers their upper one, and the
+// pipelined data-parallel schedule (second-coldest interval first, then down to feature 0, the coldest last) says it per call.
+// What a range does never depends on which call walks it, so the gradient is the same bits in any order.
 int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo, int64_t feat_hi, bool finish,
-                  double *acc, const FusedPlan *fused, bool ascending) {
+                  double *acc, const FusedPlan *fused, int own) {
     const BatchMeta &bm = d->batches[(size_t)b];
     BwdArgs ba = bwd_args(m, d, b);
     if (fused) {
@@ -348,13 +348,11 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
     const int32_t s_lo = (int32_t)(std::lower_bound(hf, hf + bm.n_cols, (int32_t)std::min<int64_t>(feat_lo, INT32_MAX)) - hf);
     const int32_t s_hi = (int32_t)(std::lower_bound(hf, hf + bm.n_cols, (int32_t)std::min<int64_t>(feat_hi, INT32_MAX)) - hf);
     const int32_t e_lo = hp[s_lo], e_hi = hp[s_hi];            // entry interval of the columns
-    if (ascending) {
-        ba.rho_lo = (e_lo + kRangeLen - 1) / kRangeLen;               // the range holding entry e_lo - 1 went with the interval below
-        ba.rho_hi = s_hi >= bm.n_cols ? bm.n_ranges : (e_hi + kRangeLen - 1) / kRangeLen;
-    } else {
-        ba.rho_lo = e_lo / kRangeLen;
-        ba.rho_hi = s_hi >= bm.n_cols ? bm.n_ranges : e_hi / kRangeLen;   // the straddling range goes to the next interval
-    }
+    // lower edge owned: from the range holding entry e_lo; else from the first range that starts at or after it (the range
+    // holding entry e_lo - 1 goes with the interval below).  Upper edge likewise.
+    ba.rho_lo = (own & kOwnLower) ? e_lo / kRangeLen : (e_lo + kRangeLen - 1) / kRangeLen;
+    ba.rho_hi = s_hi >= bm.n_cols ? bm.n_ranges : ((own & kOwnUpper) ? (e_hi + kRangeLen - 1) / kRangeLen : e_hi / kRangeLen);
+    if (ba.rho_hi < ba.rho_lo) ba.rho_hi = ba.rho_lo;                  // (an interval inside one range that a neighbour owns)
     if (banded) {
         // every run of the plan holds ascending range ids: the part of it inside [rho_lo, rho_hi) is one sub-run
         for (int x = 0; x < kXcds; ++x)
