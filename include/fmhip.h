@@ -391,14 +391,15 @@ int fmhip_device_write(void *device_dst, const void *host_src, size_t bytes, voi
 #define FMHIP_EXCHANGE_DENSE 0
 #define FMHIP_EXCHANGE_TOUCHED 1
 #define FMHIP_EXCHANGE_SHARDED 2
-/*   FMHIP_EXCHANGE_PIPELINED the dense exchange, CONSECUTIVE STEPS OVERLAPPED: the intervals go from feature 0 up — the small hot
- *                           slices leave first and are updated as they arrive, the large cold slice leaves last — and while that one
- *                           travels the NEXT position's forward runs over every feature below the top cut (the two-pass forward,
- *                           fmhip_step_forward_pass; fmhip_dp_plan's top cut is where the run partitions the rows' entries).  When the
- *                           slice has arrived its rows are updated and the second pass finishes the rows.  The same sums and the same
- *                           update as the dense mode (the forward's fp32 sums in another order); needs at least one cut and a model of
- *                           up to 64 padded factors (else: the dense step).  The overlap needs the next position: fmhip_dp_epoch /
- *                           _epoch_order / fmhip_dp_steps have it, a single fmhip_dp_step(_at) is the same step without it. */
+/*   FMHIP_EXCHANGE_PIPELINED the dense exchange, CONSECUTIVE STEPS OVERLAPPED: the coldest interval (most of the bytes, a few per cent
+ *                           of the work) is walked and sent LAST — the others before it, from the second-coldest down to feature 0,
+ *                           updated as they arrive — and while that slice travels the NEXT position's forward runs over every
+ *                           feature below the top cut (the two-pass forward, fmhip_step_forward_pass; the run partitions the rows'
+ *                           entries at fmhip_dp_plan's top cut).  When the slice has arrived its rows are updated and the second
+ *                           pass finishes the rows.  The same sums and the same update as the dense mode (the forward's fp32 sums in
+ *                           another order); needs at least one cut and a model of up to 64 padded factors (else: the dense step).
+ *                           The overlap needs the next position: fmhip_dp_epoch / _epoch_order / fmhip_dp_steps have it, a single
+ *                           fmhip_dp_step(_at) is the same step without it. */
 #define FMHIP_EXCHANGE_PIPELINED 3
 int fmhip_dp_exchange(fmhip_comm_t c, int mode);
 int fmhip_dp_exchange_info(fmhip_comm_t c, int *mode, int64_t *id_slots_per_rank, double *mean_union_rows);

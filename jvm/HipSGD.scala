@@ -39,7 +39,9 @@ class HipSGD protected (eta: Double, reg0: Double, regw: Double, regv: Double, b
   /** what a data-parallel step exchanges: 0 = the dense gradient, all-reduced in slices under the backward, every rank
     * applying the identical update (default: the faster of the two dense modes in every schedule measured so far —
     * DESIGN.md section 7; bench.py times both on the node it runs on); 2 = the same reduce-scattered, every rank updating
-    * its share; 1 = only the rows some rank touched (models far wider than a global batch) */
+    * its share; 1 = only the rows some rank touched (models far wider than a global batch); 3 = the dense exchange with
+    * consecutive steps overlapped (the coldest slice travels beside the next position's forward: 14 % faster than 0 against
+    * emulated 8 x 300 GB/s collectives, slower where the step is compute-bound — bench.py times it with the others) */
   var exchange: Int = 0
   /** visit the mini-batches in a seeded random order, a fresh permutation per epoch (None = ascending).  Data-parallel: every
     * rank draws the SAME permutation of the epoch's positions (fmhip_dp_epoch_order) */

@@ -82,7 +82,8 @@ int main(void) {
     CHECK(fmhip_comm_create_external(NULL, 0, 1, NULL, NULL, NULL) == FMHIP_ERR_INVALID);
     CHECK(fmhip_dp_exchange(NULL, FMHIP_EXCHANGE_TOUCHED) == FMHIP_ERR_INVALID);
     CHECK(fmhip_dataset_hot_pages(NULL, NULL, NULL, NULL, NULL) == FMHIP_ERR_INVALID);
-    CHECK(FMHIP_HOT_PAGES * 16 <= 128 && FMHIP_COLL_ALLGATHER_I32 == 3 && FMHIP_COLL_ALLGATHER_F32 == 5 && FMHIP_EXCHANGE_SHARDED == 2);
+    CHECK(FMHIP_HOT_PAGES * 16 <= 128 && FMHIP_COLL_ALLGATHER_I32 == 3 && FMHIP_COLL_ALLGATHER_F32 == 5 && FMHIP_EXCHANGE_SHARDED == 2 && FMHIP_EXCHANGE_PIPELINED == 3);
+    CHECK(fmhip_dp_steps(NULL, NULL, NULL, 0, NULL, 0.1, 0, 0, 0) == FMHIP_ERR_INVALID && fmhip_dataset_partition_rows(NULL, 0) == FMHIP_ERR_INVALID);
     printf("c_abi_smoke ok (fmhip %d)\n", fmhip_version());
     return 0;
 }

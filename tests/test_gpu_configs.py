@@ -460,7 +460,60 @@ def _oracle_two_rank_epochs(n1=800):
     return w0, w, v
 
 
-@pytest.mark.parametrize("exchange", ["dense", "sharded"])
+@pytest.mark.parametrize("k", [32, 16, 64])
+def test_pipelined_exchange_one_rank_over_rccl(fmhip, k):
+    """FMHIP_EXCHANGE_PIPELINED with one rank over real RCCL (every collective really runs, in place, on the second stream; the
+    comm stream held as a 40 GB/s all-reduce would hold it, with the footprint): fmhip_dp_epoch, fmhip_dp_steps over a list of
+    positions that wraps around the epoch, and single fmhip_dp_step_at calls give the SAME bits (the overlap changes when things
+    run, not what they compute) and match the plain step up to the order of the forward's fp32 sums, and the fp64 oracle."""
+    from sparkfm_amd import _ffi, synth
+    from sparkfm_amd.distributed import HipDataParallelSGD, RcclComm
+    L = _ffi.load()
+    d = synth.make_zipf(93, 5000, 900, 4, 30, zipf_s=1.05)
+    w0, w, v = synth.init_params(6, 900, k, stdev=0.05)
+    w = np.random.default_rng(1).normal(0, 0.05, 900)
+    positions = np.array([0, 1, 2, 3, 2, 0, 3, 1, 1], np.int64)
+    out = {}
+    for mode in ("epoch+steps", "stepwise", "plain"):
+        ds = fmhip.DataSet.from_arrays(d, batch_rows=1500).cache()
+        fm = fmhip.FMModel(899, k)
+        fm.w0, fm.w, fm.v = w0, w, v
+        if mode != "plain":
+            comm = RcclComm(fm, 0, 1).selftest()
+            _ffi.check(L.fmhip_comm_emulate(comm.handle, 40.0))
+            _ffi.check(L.fmhip_comm_emulate_load(comm.handle, 8))
+            dp = HipDataParallelSGD(comm, eta=0.05, regw=1e-3, regv=1e-3, upper_fractions=(0.1, 0.3, 0.6), exchange="pipelined")
+            dp.plan(fm, ds)
+            assert len(dp.cuts) == 3
+            if mode == "epoch+steps":
+                dp.learn(fm, ds)
+                _ffi.check(L.fmhip_dp_steps(fm.handle, ds.handle, _ffi.ptr(positions), len(positions), comm.handle, 0.05, 0.0, 1e-3, 1e-3))
+            else:
+                for p in list(range(4)) + positions.tolist():
+                    dp.step_at(fm, ds, int(p))
+            fm._device_updated()
+            out[mode] = (fm.w0, fm.w.copy(), fm.v.copy())
+            comm.close()
+        else:
+            for p in list(range(4)) + positions.tolist():
+                _ffi.check(L.fmhip_step_compute(fm.handle, ds.handle, int(p)))
+                _ffi.check(L.fmhip_step_apply(fm.handle, 0.05, 0.0, 1e-3, 1e-3))
+            fm._device_updated()
+            out[mode] = (fm.w0, fm.w.copy(), fm.v.copy())
+        ds.unpersist()
+        fm.close()
+    a, b, c = out["epoch+steps"], out["stepwise"], out["plain"]
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert np.linalg.norm(a[2] - c[2]) <= 1e-5 * np.linalg.norm(c[2]) and np.linalg.norm(a[1] - c[1]) <= 1e-5 * np.linalg.norm(c[1])
+    ow0, ow, ov = w0, w.copy(), v.copy()
+    for p in list(range(4)) + positions.tolist():
+        lo, hi = p * 1500, min(5000, (p + 1) * 1500)
+        ow0, ow, ov, _ = oracle.sgd_step(ow0, ow, ov, lo, hi, d["row_ptr"], d["col"], d["val"].astype(np.float64), d["y"].astype(np.float64),
+                                         0.05, 0.0, 1e-3, 1e-3)
+    assert np.linalg.norm(a[2] - ov) <= 1e-5 * np.linalg.norm(ov) and np.linalg.norm(a[1] - ow) <= 1e-5 * np.linalg.norm(ow)
+
+
+@pytest.mark.parametrize("exchange", ["dense", "sharded", "pipelined"])
 @pytest.mark.parametrize("fractions,world", [("", 2), ("0.3", 2), ("0.05,0.15,0.3,0.55", 2), ("0.12,0.4", 3)])
 def test_library_side_exchange_two_ranks_on_one_gpu_host_staged(fractions, world, exchange):
     """The library's data-parallel step with two (three) real ranks on the one GPU of the test box: fmhip_dp_epoch over
@@ -486,7 +539,7 @@ def test_library_side_exchange_two_ranks_on_one_gpu_host_staged(fractions, world
     assert len(r0["cuts"]) == n_cuts and int(r0["steps"]) == 3 and int(r0["rows"]) == 1000      # last global batch: 1000 + 0 rows
     # per epoch: 1 max-reduce (step count + validation); per step: the row count + (1 region, or 3 per interval); per plan: 1 max-reduce + cuts
     sums = r0["calls"][r0["calls"][:, 0] == 0]
-    if exchange == "dense":
+    if exchange in ("dense", "pipelined"):         # pipelined: the same collectives, the coldest interval's last
         per_step = 1 + (1 if n_cuts == 0 else 3 * (n_cuts + 1))
     else:
         # sharded: per interval a reduce-scatter of G_V (kind 4), two all-reduces (G_w with or without the scalars, G_b), an all-gather of V (kind 5)

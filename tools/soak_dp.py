@@ -2,7 +2,7 @@
 """Soak of the data-parallel step: randomly shaped cases — 2 to 8 real ranks on ONE GPU (2-3 as processes over the host-staged
 gloo transport, 4 and 8 as threads of one process over ThreadStagedComm: RCCL refuses two ranks on one device and the test
 pool admits at most 6 processes on the card), uneven and empty shards, model widths from narrower than a batch to far
-wider, 0-4 cuts, the three exchange modes, weight decay on and off, ascending and permuted batch order — each compared
+wider, 0-4 cuts, the four exchange modes, weight decay on and off, ascending and permuted batch order — each compared
 with the fp64 oracle over the equivalent global batches; replicas must agree bit for bit and issue the same collectives.
     python3 tools/soak_dp.py [cases, default 12] [first seed, default 1]"""
 import json
@@ -37,7 +37,7 @@ def make_case(seed):
         rows[int(rng.integers(0, world))] = 900
     hi = int(rng.integers(2, min(n1_data, 40) + 1))
     cfg = dict(seed=int(1000 + seed), rows=rows, n1_data=n1_data, n1=n1, k=int(rng.choice([4, 16, 32, 64])), lo=int(rng.integers(1, hi + 1)), hi=hi,
-               batch_rows=int(rng.choice([64, 300, 1000])), exchange=str(rng.choice(["dense", "sharded", "touched"])),
+               batch_rows=int(rng.choice([64, 300, 1000])), exchange=str(rng.choice(["dense", "sharded", "touched", "pipelined"])),
                fractions=[[], [0.3], [0.1, 0.4], [0.05, 0.15, 0.3, 0.55]][int(rng.integers(0, 4))], epochs=int(rng.choice([1, 2])),
                eta=0.02, regw=float(rng.choice([0.0, 1e-3])), regv=float(rng.choice([0.0, 1e-3])),
                shuffle_seed=None if rng.random() < 0.6 else int(rng.integers(0, 1000)))
