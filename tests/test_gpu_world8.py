@@ -231,10 +231,10 @@ def test_bench_with_eight_thread_ranks():
     assert out["metric"] == "nnz_per_sec_fm_sgd_training" and out["value"] > 0 and out["ms_per_step"] > 0
     assert out["config"]["workload"].startswith("C4") and out["config"]["rows_per_gpu"] == 100000
     x = out["exchange"]
-    assert x["nranks"] == 8 and x["transport"] == "threads" and x["mode"] in ("dense", "sharded")
+    assert x["nranks"] == 8 and x["transport"] == "threads" and x["mode"] in ("dense", "sharded", "pipelined")
     # the communicator passed its self-test on every rank, and after the timed steps the replicas hold the same bits
     assert "passed" in x["selftest"] and x["replicas"]["identical"] is True and x["replicas"]["rows_compared"] > 1000
-    assert {t["exchange"] for t in x["cut_tuning"]} == {"dense", "sharded"} and all(t["ms_per_step"] > 0 for t in x["cut_tuning"])
+    assert {t["exchange"] for t in x["cut_tuning"]} == {"dense", "sharded", "pipelined"} and all(t["ms_per_step"] > 0 for t in x["cut_tuning"])
     assert any(len(t["cuts"]) == 2 and all(c % 8 == 0 for c in t["cuts"]) for t in x["cut_tuning"] if t["exchange"] == "sharded")
     assert x["exposed_comm_ms"] >= 0 and x["comm_busy_ms"] > 0
     assert x["c3_on_every_gpu"]["value"] > 0 and x["per_gpu_without_exchange"]["value"] > 0
