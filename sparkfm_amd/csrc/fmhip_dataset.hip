@@ -997,9 +997,13 @@ int fmhip_dataset_partition_rows(fmhip_dataset_t d, int64_t cut_feature) {
         hipLaunchKernelGGL(k_row_partition, dim3((unsigned)((d->n_rows + 255) / 256)), dim3(256), 0, nullptr, d->row_ptr.p, d->n_rows, d->col.p, d->val.p,
                            cut, col2.p, val2.p, d->row_split.p);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(d->col.p, col2.p, (size_t)nnz_s * sizeof(int32_t), hipMemcpyDeviceToDevice, nullptr));
-        HIP_TRY(hipMemcpyAsync(d->val.p, val2.p, (size_t)nnz_s * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
         HIP_TRY(hipStreamSynchronize(nullptr));
+        // the partitioned copies BECOME the streams (nothing holds the old pointers: every launch takes them from the dataset) — no
+        // copy back, and a failure above leaves the dataset exactly as it was
+        std::swap(d->col.p, col2.p);
+        std::swap(d->col.n, col2.n);
+        std::swap(d->val.p, val2.p);
+        std::swap(d->val.n, val2.n);
     }
     d->split_cut = cut;
     return FMHIP_OK;
