@@ -779,7 +779,16 @@ int dp_run_pipelined(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, const i
     }
     bool any_live = false;
     for (int64_t t = 0; t < n; ++t) any_live = any_live || batches[t] >= 0;
-    if (any_live && d->split_cut != edge[(size_t)T]) TRY(fmhip_dataset_partition_rows(d, edge[(size_t)T]));   // local: no collective inside
+    // the rows' entries partitioned at the top cut: local work (no collective inside) — if it fails here, this rank keeps in step
+    // with zeros, as after any other local failure, and reports afterwards: no peer is left waiting in a collective
+    std::vector<int64_t> zeros;
+    std::string part_err;
+    int part_rc = FMHIP_OK;
+    if (any_live && d->split_cut != edge[(size_t)T] && (part_rc = fmhip_dataset_partition_rows(d, edge[(size_t)T])) != FMHIP_OK) {
+        part_err = fmhip_last_error();
+        zeros.assign((size_t)n, -1);
+        batches = zeros.data();
+    }
     TRY(fold_scales(m));                 // pass A of the next step runs before the last interval's update: the tables stay at scale 1
     for (int64_t t = 0; t < n; ++t) {
         const int64_t b = batches[t];
@@ -842,6 +851,7 @@ int dp_run_pipelined(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, const i
             TRY(step_apply_interval(m, eta, reg0, regw, regv, edge[(size_t)T], edge[(size_t)T + 1], rows_t, true));
         }
     }
+    if (part_rc != FMHIP_OK) return fail(part_rc, "%s (this rank contributed zeros to the run)", part_err.c_str());
     return FMHIP_OK;
 }
 

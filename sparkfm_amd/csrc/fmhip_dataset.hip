@@ -965,17 +965,18 @@ int fmhip_dataset_hot_pages(fmhip_dataset_t d, int32_t *n_pages, int32_t *n_ids,
 }
 
 // one thread per row: the entries of features below `cut` first, then the others, each group in its stored order
-__global__ __launch_bounds__(256) void k_row_partition(const int64_t *row_ptr, int64_t n_rows, const int32_t *col, const float *val, int32_t cut,
-                                                       int32_t *col_out, float *val_out, int64_t *split) {
+// (v64: the fp64 copy of the values a single-batch dataset keeps for the ALS learner, in the same order — it moves with them)
+__global__ __launch_bounds__(256) void k_row_partition(const int64_t *row_ptr, int64_t n_rows, const int32_t *col, const float *val, const double *v64,
+                                                       int32_t cut, int32_t *col_out, float *val_out, double *v64_out, int64_t *split) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n_rows) return;
     const int64_t p0 = row_ptr[r], p1 = row_ptr[r + 1];
     int64_t h = p0;
     for (int64_t p = p0; p < p1; ++p)
-        if (col[p] < cut) { col_out[h] = col[p]; val_out[h] = val[p]; ++h; }
+        if (col[p] < cut) { col_out[h] = col[p]; val_out[h] = val[p]; if (v64) v64_out[h] = v64[p]; ++h; }
     split[r] = h;
     for (int64_t p = p0; p < p1; ++p)
-        if (col[p] >= cut) { col_out[h] = col[p]; val_out[h] = val[p]; ++h; }
+        if (col[p] >= cut) { col_out[h] = col[p]; val_out[h] = val[p]; if (v64) v64_out[h] = v64[p]; ++h; }
 }
 
 // Stable partition of every row's stored entries at feature id `cut` (the two-pass forward, fm_kernels.h kFwdPartA / B).  Only
@@ -992,10 +993,13 @@ int fmhip_dataset_partition_rows(fmhip_dataset_t d, int64_t cut_feature) {
     if (rc) return rc;
     DevBuf<int32_t> col2;
     DevBuf<float> val2;
-    if ((rc = col2.alloc((size_t)std::max<int64_t>(nnz_s, 1))) || (rc = val2.alloc((size_t)std::max<int64_t>(nnz_s, 1)))) return rc;
+    DevBuf<double> v64_2;
+    if ((rc = col2.alloc((size_t)std::max<int64_t>(nnz_s, 1))) || (rc = val2.alloc((size_t)std::max<int64_t>(nnz_s, 1))) ||
+        (d->val64.p && (rc = v64_2.alloc((size_t)std::max<int64_t>(nnz_s, 1)))))
+        return rc;
     if (d->n_rows > 0) {
         hipLaunchKernelGGL(k_row_partition, dim3((unsigned)((d->n_rows + 255) / 256)), dim3(256), 0, nullptr, d->row_ptr.p, d->n_rows, d->col.p, d->val.p,
-                           cut, col2.p, val2.p, d->row_split.p);
+                           d->val64.p, cut, col2.p, val2.p, v64_2.p, d->row_split.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(nullptr));
         // the partitioned copies BECOME the streams (nothing holds the old pointers: every launch takes them from the dataset) — no
@@ -1004,6 +1008,7 @@ int fmhip_dataset_partition_rows(fmhip_dataset_t d, int64_t cut_feature) {
         std::swap(d->col.n, col2.n);
         std::swap(d->val.p, val2.p);
         std::swap(d->val.n, val2.n);
+        if (d->val64.p) { std::swap(d->val64.p, v64_2.p); std::swap(d->val64.n, v64_2.n); }
     }
     d->split_cut = cut;
     return FMHIP_OK;

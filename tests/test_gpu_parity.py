@@ -1336,3 +1336,31 @@ def test_two_pass_forward_equals_the_forward(fmhip, k, hot):
         fm.close()
     finally:
         _ffi.check(L.fmhip_tune(5, 1))
+
+
+def test_partitioned_rows_keep_the_als_learner_right(fmhip):
+    """fmhip_dataset_partition_rows on a single-batch dataset: the fp64 copy of the values the ALS learner reads beside the column
+    ids moves with them — two ALS epochs on partitioned rows equal the oracle's (and the unpartitioned run) to fp64 reassociation."""
+    from sparkfm_amd import _ffi
+    L = _ffi.load()
+    a = random_problem(516, 1200, 100, 5, 0, 12, empty_rows=(3,))
+    rng = np.random.default_rng(4)
+    a["y"] = oracle.predict(0.3, rng.normal(0, 0.3, 100), rng.normal(0, 0.3, (3, 100)), a["row_ptr"], a["col"], a["val"]) + rng.normal(0, 0.05, 1200)
+    out = []
+    for cut in (None, 37):
+        ds, fm = make(fmhip, a)
+        if cut is not None:
+            _ffi.check(L.fmhip_dataset_partition_rows(ds.handle, cut))
+        fm.reg0, fm.regw, fm.regv = 0.0, 0.1, 10.0
+        for _ in range(2):
+            fmhip.HipALS.run().learn(fm, ds)
+        out.append((fm.w0, fm.w.copy(), fm.v.copy()))
+        ds.unpersist()
+        fm.close()
+    w0, w, v = a["w0"], a["w"], a["v"]
+    for _ in range(2):
+        w0, w, v = oracle.als_epoch(w0, w, v, 0.0, 0.1, 10.0, a["row_ptr"], a["col"], a["val"], a["y"])
+    for got in out:
+        np.testing.assert_allclose(got[2], v, rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(got[1], w, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(out[1][2], out[0][2], rtol=1e-10, atol=1e-13)
