@@ -469,7 +469,9 @@ class HipDataParallelSGD(FMLearn):
         self.upper_fractions = tuple(float(f) for f in upper_fractions)
         # "dense": the whole packed gradient all-reduced in overlapped slices, every rank updates every row; "sharded": the
         # slices reduce-scattered, every rank updates its 1/world share, the updated rows all-gathered; "touched": only the
-        # rows some rank's batch touched (fmhip_dp_exchange) — for models far wider than a global batch
+        # rows some rank's batch touched (fmhip_dp_exchange) — for models far wider than a global batch; "pipelined": the dense
+        # exchange with consecutive steps overlapped (the coldest slice travels beside the next position's forward; `learn` and
+        # `steps_at` know the next position, a single `step` / `step_at` is the same step without the overlap)
         self.exchange = exchange
         _ffi.check(_ffi.load().fmhip_dp_exchange(comm.handle, _ffi.EXCHANGE_MODES[exchange]))
         self.cuts = None
@@ -519,6 +521,18 @@ class HipDataParallelSGD(FMLearn):
             self.plan(fm, dataset)
         _ffi.check(_ffi.load().fmhip_dp_step_at(fm.handle, dataset.handle, position, self.comm.handle, self.eta, self.reg0,
                                                 self.regw, self.regv))
+        fm._device_updated()
+
+    def steps_at(self, fm, dataset, positions):
+        """Several global steps in ONE call, at the named positions of the lock-step schedule (every rank the same list;
+        fmhip_dp_steps): what the pipelined exchange needs to overlap each step's last slice with the next position's forward —
+        in the other modes the same as step_at per position."""
+        import numpy as np
+        if self._planned_for != id(dataset):
+            self.plan(fm, dataset)
+        pos = np.ascontiguousarray(positions, np.int64)
+        _ffi.check(_ffi.load().fmhip_dp_steps(fm.handle, dataset.handle, _ffi.ptr(pos), len(pos), self.comm.handle, self.eta, self.reg0,
+                                              self.regw, self.regv))
         fm._device_updated()
 
     def learn(self, fm, dataset, order=None):

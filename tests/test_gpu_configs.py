@@ -487,7 +487,7 @@ def test_pipelined_exchange_one_rank_over_rccl(fmhip, k):
             assert len(dp.cuts) == 3
             if mode == "epoch+steps":
                 dp.learn(fm, ds)
-                _ffi.check(L.fmhip_dp_steps(fm.handle, ds.handle, _ffi.ptr(positions), len(positions), comm.handle, 0.05, 0.0, 1e-3, 1e-3))
+                dp.steps_at(fm, ds, positions)                      # fmhip_dp_steps
             else:
                 for p in list(range(4)) + positions.tolist():
                     dp.step_at(fm, ds, int(p))
