@@ -983,7 +983,10 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
             mode_cands = cands
             if mode == "pipelined" and args.transport == "rccl":
                 # the pipelined schedule likes finer cuts (its wire idles only until the first, cheapest interval is walked)
-                mode_cands = tuple(c_ for c_ in cands if len(c_) >= 2) + ((0.03, 0.07, 0.13, 0.22, 0.35, 0.6), (0.02, 0.05, 0.1, 0.17, 0.27, 0.4, 0.6))
+                # ... or few launches with a small top: the top slice should take about as long on the wire as the next pass A,
+                # the second interval is the cheap one that starts the wire, and every further cut costs a launch of the walk
+                mode_cands = tuple(c_ for c_ in cands if len(c_) >= 2) + ((0.03, 0.07, 0.13, 0.22, 0.35, 0.6), (0.04, 0.1), (0.04, 0.1, 0.3),
+                                                                           (0.05, 0.12, 0.35), (0.04, 0.09, 0.2, 0.5))
             for cand in mode_cands:
                 dp.upper_fractions = cand
                 dp.plan(fm, ds)
