@@ -625,6 +625,45 @@ __global__ __launch_bounds__(kBlock, (LPN * J <= 8 ? FMHIP_FWD_WGS : 1)) void k_
     forward_rows<LPN, J, MODE, false, HOT, true, BUF>(a, wt, vh, wh, hot_plain);
 }
 
+// Pass B of the two-pass forward (kFwdPartB): a row has a handful of cold entries — the features at or above the top cut, a few per
+// cent of the nonzeros — so the generic walk (eight entries per step, the next step's entries requested ahead, 86 registers, five
+// waves per SIMD) is the wrong shape.  Here an 8-lane slot takes a row and its entries ONE AT A TIME (the slot's lanes read the
+// entry's id and value from one address — a broadcast — and 16 B of the V row each); the body is lean enough for more waves, and
+// what pass B waits for is the chain of dependent loads per row (extent, entry, V row; the row's partial q from P), which more rows in
+// flight hide.  Same arithmetic per entry (acc_entry), same finish (row_finish); the linear term's few addends are summed by one lane.
+template <int LPN, int J, bool PACKED>
+__global__ __launch_bounds__(kBlock) void k_forward_pass_b(FwdArgs a) {
+    constexpr int KP = 4 * LPN * J;
+    constexpr int SLOTS = kBlock / LPN;
+    const int l = threadIdx.x & (LPN - 1);
+    const int slot = threadIdx.x / LPN;
+    const float w0 = *a.w0;
+    const int32_t *colb = a.col + a.nz0;
+    const float *valb = a.val + a.nz0;
+    float st1 = 0.f, st2 = 0.f, stbad = 0.f;
+    for (int ri = blockIdx.x * SLOTS + slot; ri < a.n_rows; ri += gridDim.x * SLOTS) {
+        const int r = a.order ? a.order[ri] : ri;
+        const uint32_t p0 = (uint32_t)(a.row_split[a.row0 + r] - a.nz0), p1 = (uint32_t)(a.row_ptr[a.row0 + r + 1] - a.nz0);
+        float4 q[J], s[J];
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) {
+            q[jj] = reinterpret_cast<const float4 *>(a.P + (size_t)r * KP)[jj * LPN + l];
+            s[jj] = f4zero();
+        }
+        float lin = 0.f;
+        for (uint32_t p = p0; p < p1; ++p) {
+            const int c = colb[p];
+            const float x = valb[p];
+            const float4 *vp = reinterpret_cast<const float4 *>(a.V + (size_t)(uint32_t)c * KP) + l;
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) acc_entry(q[jj], s[jj], vp[jj * LPN], x);
+            if (!PACKED && l == 0) lin = fmaf(a.w[c], x, lin);      // (row_finish sums the lanes' linear terms)
+        }
+        row_finish<LPN, J, kFwdPartB, PACKED>(a, r, l, q, s, lin, w0, st1, st2, stbad);
+    }
+    block_stats<kBlock>(a.bsum, st1, st2, stbad);
+}
+
 __global__ __launch_bounds__(kBlock) void k_reduce_blocks(const double *bsum, int32_t nblocks, int32_t n_rows, float *scal,
                                                          double *acc) {
     __shared__ double sh[3][kBlock / 64];
@@ -699,8 +738,8 @@ hipError_t fwd_launch(const FwdArgs &a, hipStream_t s, int *n_partials) {
 }
 
 // The two passes of the pipelined schedule's forward (Kp <= 64).  Pass A is the training forward's own choice of kernel (w-tile
-// or plain, with the hot-block prologue) minus the LDS V-tile variant; pass B — the few cold entries of a row — is the plain
-// kernel without a prologue (the dense hot block's ids are the most frequent ones: all below any cut).
+// or plain, with the hot-block prologue) minus the LDS V-tile variant; pass B — the few cold entries of a row — is
+// k_forward_pass_b (no prologue: the dense hot block's ids are the most frequent ones, all below any cut).
 template <int LPN, int J, int MODE>
 hipError_t fwd_launch_pass(const FwdArgs &a0, hipStream_t s, int *n_partials) {
     if constexpr (LPN * J > 16) {
@@ -713,6 +752,12 @@ hipError_t fwd_launch_pass(const FwdArgs &a0, hipStream_t s, int *n_partials) {
         if (n_partials) *n_partials = pl.blocks;
         const dim3 g((unsigned)pl.blocks), b(kBlock);
         const bool buf = a.v_bytes != 0;
+        if constexpr (MODE == kFwdPartB) {
+            // (the generic walk in this mode, A/B on one box: forward 409 -> 401 us per step, step 1.066 -> 1.058 ms)
+            if (a.pack_k >= 0) hipLaunchKernelGGL((k_forward_pass_b<LPN, J, true>), g, b, 0, s, a);
+            else hipLaunchKernelGGL((k_forward_pass_b<LPN, J, false>), g, b, 0, s, a);
+            return hipGetLastError();
+        } else {
         if constexpr (MODE == kFwdPartA) {
             if (pl.var == 60) {
                 const size_t lds_bytes = (size_t)a.wt_rows * sizeof(float);
@@ -744,6 +789,7 @@ hipError_t fwd_launch_pass(const FwdArgs &a0, hipStream_t s, int *n_partials) {
             else hipLaunchKernelGGL((k_forward<LPN, J, MODE, false, false, false>), g, b, 0, s, a);
         }
         return hipGetLastError();
+        }
     }
 }
 
