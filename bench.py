@@ -1248,6 +1248,11 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
             payload = int(gf.value) * 4
             xc = {"nranks": world, "allreduce_bytes_per_step": payload, "backend": exchange, "transport": args.transport,
                   "mode": dp.exchange if exchange == "rccl" else "dense"}
+            if exchange == "rccl" and dp.exchange == "pipelined":
+                xc["mode_note"] = ("pipelined (FMHIP_EXCHANGE_PIPELINED): the dense exchange with consecutive steps overlapped — the coldest feature "
+                                   "interval is walked and sent last, and while its slice travels the next position's forward runs over every feature "
+                                   "below the top cut (a two-pass forward over rows partitioned at that cut; fmhip_dp_steps hands the library the whole "
+                                   "run of positions); same sums and update as the dense mode, the forward's fp32 sums in another order")
             if exchange == "rccl" and dp.exchange == "touched":
                 info = dp.exchange_info()
                 xc["mode_note"] = ("touched rows (fmhip_dp_exchange): the union of the rows every position's batches touch is planned ONCE "
