@@ -90,14 +90,23 @@ class HipSGD protected (eta: Double, reg0: Double, regw: Double, regv: Double, b
       else {
         val n1 = fm.num_attribute + 1
         val counts = parts.mapPartitions { rows =>
-          // ONE native call per partition: the partition's ids flattened first (a call per row would copy the n1-long
-          // counts array in and out every time)
-          val buf = rows.map { case (_, sv) => java.util.Arrays.copyOf(sv.index, sv.used) }.toArray
-          val flat = new Array[Int](buf.map(_.length.toLong).sum.toInt)
-          var o = 0
-          buf.foreach { a => System.arraycopy(a, 0, flat, o, a.length); o += a.length }
+          // A native call per CHUNK of at most 2^26 ids (not per row: every call copies the n1-long counts array in and
+          // out; not per partition: a partition may hold more than 2^31 - 1 ids, and flattening it whole doubles its
+          // memory).  featureCounts accumulates into `c`, so the chunks just follow each other.
           val c = new Array[Long](n1)
-          HipSGD.featureCounts(flat, n1, c)
+          val chunk = new Array[Int](1 << 26)
+          var o = 0
+          def flush(): Unit = if (o > 0) { HipSGD.featureCounts(java.util.Arrays.copyOf(chunk, o), n1, c); o = 0 }
+          rows.foreach { case (_, sv) =>
+            var i = 0
+            while (i < sv.used) {                  // a row longer than the chunk is cut across calls
+              val n = math.min(sv.used - i, chunk.length - o)
+              System.arraycopy(sv.index, i, chunk, o, n)
+              o += n; i += n
+              if (o == chunk.length) flush()
+            }
+          }
+          flush()
           Iterator(c)
         }.reduce { (a, b) => var i = 0; while (i < a.length) { a(i) += b(i); i += 1 }; a }
         val rank = new Array[Int](n1); val byRank = new Array[Int](n1)

@@ -13,9 +13,9 @@ LIB = os.path.join(LIBDIR, "libfmhip.so")
 SYNTH = os.path.join(LIBDIR, "libfmsynth.so")
 
 HIP_SOURCES = ["fm_forward.hip", "fm_backward.hip", "fm_apply.hip", "als_kernels.hip", "csc_build.hip", "fmhip_api.hip",
-               "fmhip_dataset.hip", "fmhip_step.hip", "fmhip_comm.hip"]
-HIP_DEPS = ["fm_kernels.h", "fm_device.h", "als_kernels.h", "csc_build.h", "fmhip_internal.h",
-            os.path.join("..", "..", "include", "fmhip.h")]
+               "fmhip_dataset.hip", "fmhip_step.hip", "fmhip_comm.hip", "fmhip_host.cpp"]
+HIP_DEPS = ["fm_kernels.h", "fm_constants.h", "fm_device.h", "als_kernels.h", "csc_build.h", "fmhip_internal.h", "fmhip_host.h",
+            os.path.join("..", "..", "include", "fmhip.h"), os.path.join("..", "..", "include", "fmhip_experimental.h")]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 
 
@@ -35,7 +35,7 @@ def build_lib(force=False, verbose=False):
     deps = [os.path.join(CSRC, f) for f in HIP_SOURCES + HIP_DEPS]
     objs, jobs = [], []
     for src in HIP_SOURCES:     # the translation units compile side by side (the two big kernel files take ~25 s each)
-        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, deps):
             cmd = [_hipcc()] + HIPCC_FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]

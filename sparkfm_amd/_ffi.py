@@ -1,4 +1,4 @@
-"""ctypes binding of libfmhip.so — the same C ABI (include/fmhip.h) a JNI shim would bind.
+"""ctypes binding of libfmhip.so — the same C ABI (include/fmhip.h, include/fmhip_experimental.h) a JNI shim would bind.
 
 There is NO CPU fallback: if the HIP library is missing this module raises, loudly.
 """
@@ -13,29 +13,38 @@ K_FORWARD, K_REDUCE, K_BACKWARD, K_FIXUP, K_APPLY, K_COUNT = 0, 1, 2, 3, 4, 5
 KERNEL_NAMES = ("forward", "reduce", "backward", "fixup", "apply")
 RANGE_LEN = 64
 
-# every symbol include/fmhip.h declares (tests check the library exports all of them)
+# every symbol include/fmhip.h declares — the PRODUCT surface (tests check the library exports all of them)
 SYMBOLS = (
-    "fmhip_ablation_mask", "fmhip_version", "fmhip_last_error", "fmhip_device_count", "fmhip_tune",
-    "fmhip_model_create", "fmhip_model_destroy", "fmhip_model_info",
-    "fmhip_model_set_params", "fmhip_model_get_params", "fmhip_model_set_params_f32", "fmhip_model_get_params_f32",
+    "fmhip_version", "fmhip_last_error", "fmhip_device_count",
+    "fmhip_model_create", "fmhip_model_destroy", "fmhip_model_info", "fmhip_model_init_normal",
+    "fmhip_model_set_params", "fmhip_model_get_params", "fmhip_model_get_rows", "fmhip_model_set_params_f32", "fmhip_model_get_params_f32",
     "fmhip_synchronize",
-    "fmhip_dataset_create", "fmhip_dataset_create_f32", "fmhip_dataset_destroy", "fmhip_dataset_info",
-    "fmhip_dataset_batch_info", "fmhip_dataset_get_transpose",
-    "fmhip_predict", "fmhip_rmse", "fmhip_residual", "fmhip_term_q",
+    "fmhip_dataset_create", "fmhip_dataset_create_f32", "fmhip_dataset_create_opts", "fmhip_rows_create", "fmhip_rows_create_f32",
+    "fmhip_dataset_destroy", "fmhip_dataset_info", "fmhip_dataset_batch_info", "fmhip_dataset_get_transpose",
+    "fmhip_predict", "fmhip_predict_rows", "fmhip_rmse", "fmhip_residual", "fmhip_term_q",
     "fmhip_sgd_step", "fmhip_sgd_epoch", "fmhip_batch_grad", "fmhip_als_epoch",
     "fmhip_grad_floats", "fmhip_grad_bind", "fmhip_grad_ptr", "fmhip_grad_layout", "fmhip_step_compute",
-    "fmhip_step_forward", "fmhip_step_backward", "fmhip_step_apply",
-    "fmhip_step_stats", "fmhip_profile_begin", "fmhip_profile_begin_rotating", "fmhip_profile_begin_sampled", "fmhip_profile_end",
-    "fmhip_rows_create", "fmhip_rows_create_f32", "fmhip_predict_rows", "fmhip_model_init_normal", "fmhip_dataset_layout", "fmhip_dataset_create_opts", "fmhip_model_get_rows",
-    "fmhip_comm_unique_id", "fmhip_comm_create", "fmhip_comm_destroy", "fmhip_comm_info", "fmhip_dp_plan",
-    "fmhip_dp_step", "fmhip_dp_epoch", "fmhip_comm_profile_begin", "fmhip_comm_profile_end", "fmhip_shard_rows", "fmhip_comm_emulate",
-    "fmhip_feature_counts", "fmhip_rank_from_counts", "fmhip_relabel_columns", "fmhip_dataset_hot_pages",
-    "fmhip_comm_create_external", "fmhip_stream_wait", "fmhip_device_read", "fmhip_device_write",
-    "fmhip_dp_exchange", "fmhip_dp_exchange_info", "fmhip_comm_emulate_ranks", "fmhip_model_tune", "fmhip_dataset_band_plan",
-    "fmhip_dp_step_at", "fmhip_dp_epoch_order", "fmhip_dp_plan_info", "fmhip_dataset_als_levels",
-    "fmhip_feature_counts_gpu", "fmhip_rank_from_counts_gpu", "fmhip_relabel_columns_gpu", "fmhip_comm_emulate_load", "fmhip_comm_selftest",
-    "fmhip_dataset_partition_rows", "fmhip_step_forward_pass", "fmhip_dp_steps",
+    "fmhip_step_forward", "fmhip_step_backward", "fmhip_step_apply", "fmhip_step_stats",
+    "fmhip_comm_unique_id", "fmhip_comm_create", "fmhip_comm_destroy", "fmhip_comm_info", "fmhip_comm_selftest",
+    "fmhip_dp_exchange", "fmhip_dp_exchange_info", "fmhip_dp_plan", "fmhip_dp_plan_info",
+    "fmhip_dp_step", "fmhip_dp_step_at", "fmhip_dp_steps", "fmhip_dp_epoch", "fmhip_dp_epoch_order", "fmhip_shard_rows",
+    "fmhip_feature_counts", "fmhip_rank_from_counts", "fmhip_relabel_columns",
+    "fmhip_feature_counts_gpu", "fmhip_rank_from_counts_gpu", "fmhip_relabel_columns_gpu",
 )
+# ... and include/fmhip_experimental.h — the measurement / experiment surface (tuning keys, profiling, emulation, layout
+# queries, the two-pass forward on its own, a transport of the caller's own)
+SYMBOLS_EXPERIMENTAL = (
+    "fmhip_ablation_mask", "fmhip_tune", "fmhip_model_tune",
+    "fmhip_profile_begin", "fmhip_profile_begin_rotating", "fmhip_profile_begin_sampled", "fmhip_profile_end",
+    "fmhip_dataset_layout", "fmhip_dataset_hot_pages", "fmhip_dataset_band_plan", "fmhip_dataset_als_levels",
+    "fmhip_dataset_partition_rows", "fmhip_step_forward_pass",
+    "fmhip_comm_create_external", "fmhip_stream_wait", "fmhip_device_read", "fmhip_device_write",
+    "fmhip_comm_profile_begin", "fmhip_comm_profile_end", "fmhip_comm_emulate", "fmhip_comm_emulate_load", "fmhip_comm_emulate_ranks",
+)
+# enum fmhip_tune_key (include/fmhip_experimental.h); TUNE maps the names without their prefix
+(TUNE_FORWARD_KERNEL, TUNE_BACKWARD_KERNEL, TUNE_TILE_ROWS, TUNE_ROW_BLOCK, TUNE_XCD_PLACEMENT, TUNE_HOT_BLOCK, TUNE_FORWARD_OCCUPANCY,
+ TUNE_ROW_ORDER, TUNE_FLAT_ADDRESS, TUNE_LAZY_DECAY, TUNE_FUSED_UPDATE, TUNE_MERGED_FINISH, TUNE_HOT_PAGES) = range(13)
+TUNE = {name[5:]: value for name, value in list(globals().items()) if name.startswith("TUNE_")}
 UNIQUE_ID_BYTES = 128
 
 
@@ -184,14 +193,15 @@ def load():
     L.fmhip_feature_counts_gpu.argtypes = [C.c_int, i64, vp, i64, vp]
     L.fmhip_rank_from_counts_gpu.argtypes = [C.c_int, i64, vp, vp, vp]
     L.fmhip_relabel_columns_gpu.argtypes = [C.c_int, i64, vp, i64, vp, vp]
-    for name in SYMBOLS:
+    for name in SYMBOLS + SYMBOLS_EXPERIMENTAL:
         fn = getattr(L, name)
         if name not in ("fmhip_version", "fmhip_last_error"):
             fn.restype = C.c_int
-    # FMHIP_TUNE="key=value,key=value": experiment knobs (fmhip_tune) applied at load time
+    # FMHIP_TUNE="key=value,key=value": experiment knobs (fmhip_tune) applied at load time; key = a number or a name of
+    # enum fmhip_tune_key without its prefix (flat_address=1)
     for item in filter(None, os.environ.get("FMHIP_TUNE", "").split(",")):
         k, v = item.split("=")
-        L.fmhip_tune(int(k), int(v))
+        L.fmhip_tune(int(k) if k.strip().isdigit() else TUNE[k.strip().upper()], int(v))
     if L.fmhip_ablation_mask() != 0 and not os.environ.get("FMHIP_LIB"):
         raise ImportError("libfmhip.so was built with a timing-only kernel ablation (mask %d): rebuild it without FMHIP_EXP_* flags" % L.fmhip_ablation_mask())
     _lib = L

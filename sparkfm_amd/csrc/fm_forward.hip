@@ -739,25 +739,32 @@ hipError_t fwd_launch(const FwdArgs &a, hipStream_t s, int *n_partials) {
 
 // The two passes of the pipelined schedule's forward (Kp <= 64).  Pass A is the training forward's own choice of kernel (w-tile
 // or plain, with the hot-block prologue) minus the LDS V-tile variant; pass B — the few cold entries of a row — is
-// k_forward_pass_b (no prologue: the dense hot block's ids are the most frequent ones, all below any cut).
+// k_forward_pass_b, without a prologue: the dense hot block's features are the most frequent ones and, with ids ranked by
+// frequency, lie below any cut.  When they do NOT (hashed or field-ordered ids: a feature in a tenth of the rows may carry
+// the highest id) the prologue would read parameter rows at or above the cut in pass A, one update behind — FwdArgs::hot_in_b
+// moves it into pass B, which then takes the generic row walk with the prologue.
 template <int LPN, int J, int MODE>
 hipError_t fwd_launch_pass(const FwdArgs &a0, hipStream_t s, int *n_partials) {
     if constexpr (LPN * J > 16) {
         return hipErrorInvalidValue;
     } else {
         FwdArgs a = a0;
-        if (MODE == kFwdPartB) { a.hot_T = 0; a.variant = 0; }
+        const bool hot_here = a.hot_T && (MODE == kFwdPartB) == (a.hot_in_b != 0);      // the pass that runs the prologue
+        if (!hot_here) a.hot_T = 0;
+        if (MODE == kFwdPartB) a.variant = 0;
         if (a.variant == 20) a.variant = a.hot_T ? 60 : 0;
         const FwdPlan pl = fwd_plan<LPN, J>(a);
         if (n_partials) *n_partials = pl.blocks;
         const dim3 g((unsigned)pl.blocks), b(kBlock);
         const bool buf = a.v_bytes != 0;
         if constexpr (MODE == kFwdPartB) {
-            // (the generic walk in this mode, A/B on one box: forward 409 -> 401 us per step, step 1.066 -> 1.058 ms)
-            if (a.pack_k >= 0) hipLaunchKernelGGL((k_forward_pass_b<LPN, J, true>), g, b, 0, s, a);
-            else hipLaunchKernelGGL((k_forward_pass_b<LPN, J, false>), g, b, 0, s, a);
-            return hipGetLastError();
-        } else {
+            if (!a.hot_T) {
+                // (the generic walk in this mode, A/B on one box: forward 409 -> 401 us per step, step 1.066 -> 1.058 ms)
+                if (a.pack_k >= 0) hipLaunchKernelGGL((k_forward_pass_b<LPN, J, true>), g, b, 0, s, a);
+                else hipLaunchKernelGGL((k_forward_pass_b<LPN, J, false>), g, b, 0, s, a);
+                return hipGetLastError();
+            }
+        }
         if constexpr (MODE == kFwdPartA) {
             if (pl.var == 60) {
                 const size_t lds_bytes = (size_t)a.wt_rows * sizeof(float);
@@ -770,26 +777,28 @@ hipError_t fwd_launch_pass(const FwdArgs &a0, hipStream_t s, int *n_partials) {
                 }
                 return hipGetLastError();
             }
-            if (a.hot_T) {
-                if (a.pack_k >= 0) {
-                    if (buf) hipLaunchKernelGGL((k_forward<LPN, J, MODE, true, true, true>), g, b, 0, s, a);
-                    else hipLaunchKernelGGL((k_forward<LPN, J, MODE, true, true, false>), g, b, 0, s, a);
-                } else {
-                    if (buf) hipLaunchKernelGGL((k_forward<LPN, J, MODE, false, true, true>), g, b, 0, s, a);
-                    else hipLaunchKernelGGL((k_forward<LPN, J, MODE, false, true, false>), g, b, 0, s, a);
-                }
-                return hipGetLastError();
+        }
+        if (a.hot_T) {
+            if (a.pack_k >= 0) {
+                if (buf) hipLaunchKernelGGL((k_forward<LPN, J, MODE, true, true, true>), g, b, 0, s, a);
+                else hipLaunchKernelGGL((k_forward<LPN, J, MODE, true, true, false>), g, b, 0, s, a);
+            } else {
+                if (buf) hipLaunchKernelGGL((k_forward<LPN, J, MODE, false, true, true>), g, b, 0, s, a);
+                else hipLaunchKernelGGL((k_forward<LPN, J, MODE, false, true, false>), g, b, 0, s, a);
             }
+            return hipGetLastError();
         }
-        if (a.pack_k >= 0) {
-            if (buf) hipLaunchKernelGGL((k_forward<LPN, J, MODE, true, false, true>), g, b, 0, s, a);
-            else hipLaunchKernelGGL((k_forward<LPN, J, MODE, true, false, false>), g, b, 0, s, a);
-        } else {
-            if (buf) hipLaunchKernelGGL((k_forward<LPN, J, MODE, false, false, true>), g, b, 0, s, a);
-            else hipLaunchKernelGGL((k_forward<LPN, J, MODE, false, false, false>), g, b, 0, s, a);
+        if constexpr (MODE == kFwdPartA) {
+            if (a.pack_k >= 0) {
+                if (buf) hipLaunchKernelGGL((k_forward<LPN, J, MODE, true, false, true>), g, b, 0, s, a);
+                else hipLaunchKernelGGL((k_forward<LPN, J, MODE, true, false, false>), g, b, 0, s, a);
+            } else {
+                if (buf) hipLaunchKernelGGL((k_forward<LPN, J, MODE, false, false, true>), g, b, 0, s, a);
+                else hipLaunchKernelGGL((k_forward<LPN, J, MODE, false, false, false>), g, b, 0, s, a);
+            }
+            return hipGetLastError();
         }
-        return hipGetLastError();
-        }
+        return hipErrorInvalidValue;       // (pass B without a prologue returned above)
     }
 }
 

@@ -5,13 +5,10 @@
 
 #include <atomic>
 
+#include "fm_constants.h"   // kRangeLen, kXcds, kXSegs, kRowBands, kExtend
+
 namespace fmhip {
 
-constexpr int kRangeLen = 64;      // == FMHIP_RANGE_LEN
-constexpr int kXcds = 8;           // L2 domains of an MI355X (workgroups are dispatched round-robin over them)
-constexpr int kXSegs = 9;          // runs of one XCD's range list: up to 8 row bands + the share of the unplaced ranges
-constexpr int kRowBands = 16;      // row bands of the band-affine placement: two per XCD, 2 MB of P each at 250k-row batches of Kp = 32
-constexpr int kExtend = 16;        // a slot finishes a column that ends this close behind its range
 constexpr int kPartPad = 4;        // partial row = Kp floats + {sum e*x, sum e*x^2, pad, pad}
 constexpr int kScalars = 8;        // packed-gradient tail: {sum e, sum e^2, rows, nonfinite, ...}
 constexpr int kGradHead = 32;      // floats reserved for them at the front of the packed gradient (one 128-B line)
@@ -60,6 +57,7 @@ struct FwdArgs {
     int64_t nz0;           // row_ptr[row0]: the batch's first entry (k_forward / k_forward_wt walk 32-bit positions relative to it)
     const int64_t *row_split;  // kFwdPartA / kFwdPartB: where a row's entries of features >= the cut begin (global offsets, indexed row0 + r)
     float *part_sl;            // kFwdPartA writes, kFwdPartB reads: [rows][2] = {sum over factors of s_f, linear term} of pass A
+    int32_t hot_in_b;          // two-pass forward: 1 = the dense hot block's prologue runs in pass B, not in pass A (a hot feature's id is at or above the cut)
     const int32_t *order;  // [n_rows] batch-local row ids, longest row first (NULL = 0, 1, 2, ..)
     int32_t n_rows;
     float *P;     // train: [rows][Kp] = e*q ; q-mode: [rows][Kp] = q

@@ -116,6 +116,13 @@ int fmhip_ablation_mask(void) { return forward_ablations() | backward_ablations(
 
 const char *fmhip_last_error(void) { return g_err.c_str(); }
 
+// enum fmhip_tune_key (include/fmhip_experimental.h) names the kernels' own keys (fm_kernels.h)
+static_assert(FMHIP_TUNE_FORWARD_KERNEL == kTuneFwd && FMHIP_TUNE_BACKWARD_KERNEL == kTuneBwd && FMHIP_TUNE_TILE_ROWS == kTuneTile &&
+              FMHIP_TUNE_ROW_BLOCK == kTuneRowBlock && FMHIP_TUNE_XCD_PLACEMENT == kTuneXcd && FMHIP_TUNE_HOT_BLOCK == kTuneHot &&
+              FMHIP_TUNE_FORWARD_OCCUPANCY == kTuneFwdOcc && FMHIP_TUNE_ROW_ORDER == kTuneRowOrder && FMHIP_TUNE_FLAT_ADDRESS == kTuneFlat &&
+              FMHIP_TUNE_LAZY_DECAY == kTuneLazy && FMHIP_TUNE_FUSED_UPDATE == kTuneFused && FMHIP_TUNE_MERGED_FINISH == kTuneMerged &&
+              FMHIP_TUNE_HOT_PAGES == kTuneHotPages && FMHIP_TUNE_KEY_COUNT == kTuneCount, "fmhip_experimental.h and fm_kernels.h disagree on the tuning keys");
+
 int fmhip_tune(int key, int value) {
     if (key < 0 || key >= kTuneCount) return fail(FMHIP_ERR_INVALID, "unknown tuning key %d", key);
     g_tune[key] = value;
@@ -506,7 +513,7 @@ int fmhip_als_epoch(fmhip_model_t m, fmhip_dataset_t d, double reg0, double regw
         return fail(FMHIP_ERR_UNSUPPORTED, "ALS walks the whole-dataset transpose: create the dataset with batch_rows <= 0 "
                                            "(single batch, at most 2^27 stored nonzeros) and without asking for the dense hot "
                                            "block (fmhip_dataset_opts::hot_block <= 0)");
-    if (d->rb_rows > 0) return fail(FMHIP_ERR_UNSUPPORTED, "ALS needs a dataset without row blocks (fmhip_tune key 3 = 0)");
+    if (d->rb_rows > 0) return fail(FMHIP_ERR_UNSUPPORTED, "ALS needs a dataset without row blocks (FMHIP_TUNE_ROW_BLOCK = 0)");
     if (d->als_dup)
         return fail(FMHIP_ERR_UNSUPPORTED, "ALS: a row stores the same feature index twice; the column walk updates every row of a "
                                            "column at once and needs the (row, feature) pairs to be distinct");

@@ -113,6 +113,7 @@ int need_rccl() {
     } while (0)
 
 constexpr int kMaxCuts = 7;      // == FMHIP_DP_MAX_CUTS
+static_assert(kMaxCuts == FMHIP_DP_MAX_CUTS, "fmhip.h and fmhip_comm.hip disagree on the number of cuts");
 
 // Stand-in for a collective's duration on the comm stream (fmhip_comm_emulate): one wave spins on the
 // constant-rate clock (100 MHz) until `ticks` have passed.  Bounded by construction; occupies one wave of one CU.
@@ -715,10 +716,7 @@ int dp_step_dense(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_
     }
     CommProf *pr = next_prof(c);
     // intervals [edge[i], edge[i+1]) from the top down; the lowest one carries the statistics scalars
-    std::vector<int64_t> edge{0};
-    for (int64_t x : c->cuts)
-        if (x > edge.back() && x < m->n1) edge.push_back(x);
-    edge.push_back(m->n1);
+    const std::vector<int64_t> edge = interval_edges(c->cuts, m->n1, 0);
     const int n_int = (int)edge.size() - 1;
     for (int i = n_int - 1; i >= 0; --i) {
         const int64_t lo = edge[(size_t)i], hi = edge[(size_t)i + 1];
@@ -768,10 +766,7 @@ int dp_step_dense(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_
 //   comm           |B|        | slice T-1 | .. slice 0    | slice T ............|       |B|   | slice T-1 ..
 int dp_run_pipelined(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, const int64_t *batches, int64_t n, double eta, double reg0, double regw,
                      double regv) {
-    std::vector<int64_t> edge{0};
-    for (int64_t x : c->cuts)
-        if (x > edge.back() && x < m->n1) edge.push_back(x);
-    edge.push_back(m->n1);
+    const std::vector<int64_t> edge = interval_edges(c->cuts, m->n1, 0);
     const int n_int = (int)edge.size() - 1, T = n_int - 1;
     if (n_int < 2 || m->Kp > 64) {      // nothing to pipeline: the dense step (the same collectives on every rank: cuts and width are agreed)
         for (int64_t t = 0; t < n; ++t) TRY(dp_step_dense(m, d, batches[t], c, eta, reg0, regw, regv));
@@ -779,15 +774,33 @@ int dp_run_pipelined(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, const i
     }
     bool any_live = false;
     for (int64_t t = 0; t < n; ++t) any_live = any_live || batches[t] >= 0;
-    // the rows' entries partitioned at the top cut: local work (no collective inside) — if it fails here, this rank keeps in step
-    // with zeros, as after any other local failure, and reports afterwards: no peer is left waiting in a collective
+    // the rows' entries partitioned at the top cut, in a copy of the stream that only the two-pass forward reads (the dataset's
+    // own streams never move: other threads may be scoring or training on it) — local work, no collective inside: if it fails
+    // here, this rank keeps in step with zeros, as after any other local failure, and reports afterwards: no peer is left
+    // waiting in a collective.  The partition is held for the length of the run (PartUse): nobody re-makes it for another cut
+    // under this run's launches.
+    struct PartUse {
+        fmhip_dataset_t d = nullptr;
+        ~PartUse() {
+            if (!d) return;
+            std::lock_guard<std::mutex> lock(d->part_mu);
+            --d->part_users;
+        }
+    } part_use;
     std::vector<int64_t> zeros;
     std::string part_err;
     int part_rc = FMHIP_OK;
-    if (any_live && d->split_cut != edge[(size_t)T] && (part_rc = fmhip_dataset_partition_rows(d, edge[(size_t)T])) != FMHIP_OK) {
-        part_err = fmhip_last_error();
-        zeros.assign((size_t)n, -1);
-        batches = zeros.data();
+    if (any_live) {
+        std::lock_guard<std::mutex> lock(d->part_mu);
+        part_rc = partition_rows_locked(d, edge[(size_t)T]);
+        if (part_rc == FMHIP_OK) {
+            ++d->part_users;
+            part_use.d = d;
+        } else {
+            part_err = fmhip_last_error();
+            zeros.assign((size_t)n, -1);
+            batches = zeros.data();
+        }
     }
     TRY(fold_scales(m));                 // pass A of the next step runs before the last interval's update: the tables stay at scale 1
     for (int64_t t = 0; t < n; ++t) {
@@ -855,9 +868,9 @@ int dp_run_pipelined(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, const i
     return FMHIP_OK;
 }
 
-// rounds the shares of [0, n+1) for `world` ranks: every interval edge is a multiple of world, the top one rounded UP
-// (into the zero rows kept behind the tables, fmhip_model::kSlackRows)
-inline int64_t shard_top(fmhip_model_t m, int W) { return (m->n1 + W - 1) / W * W; }
+// the shares of [0, n+1) for `world` ranks: every interval edge is a multiple of world, the top one rounded UP (into the zero
+// rows kept behind the tables, fmhip_model::kSlackRows) — fmhip_host.h: shard_top, interval_edges, shard_share
+inline int64_t shard_top(fmhip_model_t m, int W) { return fmhip::host::shard_top(m->n1, W); }
 
 // One data-parallel step with the update sharded over the ranks (FMHIP_EXCHANGE_SHARDED; the schedule is drawn at the
 // top of this file).  Per feature interval, from the cold ids down: backward -> reduce-scatter of its G_V rows (rank r
@@ -890,12 +903,7 @@ int dp_step_sharded(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_com
         m->last_nnz = m->last_rows = 0;
     }
     CommProf *pr = next_prof(c);
-    std::vector<int64_t> edge{0};
-    for (int64_t x : c->cuts) {
-        const int64_t xr = x / W * W;                                // the plan rounds already; a plan made for another world may not have
-        if (xr > edge.back() && xr < m->n1) edge.push_back(xr);
-    }
-    edge.push_back(m->n1);
+    const std::vector<int64_t> edge = interval_edges(c->cuts, m->n1, W);      // (the plan rounds already; a plan made for another world may not have)
     const int n_int = (int)edge.size() - 1;
     const size_t kp = (size_t)m->Kp;
     const double half = 0.5;            // emulated durations: a reduce-scatter or an all-gather is half an all-reduce of the same bytes
@@ -903,9 +911,8 @@ int dp_step_sharded(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_com
         const int64_t lo = edge[(size_t)i], hi = edge[(size_t)i + 1];
         const bool last = i == 0;
         if (live) TRY(step_backward(m, d, batch, lo, n_int == 1 ? INT64_MAX : hi, last, nullptr));
-        const int64_t hi_r = i == n_int - 1 ? top : hi;              // the top interval reaches into the slack rows
-        const int64_t chunk = (hi_r - lo) / W;
-        const int64_t vlo = lo + (int64_t)R * chunk, vhi = vlo + chunk;
+        const Share sh = shard_share(lo, hi, i == n_int - 1, m->n1, W, R);      // the top interval reaches into the slack rows
+        const int64_t hi_r = sh.hi_r, chunk = sh.chunk, vlo = sh.vlo, vhi = sh.vhi;
         // one real rank playing `emu_ranks`: the collectives run on its own share (in place), the delays are the interval's
         const size_t count = (size_t)chunk * kp, at = (size_t)(c->emu_ranks > 0 ? vlo : lo) * kp;
         float *gw = last ? m->grad : m->Gw() + lo;
@@ -1008,7 +1015,21 @@ int dp_step(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, fmhip_comm_t c, d
 int dp_run(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, const int64_t *positions, int64_t n, double eta, double reg0, double regw, double regv) {
     const int64_t nb = (int64_t)d->batches.size();
     if (c->exchange != FMHIP_EXCHANGE_PIPELINED) {
-        for (int64_t j = 0; j < n; ++j) TRY(dp_step(m, d, positions[j] < nb ? positions[j] : -1, c, eta, reg0, regw, regv, positions[j]));
+        // a position whose batch fails a check only THIS rank can see contributes zeros and the run goes on — stopping here
+        // would leave the peers alone in the next position's collectives; the first such error is reported at
+        // the end.  A failure of the step itself (HIP, the transport) is no local matter and ends the run at once.
+        int pre = FMHIP_OK;
+        std::string why;
+        for (int64_t j = 0; j < n; ++j) {
+            int64_t b = positions[j] < nb ? positions[j] : -1;
+            const int rc = local_checks(m, d, b, c, false);
+            if (rc != FMHIP_OK) {
+                if (pre == FMHIP_OK) { pre = rc; why = fmhip_last_error(); }
+                b = -1;
+            }
+            TRY(dp_step_mode(m, d, b, c, eta, reg0, regw, regv, positions[j]));
+        }
+        if (pre != FMHIP_OK) return fail(pre, "%s (this rank contributed zeros to those steps)", why.c_str());
         return FMHIP_OK;
     }
     std::vector<int64_t> batches((size_t)n);
@@ -1290,21 +1311,12 @@ int fmhip_dp_plan(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, int n_frac
         // stored nonzeros per feature over this rank's batches (the sparse streams: the dense hot block's
         // features do not depend on the interval), then for every fraction the id above which that share lies
         std::vector<int32_t> cnt((size_t)m->n1, 0);
-        int64_t total = 0;
         for (size_t b = 0; b < d->batches.size(); ++b) {
             const auto &bm = d->batches[b];
             const int32_t *hf = d->h_cfeat.data() + bm.col_off, *hp = d->h_cptr.data() + bm.col_off + b;
-            for (int32_t s = 0; s < bm.n_cols; ++s) {
-                cnt[(size_t)hf[s]] += hp[s + 1] - hp[s];
-                total += hp[s + 1] - hp[s];
-            }
+            for (int32_t s = 0; s < bm.n_cols; ++s) cnt[(size_t)hf[s]] += hp[s + 1] - hp[s];
         }
-        int64_t above = 0, f = m->n1 - 1;
-        for (int i = 0; i < n_fractions; ++i) {
-            const double want = std::min(std::max(upper_fractions[i], 0.0), 1.0) * (double)total;
-            while (f > 0 && (double)above < want) above += cnt[(size_t)f--];
-            cuts[i] = f + 1 < m->n1 ? f + 1 : 0;
-        }
+        choose_cuts(cnt.data(), m->n1, n_fractions, upper_fractions, cuts);
     }
     // What every rank must agree on before a step can be sized (one max-reduce): the largest mini-batch of any rank —
     // its global row count travels as one fp32 sum, exact below 2^24 —, whether some rank's transposes are row-blocked
@@ -1383,10 +1395,28 @@ static int dp_epoch(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double e
     // every rank takes the same number of steps — the largest local batch count — and every rank learns whether SOME
     // rank's dataset does not fit the plan, or whether the ranks disagree about taking an order at all (then all of them stop
     // here, none inside a collective)
-    int64_t agree[4] = {nb, 0, order ? n_order : -1, order ? -n_order : 1};
+    // ... and whether every rank holds the SAME valid order: a permutation check that only one rank fails, or two ranks walking
+    // different permutations, would otherwise end inside the first collective — the order's validity and a hash of
+    // its content travel in the same max-reduce (max of h and of -h: equal on all ranks iff max == -max of the negatives)
+    int64_t order_bad = 0, order_hash = 0;
+    if (order) {
+        std::vector<char> seen((size_t)std::max<int64_t>(n_order, 0), 0);
+        uint64_t h = 1469598103934665603ull;
+        for (int64_t j = 0; j < n_order; ++j) {
+            if (order[j] < 0 || order[j] >= n_order || seen[(size_t)order[j]]) { order_bad = j + 1; break; }
+            seen[(size_t)order[j]] = 1;
+            h = (h ^ (uint64_t)order[j]) * 1099511628211ull;
+        }
+        order_hash = (int64_t)(h >> 2);        // (62 bits: its negative exists)
+    }
+    int64_t agree[7] = {nb, 0, order ? n_order : -1, order ? -n_order : 1, order_bad, order_hash, -order_hash};
     for (int64_t j = 0; j < nb && !agree[1]; ++j) agree[1] = local_checks(m, d, j, c, false) != FMHIP_OK;
+    if (!agree[1] && c->exchange == FMHIP_EXCHANGE_TOUCHED && !lazy_decay_ok(m, eta, regw, regv)) {
+        agree[1] = 1;
+        (void)fail(FMHIP_ERR_UNSUPPORTED, "the touched-rows exchange needs weight decay that fits the tables' scale (0.5 <= 1 - eta*reg <= 1)");
+    }
     const std::string why = agree[1] ? fmhip_last_error() : "";
-    TRY(control_i64(m, c, agree, 4, false));
+    TRY(control_i64(m, c, agree, 7, false));
     if (agree[1])
         return fail(FMHIP_ERR_INVALID, "%s", why.empty() ? "another rank's dataset does not fit the communicator's plan: call fmhip_dp_plan "
                                                            "with the datasets of this epoch (every rank)" : why.c_str());
@@ -1395,16 +1425,15 @@ static int dp_epoch(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, double e
         return fail(FMHIP_ERR_INVALID, "fmhip_dp_epoch_order: every rank passes the same order of the epoch's %lld positions (this rank: %lld "
                                        "entries; the ranks' counts range from %lld to %lld)", (long long)steps, (long long)(order ? n_order : -1),
                     (long long)-agree[3], (long long)agree[2]);
-    if (order) {
-        // a permutation of [0, steps): checked locally — the arrays are the same on every rank by contract, and a rank whose
-        // copy is bad would otherwise walk other positions than its peers
-        std::vector<char> seen((size_t)steps, 0);
-        for (int64_t j = 0; j < steps; ++j) {
-            if (order[j] < 0 || order[j] >= steps || seen[(size_t)order[j]])
-                return fail(FMHIP_ERR_INVALID, "order[%lld] = %lld: the order must be a permutation of [0, %lld)", (long long)j, (long long)order[j], (long long)steps);
-            seen[(size_t)order[j]] = 1;
-        }
+    if (agree[4]) {
+        if (order_bad)
+            return fail(FMHIP_ERR_INVALID, "order[%lld] = %lld: the order must be a permutation of [0, %lld)", (long long)(order_bad - 1),
+                        (long long)order[order_bad - 1], (long long)steps);
+        return fail(FMHIP_ERR_INVALID, "fmhip_dp_epoch_order: another rank's order is not a permutation of [0, %lld)", (long long)steps);
     }
+    if (agree[5] != -agree[6])
+        return fail(FMHIP_ERR_INVALID, "fmhip_dp_epoch_order: the ranks passed DIFFERENT orders (every rank passes the same permutation of the epoch's %lld positions)",
+                    (long long)steps);
     if (c->exchange == FMHIP_EXCHANGE_TOUCHED) {
         if (steps != (int64_t)c->tsteps.size())
             return fail(FMHIP_ERR_INVALID, "the touched-rows plan covers %zu steps, this epoch has %lld: call fmhip_dp_plan with this dataset (every rank)",
@@ -1495,20 +1524,7 @@ int fmhip_comm_profile_end(fmhip_comm_t c, fmhip_comm_profile *p) {
 int fmhip_shard_rows(int64_t n_rows, const int64_t *row_ptr, int world, int rank, int64_t *lo, int64_t *hi) {
     if (!row_ptr || !lo || !hi) return fail(FMHIP_ERR_INVALID, "NULL argument");
     if (n_rows < 0 || world < 1 || rank < 0 || rank >= world) return fail(FMHIP_ERR_INVALID, "bad shard request (rows %lld, rank %d of %d)", (long long)n_rows, rank, world);
-    const int64_t nnz = row_ptr[n_rows];
-    // boundary of rank i: the row offset NEAREST to i/world of the stored nonzeros (so one giant row does
-    // not drag every row before it into the same shard); datasets without nonzeros fall back to row counts
-    auto bound = [&](int i) -> int64_t {
-        if (i <= 0) return 0;
-        if (i >= world) return n_rows;
-        if (nnz == 0) return n_rows * i / world;
-        const int64_t target = (int64_t)((__int128)nnz * i / world);
-        int64_t r = std::lower_bound(row_ptr, row_ptr + n_rows + 1, target) - row_ptr;
-        if (r > 0 && (r > n_rows || target - row_ptr[r - 1] < row_ptr[r] - target)) --r;
-        return r;
-    };
-    *lo = std::min(bound(rank), n_rows);
-    *hi = std::min(std::max(bound(rank + 1), *lo), n_rows);
+    shard_bounds(n_rows, row_ptr, world, rank, lo, hi);
     return FMHIP_OK;
 }
 

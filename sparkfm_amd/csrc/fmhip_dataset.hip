@@ -34,78 +34,11 @@ namespace host {
 
 // ---- dataset construction -------------------------------------------------------
 
-struct HostBatch {
-    std::vector<int32_t> cfeat, cptr, range_seg, split_seg, split_short, cdst, mp_feat, mp_ptr;
-    int32_t n_feats = 0, n_pieces = 0;
-};
-
-// Host-side metadata of one batch from its column offsets (the transposed stream itself is built
-// on the device, csc_build.hip): the column open at the start of every 64-entry range and the
-// columns whose sum is assembled by k_fixup.
-void finish_batch_meta(HostBatch &hb, int32_t nnz, std::vector<int32_t> &cnt, std::vector<int32_t> &base) {
-    const size_t nc = hb.cfeat.size();
-    // destinations of the column pieces: a feature with one piece stores straight to its G row; a
-    // feature with several (row-blocked stream) gets consecutive piece rows, in stream (= row block)
-    // order, that k_fixup2 sums.  `cnt` / `base` are zeroed scratch arrays of dimension + 1 entries.
-    {
-        std::vector<int32_t> multi;
-        hb.n_feats = 0;
-        for (size_t s = 0; s < nc; ++s) {
-            const int32_t c = ++cnt[hb.cfeat[s]];
-            if (c == 1) ++hb.n_feats;
-            if (c == 2) multi.push_back(hb.cfeat[s]);
-        }
-        std::sort(multi.begin(), multi.end());
-        hb.mp_feat = multi;
-        hb.mp_ptr.assign(multi.size() + 1, 0);
-        for (size_t m = 0; m < multi.size(); ++m) {
-            base[multi[m]] = hb.mp_ptr[m];
-            hb.mp_ptr[m + 1] = hb.mp_ptr[m] + cnt[multi[m]];
-        }
-        hb.n_pieces = multi.empty() ? 0 : hb.mp_ptr[multi.size()];
-        hb.cdst.resize(nc);
-        for (size_t s = 0; s < nc; ++s) {
-            const int32_t f = hb.cfeat[s];
-            hb.cdst[s] = cnt[f] > 1 ? -1 - (base[f]++) : f;
-        }
-        for (size_t s = 0; s < nc; ++s) { cnt[hb.cfeat[s]] = 0; base[hb.cfeat[s]] = 0; }
-    }
-    const int32_t n_ranges = (int32_t)((nnz + kRangeLen - 1) / kRangeLen);
-    hb.range_seg.assign((size_t)n_ranges, 0);
-    size_t s = 0;
-    for (int32_t rho = 0; rho < n_ranges; ++rho) {
-        const int32_t pos = rho * kRangeLen;
-        while (s + 1 < nc && hb.cptr[s + 1] <= pos) ++s;
-        hb.range_seg[(size_t)rho] = (int32_t)s;
-    }
-    hb.split_seg.clear();
-    hb.split_short.clear();
-    // the same predicates k_backward applies: a column spanning two ranges whose remainder in the
-    // second is <= kExtend is finished by the first range's slot and needs no fixup; the others are
-    // summed by k_fixup, a slot each when they span <= 8 ranges, else a wave each
-    for (size_t c = 0; c < nc; ++c) {
-        const int32_t ra = hb.cptr[c] / kRangeLen, rb = (hb.cptr[c + 1] - 1) / kRangeLen;
-        if (rb > ra && !(rb == ra + 1 && hb.cptr[c + 1] - rb * kRangeLen <= kExtend))
-            (rb - ra + 1 <= 8 ? hb.split_short : hb.split_seg).push_back((int32_t)c);
-    }
-}
-
 template <typename T>
 int upload(DevBuf<T> &dst, const T *src, size_t n) {
     TRY(dst.alloc(n));
     if (n) HIP_TRY(hipMemcpy(dst.p, src, n * sizeof(T), hipMemcpyHostToDevice));
     return FMHIP_OK;
-}
-
-// Host-side passes of the dataset build (validation, dense-hot-block split, forward row order, fp32
-// re-pack) run over row chunks on all host cores: they are what `DataSet.cache()` costs before the
-// device takes over (single-threaded they took 3.9 s for C4's 10 M rows).
-int host_threads(int64_t work_items) {
-    unsigned hc = std::thread::hardware_concurrency();
-    int64_t t = hc ? (int64_t)hc : 4;
-    if (const char *e = getenv("FMHIP_HOST_THREADS")) t = atoi(e);
-    t = std::min<int64_t>({t, 32, work_items / 65536 + 1});
-    return (int)std::max<int64_t>(t, 1);
 }
 
 // FMHIP_BUILD_TIMING=1: the phases of fmhip_dataset_create on stderr (what `DataSet.cache()` costs, and where)
@@ -120,79 +53,6 @@ struct PhaseTimer {
         t = now;
     }
 };
-
-// f(tid, lo, hi) over [0, n) cut into one contiguous chunk per thread
-template <class F>
-void parallel_chunks(int64_t n, int threads, F f) {
-    if (threads <= 1 || n <= 0) { f(0, (int64_t)0, n); return; }
-    std::vector<std::thread> pool;
-    pool.reserve((size_t)threads);
-    for (int t = 0; t < threads; ++t) {
-        const int64_t lo = n * t / threads, hi = n * (t + 1) / threads;
-        pool.emplace_back([=]() { f(t, lo, hi); });
-    }
-    for (auto &th : pool) th.join();
-}
-
-// Band-affine placement of one batch's ranges (BwdArgs::xlist).  first/last: the rows of the first and last entry of every
-// range.  A range that lies inside ONE column and spans at most a band and a half of rows is "affine" to the band of its
-// middle row; XCD x owns a run of consecutive bands (two at 250k-row batches) and its list starts with their ranges, band by band,
-// so that one band's slice of P (rows / 16 x 4 Kp bytes: 2 MB at 250k rows of Kp = 32) is what that XCD's L2 holds while
-// they are walked; every other range is "free" and fills the lists up to equal length.  Returns the affine count.
-int32_t plan_bands(const HostBatch &hb, int32_t cnnz, int64_t rows, const std::vector<int32_t> &first, const std::vector<int32_t> &last,
-                   std::vector<int32_t> (&lists)[kXcds], int32_t (&seg)[kXcds][kXSegs + 1]) {
-    const int32_t n_ranges = (int32_t)hb.range_seg.size();
-    // bands of about 16k rows (2 MB of P at Kp = 32, 4 MB at Kp = 64: C3 and C5's width measured the same with 16 and 32
-    // bands of 250k rows), a multiple of the XCD count, at most 8 per XCD
-    int n_bands = (int)std::min<int64_t>(((rows + 16383) / 16384 + kXcds - 1) / kXcds * kXcds, (kXSegs - 1) * kXcds);
-    n_bands = std::max(n_bands, kRowBands);
-    if (const char *ev = getenv("FMHIP_ROW_BANDS")) {           // measurement knob: a multiple of kXcds, at most 8 per XCD
-        const int v = atoi(ev);
-        if (v >= kXcds && v <= (kXSegs - 1) * kXcds && v % kXcds == 0) n_bands = v;
-    }
-    const int per_xcd = n_bands / kXcds;
-    const int64_t band_rows = std::max<int64_t>((rows + n_bands - 1) / n_bands, 1);
-    std::vector<std::vector<int32_t>> by_band((size_t)n_bands);
-    std::vector<int32_t> free_ranges;
-    for (int32_t rho = 0; rho < n_ranges; ++rho) {
-        const int32_t beg = rho * kRangeLen, end = std::min(beg + kRangeLen, cnnz);
-        const int32_t seg = hb.range_seg[(size_t)rho];
-        const bool one_column = hb.cptr[(size_t)seg] <= beg && hb.cptr[(size_t)seg + 1] >= end;
-        const int64_t span = (int64_t)last[(size_t)rho] - first[(size_t)rho];
-        if (one_column && end - beg == kRangeLen && span >= 0 && span * 2 <= band_rows * 3) {
-            const int64_t band = std::min<int64_t>(((int64_t)first[(size_t)rho] + last[(size_t)rho]) / 2 / band_rows, n_bands - 1);
-            by_band[(size_t)band].push_back(rho);
-        } else {
-            free_ranges.push_back(rho);
-        }
-    }
-    int32_t affine = 0;
-    for (int x = 0; x < kXcds; ++x) {
-        lists[x].clear();
-        for (int b = 0; b < kXSegs - 1; ++b) {                     // one run per band (runs of bands the XCD does not have: empty)
-            seg[x][b] = (int32_t)lists[x].size();
-            if (b >= per_xcd) continue;
-            const auto &v = by_band[(size_t)(x * per_xcd + b)];
-            lists[x].insert(lists[x].end(), v.begin(), v.end());
-            affine += (int32_t)v.size();
-        }
-        seg[x][kXSegs - 1] = (int32_t)lists[x].size();            // the last run: this XCD's share of the other ranges
-    }
-    // The free ranges follow in blocks of 32 consecutive ranges, each block to the list that is shortest so far: close to the
-    // round-robin of the default placement — every XCD gets hot (few columns per range) and cold (a flush per entry)
-    // stretches of the stream alike; handing each XCD one contiguous eighth instead left the XCD with the coldest
-    // features far behind the others (C4: backward 203 -> 268 us) — and the lists end within a block of each other.
-    constexpr size_t kBlockRanges = 32;
-    for (size_t next = 0; next < free_ranges.size(); next += kBlockRanges) {
-        int best = 0;
-        for (int x = 1; x < kXcds; ++x)
-            if (lists[x].size() < lists[best].size()) best = x;
-        const size_t hi = std::min(next + kBlockRanges, free_ranges.size());
-        lists[best].insert(lists[best].end(), free_ranges.begin() + (std::ptrdiff_t)next, free_ranges.begin() + (std::ptrdiff_t)hi);
-    }
-    for (int x = 0; x < kXcds; ++x) seg[x][kXSegs] = (int32_t)lists[x].size();
-    return affine;
-}
 
 // The gradient-side pages of the dense hot block, filled on the device from the CSR stream that was just uploaded (their
 // entries stay in it): 8 lanes per row walk the row's entries, an entry whose feature sits in slot h >= kHotT of the id table
@@ -235,8 +95,8 @@ hipError_t fill_hot_pages(const int64_t *row_ptr, const int32_t *col, const floa
 
 // scoring = true: rows + labels only (FMModel.predict / Model.computeRMSE on held-out data,
 // S/driver.scala:100-112) — no transposes, no hot block, nothing a training step needs
-// hot_opt: -1 = the process-wide defaults (fmhip_tune keys 5, 12), 0 = no hot block, n >= 1 = up to n pages of it;
-// rb_opt: -1 = the default (key 3)
+// hot_opt: -1 = the process-wide defaults (FMHIP_TUNE_HOT_BLOCK, FMHIP_TUNE_HOT_PAGES), 0 = no hot block, n >= 1 = up to n pages of it;
+// rb_opt: -1 = the default (FMHIP_TUNE_ROW_BLOCK)
 template <typename FT>
 int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const FT *val,
                         const FT *y, int64_t batch_rows, bool scoring, fmhip_dataset_t *out, int hot_opt = -1,
@@ -293,7 +153,7 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     if (batch_rows <= 0 || batch_rows > n_rows) batch_rows = std::max<int64_t>(n_rows, 1);
     d->batch_rows = batch_rows;
     const int64_t nb = n_rows > 0 ? (n_rows + batch_rows - 1) / batch_rows : 0;
-    // ---- dense hot block (fmhip_tune keys 5, 12): features present in >= 10 % of the rows, the most frequent first, fill
+    // ---- dense hot block (FMHIP_TUNE_HOT_BLOCK, FMHIP_TUNE_HOT_PAGES): features present in >= 10 % of the rows, the most frequent first, fill
     // up to `max_pages` pages of kHotT slots; x_rh sits in xhot[page][r][slot].  Page 0's entries leave the sparse
     // streams altogether; the entries of pages 1.. stay in the CSR stream (the forward walks them like any other entry)
     // and leave only the transposes (fm_kernels.h, kHotPages).  A feature that occurs twice in a row, or is stored with
@@ -453,6 +313,7 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
             d->hot_T = kHotT;
             d->hot_pages = pages;
             for (int32_t f : d->hot_ids) d->hot_max_id = std::max(d->hot_max_id, (int64_t)f);
+            for (int h = 0; h < kHotT && h < (int)d->hot_ids.size(); ++h) d->hot0_max_id = std::max(d->hot0_max_id, d->hot_ids[(size_t)h]);
         }
     }
     pt.lap("hot block: choose + split");
@@ -610,7 +471,7 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
         }
         int key_bits = 1;
         while (key_bits < 31 && ((int64_t)1 << key_bits) <= (int64_t)dim + (drop ? 1 : 0)) ++key_bits;
-        // optional row blocking of the transposes (fmhip_tune key 3): entries sorted by (row block,
+        // optional row blocking of the transposes (FMHIP_TUNE_ROW_BLOCK): entries sorted by (row block,
         // feature) so that a block's slice of P stays L2-resident while its columns are walked
         int64_t rb_rows = want_rb;
         int rb_bits = 0;
@@ -684,21 +545,8 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
                     delete d;
                     return fail(FMHIP_ERR_HIP, "reading the transpose back for the ALS level schedule: %s", hipGetErrorString(he));
                 }
-                std::vector<int32_t> row_level((size_t)bm.rows, 0), level((size_t)nc, 0);
-                int32_t n_levels = 0;
-                for (int32_t c = 0; c < (int32_t)hb.cfeat.size(); ++c) {
-                    int32_t lv = 0;
-                    for (int32_t p = hb.cptr[(size_t)c]; p < hb.cptr[(size_t)c + 1]; ++p) lv = std::max(lv, row_level[h_crow[(size_t)p] & 0x7fffffffu]);
-                    ++lv;
-                    level[(size_t)c] = lv;
-                    n_levels = std::max(n_levels, lv);
-                    for (int32_t p = hb.cptr[(size_t)c]; p < hb.cptr[(size_t)c + 1]; ++p) row_level[h_crow[(size_t)p] & 0x7fffffffu] = lv;
-                }
-                d->als_lev_ptr.assign((size_t)n_levels + 1, 0);
-                for (size_t c = 0; c < hb.cfeat.size(); ++c) ++d->als_lev_ptr[(size_t)level[c]];
-                for (int32_t l = 1; l <= n_levels; ++l) d->als_lev_ptr[(size_t)l] += d->als_lev_ptr[(size_t)l - 1];
-                std::vector<int32_t> cols(hb.cfeat.size()), at(d->als_lev_ptr.begin(), d->als_lev_ptr.end() - 1);
-                for (size_t c = 0; c < hb.cfeat.size(); ++c) cols[(size_t)at[(size_t)level[c] - 1]++] = (int32_t)c;   // ascending id inside a level
+                std::vector<int32_t> cols;
+                als_levels(hb.cptr, h_crow.data(), bm.rows, d->als_lev_ptr, cols);
                 if ((rc = upload(d->als_lev_cols, cols.data(), cols.size()))) {
                     delete d;
                     return rc;
@@ -797,6 +645,49 @@ int dataset_create_impl(int device, int64_t n_rows, const int64_t *row_ptr, cons
     }
     pt.lap("pack + upload column index");
     *out = d;
+    return FMHIP_OK;
+}
+
+// one thread per row: the entries of features below `cut` first, then the others, each group in its stored order
+__global__ __launch_bounds__(256) void k_row_partition(const int64_t *row_ptr, int64_t n_rows, const int32_t *col, const float *val, int32_t cut,
+                                                       int32_t *col_out, float *val_out, int64_t *split) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    const int64_t p0 = row_ptr[r], p1 = row_ptr[r + 1];
+    int64_t h = p0;
+    for (int64_t p = p0; p < p1; ++p)
+        if (col[p] < cut) { col_out[h] = col[p]; val_out[h] = val[p]; ++h; }
+    split[r] = h;
+    for (int64_t p = p0; p < p1; ++p)
+        if (col[p] >= cut) { col_out[h] = col[p]; val_out[h] = val[p]; ++h; }
+}
+
+// Stable partition of every row's stored entries at feature id `cut` (the two-pass forward, fm_kernels.h kFwdPartA / B) into a
+// COPY of the CSR stream (col_part / val_part) that only the two-pass forward reads: the dataset's own streams never move, so
+// threads that score or train other models on the same dataset are not disturbed (the first version swapped the
+// partitioned copy in for the streams under a launch that might still be reading them).  One partition per dataset: it is
+// re-made for another cut unless a pipelined run is using it (part_users, fmhip_comm.hip) — then the call fails and says so.
+int partition_rows_locked(fmhip_dataset_t d, int64_t cut_feature) {
+    const int32_t cut = (int32_t)std::min<int64_t>(cut_feature, INT32_MAX);
+    if (d->split_cut == cut) return FMHIP_OK;
+    if (d->part_users > 0)
+        return fail(FMHIP_ERR_INVALID, "the dataset's rows are partitioned at feature %lld and a pipelined data-parallel run is using that partition: "
+                                       "models that share a dataset must share the top cut of their plans (asked for: %d)", (long long)d->split_cut, cut);
+    const int64_t nnz_s = d->nnz_sparse;
+    TRY(d->row_split.ensure((size_t)std::max<int64_t>(d->n_rows, 1)));
+    TRY(d->col_part.ensure((size_t)std::max<int64_t>(nnz_s, 1)));
+    TRY(d->val_part.ensure((size_t)std::max<int64_t>(nnz_s, 1)));
+    // an earlier partition may still be read by launches queued on some model's stream (a run releases it when it has
+    // ENQUEUED its steps): drain the device before the copy is overwritten
+    if (d->split_cut >= 0) HIP_TRY(hipDeviceSynchronize());
+    d->split_cut = -1;                     // (a failure below leaves no half-made partition behind)
+    if (d->n_rows > 0) {
+        hipLaunchKernelGGL(k_row_partition, dim3((unsigned)((d->n_rows + 255) / 256)), dim3(256), 0, nullptr, d->row_ptr.p, d->n_rows, d->col.p, d->val.p,
+                           cut, d->col_part.p, d->val_part.p, d->row_split.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(nullptr));
+    }
+    d->split_cut = cut;
     return FMHIP_OK;
 }
 
@@ -964,54 +855,12 @@ int fmhip_dataset_hot_pages(fmhip_dataset_t d, int32_t *n_pages, int32_t *n_ids,
     return FMHIP_OK;
 }
 
-// one thread per row: the entries of features below `cut` first, then the others, each group in its stored order
-// (v64: the fp64 copy of the values a single-batch dataset keeps for the ALS learner, in the same order — it moves with them)
-__global__ __launch_bounds__(256) void k_row_partition(const int64_t *row_ptr, int64_t n_rows, const int32_t *col, const float *val, const double *v64,
-                                                       int32_t cut, int32_t *col_out, float *val_out, double *v64_out, int64_t *split) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= n_rows) return;
-    const int64_t p0 = row_ptr[r], p1 = row_ptr[r + 1];
-    int64_t h = p0;
-    for (int64_t p = p0; p < p1; ++p)
-        if (col[p] < cut) { col_out[h] = col[p]; val_out[h] = val[p]; if (v64) v64_out[h] = v64[p]; ++h; }
-    split[r] = h;
-    for (int64_t p = p0; p < p1; ++p)
-        if (col[p] >= cut) { col_out[h] = col[p]; val_out[h] = val[p]; if (v64) v64_out[h] = v64[p]; ++h; }
-}
-
-// Stable partition of every row's stored entries at feature id `cut` (the two-pass forward, fm_kernels.h kFwdPartA / B).  Only
-// the order of a row's entries in the CSR stream changes — the transposes, the dense hot block and every result up to the order
-// of the forward's fp32 sums stay what they were.  Not to be called while another thread trains or scores with this dataset.
 int fmhip_dataset_partition_rows(fmhip_dataset_t d, int64_t cut_feature) {
     if (!d) return fail(FMHIP_ERR_INVALID, "dataset is NULL");
     if (cut_feature < 0) return fail(FMHIP_ERR_INVALID, "negative feature id");
     TRY(set_device(d->device));
-    const int32_t cut = (int32_t)std::min<int64_t>(cut_feature, INT32_MAX);
-    if (d->split_cut == cut) return FMHIP_OK;
-    const int64_t nnz_s = d->nnz_sparse;
-    int rc = d->row_split.ensure((size_t)std::max<int64_t>(d->n_rows, 1));
-    if (rc) return rc;
-    DevBuf<int32_t> col2;
-    DevBuf<float> val2;
-    DevBuf<double> v64_2;
-    if ((rc = col2.alloc((size_t)std::max<int64_t>(nnz_s, 1))) || (rc = val2.alloc((size_t)std::max<int64_t>(nnz_s, 1))) ||
-        (d->val64.p && (rc = v64_2.alloc((size_t)std::max<int64_t>(nnz_s, 1)))))
-        return rc;
-    if (d->n_rows > 0) {
-        hipLaunchKernelGGL(k_row_partition, dim3((unsigned)((d->n_rows + 255) / 256)), dim3(256), 0, nullptr, d->row_ptr.p, d->n_rows, d->col.p, d->val.p,
-                           d->val64.p, cut, col2.p, val2.p, v64_2.p, d->row_split.p);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(nullptr));
-        // the partitioned copies BECOME the streams (nothing holds the old pointers: every launch takes them from the dataset) — no
-        // copy back, and a failure above leaves the dataset exactly as it was
-        std::swap(d->col.p, col2.p);
-        std::swap(d->col.n, col2.n);
-        std::swap(d->val.p, val2.p);
-        std::swap(d->val.n, val2.n);
-        if (d->val64.p) { std::swap(d->val64.p, v64_2.p); std::swap(d->val64.n, v64_2.n); }
-    }
-    d->split_cut = cut;
-    return FMHIP_OK;
+    std::lock_guard<std::mutex> lock(d->part_mu);
+    return partition_rows_locked(d, cut_feature);
 }
 
 int fmhip_dataset_band_plan(fmhip_dataset_t d, int64_t *n_ranges, int64_t *planned_ranges, int64_t *band_affine_ranges) {
@@ -1041,59 +890,21 @@ int fmhip_dataset_als_levels(fmhip_dataset_t d, int64_t *n_levels, int64_t *n_co
 // ---- feature relabelling by frequency (host arithmetic; see include/fmhip.h) -----------------------------------
 int fmhip_feature_counts(int64_t nnz, const int32_t *col, int64_t n1, int64_t *counts) {
     if (nnz < 0 || n1 < 1 || n1 > INT32_MAX || !counts || (nnz > 0 && !col)) return fail(FMHIP_ERR_INVALID, "bad arguments");
-    const int T = host_threads(nnz);
-    std::atomic<int64_t> bad{-1};
-    // a private table per thread while that stays small (<= 64 MiB each), one shared table with atomic adds beyond
-    const bool private_tables = T > 1 && n1 <= (int64_t)1 << 23;
-    std::vector<std::vector<int64_t>> part(private_tables ? (size_t)T : 0);
-    parallel_chunks(nnz, T, [&](int t, int64_t lo, int64_t hi) {
-        int64_t *dst = counts;
-        if (private_tables) {
-            part[(size_t)t].assign((size_t)n1, 0);
-            dst = part[(size_t)t].data();
-        }
-        for (int64_t i = lo; i < hi; ++i) {
-            const int64_t c = col[i];
-            if (c < 0 || c >= n1) { bad.store(i); return; }
-            if (private_tables || T == 1) ++dst[c];
-            else __atomic_fetch_add(&dst[c], (int64_t)1, __ATOMIC_RELAXED);
-        }
-    });
-    if (bad.load() >= 0) return fail(FMHIP_ERR_INVALID, "col[%lld] = %d outside [0, %lld)", (long long)bad.load(), col[bad.load()], (long long)n1);
-    if (private_tables)
-        parallel_chunks(n1, T, [&](int, int64_t lo, int64_t hi) {
-            for (int t = 0; t < T; ++t) {
-                const int64_t *src = part[(size_t)t].data();
-                for (int64_t f = lo; f < hi; ++f) counts[f] += src[f];
-            }
-        });
+    const int64_t bad = feature_counts(nnz, col, n1, counts);
+    if (bad >= 0) return fail(FMHIP_ERR_INVALID, "col[%lld] = %d outside [0, %lld)", (long long)bad, col[bad], (long long)n1);
     return FMHIP_OK;
 }
 
 int fmhip_rank_from_counts(int64_t n1, const int64_t *counts, int32_t *rank, int32_t *by_rank) {
     if (n1 < 1 || n1 > INT32_MAX || !counts || !rank) return fail(FMHIP_ERR_INVALID, "bad arguments");
-    std::vector<int32_t> order((size_t)n1);
-    std::iota(order.begin(), order.end(), 0);
-    // descending count, ties by ascending id: every rank of a job derives the same order from the same counts
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return counts[a] > counts[b]; });
-    for (int64_t r = 0; r < n1; ++r) {
-        rank[order[(size_t)r]] = (int32_t)r;
-        if (by_rank) by_rank[r] = order[(size_t)r];
-    }
+    rank_from_counts(n1, counts, rank, by_rank);
     return FMHIP_OK;
 }
 
 int fmhip_relabel_columns(int64_t nnz, const int32_t *col, int64_t n1, const int32_t *rank, int32_t *out) {
     if (nnz < 0 || n1 < 1 || !rank || (nnz > 0 && (!col || !out))) return fail(FMHIP_ERR_INVALID, "bad arguments");
-    std::atomic<int64_t> bad{-1};
-    parallel_chunks(nnz, host_threads(nnz), [&](int, int64_t lo, int64_t hi) {
-        for (int64_t i = lo; i < hi; ++i) {
-            const int64_t c = col[i];
-            if (c < 0 || c >= n1) { bad.store(i); return; }
-            out[i] = rank[c];
-        }
-    });
-    if (bad.load() >= 0) return fail(FMHIP_ERR_INVALID, "col[%lld] outside [0, %lld): nothing can be relied on in `out`", (long long)bad.load(), (long long)n1);
+    const int64_t bad = relabel_columns(nnz, col, n1, rank, out);
+    if (bad >= 0) return fail(FMHIP_ERR_INVALID, "col[%lld] outside [0, %lld): nothing can be relied on in `out`", (long long)bad, (long long)n1);
     return FMHIP_OK;
 }
 

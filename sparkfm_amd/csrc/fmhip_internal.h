@@ -1,10 +1,11 @@
-// fmhip_internal.h — host-side state behind the opaque handles of include/fmhip.h, shared by the
+// fmhip_internal.h — host-side state behind the opaque handles of include/fmhip.h / fmhip_experimental.h, shared by the
 // translation units of libfmhip.so (fmhip_api.hip: the C ABI of models, scoring and training; fmhip_dataset.hip:
 // datasets; fmhip_step.hip: the single-GPU step in pieces; fmhip_comm.hip: the data-parallel step).
 // Not installed, not part of the ABI.
 #pragma once
-#include "../../include/fmhip.h"
+#include "../../include/fmhip_experimental.h"   // (includes fmhip.h: the library implements both surfaces)
 #include "fm_kernels.h"
+#include "fmhip_host.h"   // the pure host arithmetic (shards, relabelling, batch metadata, band plan, ALS levels, the dp plan's cuts and shares)
 
 #include <cstdarg>
 #include <cstdint>
@@ -139,6 +140,14 @@ struct fmhip_dataset {
     // split_cut — [row_ptr[r], row_split[r]) hold the features below it, [row_split[r], row_ptr[r+1]) the others
     DevBuf<int64_t> row_split;
     int64_t split_cut = -1;      // -1: not partitioned
+    // ... in a COPY of the CSR stream that only the two-pass forward reads (col / val themselves never move once the dataset
+    // is built: other threads may be scoring or training with them).  part_mu guards the partition's making; part_users counts
+    // the pipelined runs that are walking it (it is not re-made for another cut while one does)
+    DevBuf<int32_t> col_part;
+    DevBuf<float> val_part;
+    std::mutex part_mu;
+    int part_users = 0;
+    int32_t hot0_max_id = -1;    // the largest feature id of the dense hot block's FORWARD page (page 0), -1 = none
     DevBuf<int32_t> cfeat, cptr, range_seg, split_seg, split_short, cdst, mp_feat, mp_ptr;
     // per batch: bitmap over the feature ids [0, dimension] of the rows whose gradient the FIXUP launch assembles (cut
     // columns, hot block) — the merged finish lets those update themselves and skips them in its dense pass
@@ -256,6 +265,8 @@ struct ReadLock {
     std::shared_lock<std::shared_mutex> lk;
     explicit ReadLock(fmhip_model_t m) { if (m) lk = std::shared_lock<std::shared_mutex>(m->mu); }
 };
+// ---- fmhip_dataset.hip
+int partition_rows_locked(fmhip_dataset_t d, int64_t cut_feature);      // fmhip_dataset_partition_rows with d->part_mu held by the caller
 // ---- fmhip_step.hip
 int ensure_workspace(fmhip_model_t m, fmhip_dataset_t d);
 FwdArgs fwd_args(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm);
@@ -264,8 +275,8 @@ int check_train(fmhip_model_t m, fmhip_dataset_t d);      // + the dataset must 
 int check_batch(fmhip_dataset_t d, int64_t batch);
 // the pieces of one mini-batch step, all asynchronous on m->stream (fmhip_api.hip)
 int step_forward(fmhip_model_t m, fmhip_dataset_t d, int64_t b);
-// a step whose update happens inside the backward (mode 1: every finished gradient row, fmhip_tune key 10) or
-// inside the fixup launch (mode 2, the merged finish: dense update beside the fixups, key 11) — fmhip_api.hip
+// a step whose update happens inside the backward (mode 1: every finished gradient row, FMHIP_TUNE_FUSED_UPDATE) or
+// inside the fixup launch (mode 2, the merged finish: dense update beside the fixups, FMHIP_TUNE_MERGED_FINISH) — fmhip_api.hip
 struct FusedPlan {
     int mode = 0;
     double eta = 0.0, reg0 = 0.0, regw = 0.0, regv = 0.0;

@@ -98,7 +98,7 @@ FwdArgs fwd_args(fmhip_model_t m, fmhip_dataset_t d, const BatchMeta &bm) {
     a.V = m->V.p;
     {
         // tables of 4 GiB and more do not fit a 32-bit buffer view and take the flat-address kernels
-        // (fmhip_tune key 8 forces those for any size, so that tests reach them on small inputs)
+        // (FMHIP_TUNE_FLAT_ADDRESS forces those for any size, so that tests reach them on small inputs)
         const uint64_t vb = (uint64_t)m->n1p * m->Kp * sizeof(float);
         a.v_bytes = (vb < 0xffffffffull && !m->tv(kTuneFlat)) ? (uint32_t)vb : 0u;
     }
@@ -206,8 +206,13 @@ int step_forward_pass(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int pass) {
     TRY(ensure_workspace(m, d));
     TRY(m->part_sl.ensure((size_t)std::max<int64_t>(d->max_rows, 1) * 2));
     FwdArgs a = fwd_args(m, d, bm);
+    a.col = d->col_part.p;               // the partitioned copy of the stream (the dataset's own never moves)
+    a.val = d->val_part.p;
     a.row_split = d->row_split.p;
     a.part_sl = m->part_sl.p;
+    // pass A runs while the parameter rows at or above the cut are still being exchanged: a hot feature up there (ids not
+    // ranked by frequency) moves the dense block's prologue into pass B — a local choice, no collective depends on it
+    a.hot_in_b = d->hot_T > 0 && (int64_t)d->hot0_max_id >= d->split_cut;
     if (pass == 0) {
         a.bsum = nullptr;
         ProfScope ps(m, FMHIP_K_FORWARD, bm.nnz_total, bm.rows);
@@ -279,7 +284,7 @@ int step_backward(fmhip_model_t m, fmhip_dataset_t d, int64_t b, int64_t feat_lo
     if (d->rb_rows > 0 && !whole)      // refused before anything of the step's state (hot_pending) is consumed
         return fail(FMHIP_ERR_UNSUPPORTED, "feature-interval backward is not available on a row-blocked dataset");
     if (whole || finish || d->hot_max_id >= feat_lo) hot_attach(m, d, bm, ba);
-    // band-affine placement (tuning key 4 = 2): XCD x walks the ranges of its own row bands first (BwdArgs::xlist); the same
+    // band-affine placement (FMHIP_TUNE_XCD_PLACEMENT = 2): XCD x walks the ranges of its own row bands first (BwdArgs::xlist); the same
     // choice for every launch of a step — the partials of a cut column are written and read under one rule (no wave sums)
     const bool banded = m->tv(kTuneXcd) == 2 && bm.xoff[0] >= 0 && d->rb_rows == 0;
     if (banded) {
@@ -414,7 +419,7 @@ bool plan_fused(fmhip_model_t m, fmhip_dataset_t d, int64_t b, double eta, doubl
         const float rows = (float)bm0.rows;
         p->upd.invb = rows > 0.f ? 1.0f / rows : 0.f;
     }
-    // merged finish (key 11): when the step's update is the DENSE pass (the batch touches most of the model, or decay
+    // merged finish (FMHIP_TUNE_MERGED_FINISH): when the step's update is the DENSE pass (the batch touches most of the model, or decay
     // cannot ride in the scale) it runs inside the fixup launch, beside the fixups, instead of as a launch of its own
     const int64_t touched = (int64_t)bm0.n_cols + d->hot_pages * kHotT;
     const bool rows_only = lazy_ok && touched * 2 <= m->n1;

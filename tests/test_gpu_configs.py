@@ -19,6 +19,7 @@ import numpy as np
 import pytest
 
 import oracle
+from sparkfm_amd import _ffi  # noqa: F401  (the tuning keys' names)
 from test_gpu_parity import TOL_Y, check_grad, term_scale
 
 pytestmark = pytest.mark.gpu
@@ -122,16 +123,16 @@ def test_c5_criteo_shape_gradient(fmhip, c5, flat, hot):
     lens = np.diff(rp)
     assert 25 <= lens.min() and lens.max() <= 39 and d["col"].max() < C5_SLOTS and d["val"].max() < 8.0
     try:
-        L.fmhip_tune(8, flat)
-        L.fmhip_tune(5, hot)
+        L.fmhip_tune(_ffi.TUNE_FLAT_ADDRESS, flat)
+        L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, hot)
         ds = fmhip.DataSet.from_arrays(d, batch_rows=C5_BATCH).cache()
         fm = fmhip.FMModel(C5_SLOTS - 1, k)
         fm.w0, fm.w, fm.v = w0, w, v
         sample_rows_check(fm, ds, d, w0, w, v, 2000, 6)
         gv, gw, g0, st = fm.batchGradient(ds, 0)
     finally:
-        L.fmhip_tune(8, 0)
-        L.fmhip_tune(5, 1)
+        L.fmhip_tune(_ffi.TUNE_FLAT_ADDRESS, 0)
+        L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, 1)
     ogv, ogw, og0, osse = c5["grad"]
     check_grad(gv, gw, ogv, ogw, np.abs(v).max())
     assert g0 == pytest.approx(og0, rel=1e-4, abs=1e-2)
@@ -157,8 +158,8 @@ def test_c5_criteo_shape_sgd(fmhip, c5, regs, flat, lazy):
     L = _ffi.load()
     d, k, val, y = c5["d"], c5["k"], c5["val"], c5["y"]
     try:
-        L.fmhip_tune(8, flat)
-        L.fmhip_tune(9, lazy)
+        L.fmhip_tune(_ffi.TUNE_FLAT_ADDRESS, flat)
+        L.fmhip_tune(_ffi.TUNE_LAZY_DECAY, lazy)
         ds = fmhip.DataSet.from_arrays(d, batch_rows=C5_BATCH).cache()
         fm = fmhip.FMModel(C5_SLOTS - 1, k)
         fm.w0, fm.w, fm.v = c5["w0"], c5["w"], c5["v"]
@@ -170,8 +171,8 @@ def test_c5_criteo_shape_sgd(fmhip, c5, regs, flat, lazy):
         mid_rmse = fm.computeRMSE(ds)          # scoring a lazily decayed model: the scale must be applied
         gv, v_after = None, fm.v
     finally:
-        L.fmhip_tune(8, 0)
-        L.fmhip_tune(9, 1)
+        L.fmhip_tune(_ffi.TUNE_FLAT_ADDRESS, 0)
+        L.fmhip_tune(_ffi.TUNE_LAZY_DECAY, 1)
     ow0, ow, ov = c5["w0"], c5["w"], c5["v"]
     for e in range(2):
         ow0, ow, ov, sse = oracle.sgd_epoch(ow0, ow, ov, C5_BATCH, d["row_ptr"], d["col"], val, y, 0.05, *regs,
@@ -460,16 +461,22 @@ def _oracle_two_rank_epochs(n1=800):
     return w0, w, v
 
 
-@pytest.mark.parametrize("k", [32, 16, 64])
-def test_pipelined_exchange_one_rank_over_rccl(fmhip, k):
+@pytest.mark.parametrize("k,hot_ids_on_top", [(32, False), (16, False), (64, False), (32, True), (16, True), (64, True)])
+def test_pipelined_exchange_one_rank_over_rccl(fmhip, k, hot_ids_on_top):
     """FMHIP_EXCHANGE_PIPELINED with one rank over real RCCL (every collective really runs, in place, on the second stream; the
     comm stream held as a 40 GB/s all-reduce would hold it, with the footprint): fmhip_dp_epoch, fmhip_dp_steps over a list of
     positions that wraps around the epoch, and single fmhip_dp_step_at calls give the SAME bits (the overlap changes when things
-    run, not what they compute) and match the plain step up to the order of the forward's fp32 sums, and the fp64 oracle."""
+    run, not what they compute) and match the plain step up to the order of the forward's fp32 sums, and the fp64 oracle.
+    hot_ids_on_top: the ids reversed, so the features of the dense hot block — those in a tenth of the rows and
+    more — carry the HIGHEST ids, at or above the plan's top cut: their parameter rows are still being exchanged while pass A of the
+    next position runs, so the block's prologue must run in pass B (FwdArgs::hot_in_b); read in pass A they would be one update
+    behind, which nothing else would notice (the replicas stay identical)."""
     from sparkfm_amd import _ffi, synth
     from sparkfm_amd.distributed import HipDataParallelSGD, RcclComm
     L = _ffi.load()
     d = synth.make_zipf(93, 5000, 900, 4, 30, zipf_s=1.05)
+    if hot_ids_on_top:
+        d = dict(d, col=(899 - d["col"]).astype(np.int32))
     w0, w, v = synth.init_params(6, 900, k, stdev=0.05)
     w = np.random.default_rng(1).normal(0, 0.05, 900)
     positions = np.array([0, 1, 2, 3, 2, 0, 3, 1, 1], np.int64)
@@ -485,6 +492,8 @@ def test_pipelined_exchange_one_rank_over_rccl(fmhip, k):
             dp = HipDataParallelSGD(comm, eta=0.05, regw=1e-3, regv=1e-3, upper_fractions=(0.1, 0.3, 0.6), exchange="pipelined")
             dp.plan(fm, ds)
             assert len(dp.cuts) == 3
+            if hot_ids_on_top:       # the case is what it claims: a feature of the forward's hot page sits at or above the top cut
+                assert max(ds.layout()["hot_ids"]) >= max(dp.cuts)
             if mode == "epoch+steps":
                 dp.learn(fm, ds)
                 dp.steps_at(fm, ds, positions)                      # fmhip_dp_steps
@@ -562,13 +571,16 @@ def test_bench_with_two_ranks_on_one_gpu():
     (RCCL refuses two ranks on one device).  Timings mean nothing here; the flow and the line's keys are what is tested."""
     import json
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "host", "--steps", "4", "--warmup", "2",
-           "--rows", "200000", "--batch-rows", "100000", "--no-pmc", "--cpu-budget", "3"]
+           "--rows", "200000", "--batch-rows", "100000", "--no-pmc", "--cpu-budget", "3", "--tune-budget", "12"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
-    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
-    assert len(lines) == 1, lines
-    out = json.loads(lines[0])
+    # the record is re-written after every leg: every line is a complete JSON object, the LAST one is the record
+    lines = [json.loads(ln) for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) >= 2 and lines[0]["record"]["stage"] == "headline" and lines[-1]["record"]["final"] is True, [ln["record"] for ln in lines]
+    assert all(ln["value"] == lines[0]["value"] and ln["roofline"] is not None for ln in lines)       # the headline never changes
+    out = lines[-1]
+    assert not out["legs"]["skipped"], out["legs"]
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 4 and out["warmup"] == 2
     assert out["config"]["global_batch"] == 2 * out["config"]["batch_rows_per_gpu"]        # one job: the global batch is what is fixed
     assert out["metric"] == "nnz_per_sec_fm_sgd_training" and out["value"] > 0 and out["ms_per_step"] > 0
@@ -766,8 +778,8 @@ def test_where_the_update_runs_does_not_change_a_bit(fmhip, k, regs, n1):
     a, _ = hot_problem(500 + k, 4000, n1, k, 9)
     outs = []
     for fused, merged in ((0, 1), (0, 0), (1, 0)):
-        L.fmhip_tune(10, fused)
-        L.fmhip_tune(11, merged)
+        L.fmhip_tune(_ffi.TUNE_FUSED_UPDATE, fused)
+        L.fmhip_tune(_ffi.TUNE_MERGED_FINISH, merged)
         try:
             ds = fmhip.DataSet(a["row_ptr"], a["col"], a["val"], a["y"], batch_rows=1100).cache()
             fm = fmhip.FMModel(a["n1"] - 1, k)
@@ -777,8 +789,8 @@ def test_where_the_update_runs_does_not_change_a_bit(fmhip, k, regs, n1):
                 sgd.learn(fm, ds)
             outs.append((fm.w0, fm.w.copy(), fm.v.copy(), sgd.last_stats["sse"]))
         finally:
-            L.fmhip_tune(10, 0)
-            L.fmhip_tune(11, 1)
+            L.fmhip_tune(_ffi.TUNE_FUSED_UPDATE, 0)
+            L.fmhip_tune(_ffi.TUNE_MERGED_FINISH, 1)
         ds.unpersist()
         fm.close()
     # merged == plain always; fused (rows-only form) == plain when the plain update is rows-only too, or there is no decay
@@ -1011,3 +1023,41 @@ def test_relabelling_on_the_gpu_is_the_host_numbering_bit_for_bit(fmhip):
         og.relabel(bad)
     with pytest.raises(_ffi.FmhipError, match="1234567"):
         FeatureOrder.counts(bad, n1, device=0)
+
+
+def test_bench_killed_inside_an_optional_leg_has_left_its_record():
+    """the bench line must not be losable.  `bench.py` writes the whole record as soon as the headline
+    exists and re-writes it after every leg; here the HBM-resident leg is made to hang (FMHIP_BENCH_TEST_STALL), the process is
+    killed once the line before it has appeared, and the last complete line on stdout is a valid record: the driver's
+    keys, `roofline` with HIP-event kernel times and what bounds the step, `cpu_baseline` — everything but the legs that never ran."""
+    import json
+    import signal
+    import time
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--rows", "200000", "--batch-rows", "100000",
+           "--no-pmc", "--cpu-budget", "2", "--settle", "0.1"]
+    env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")},
+               FMHIP_BENCH_TEST_STALL="hbm_resident")
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    os.set_blocking(p.stdout.fileno(), False)
+    t0, data = time.time(), b""
+    while time.time() - t0 < 300 and b'"stage": "extra.scoring"' not in data and p.poll() is None:
+        data += p.stdout.read() or b""
+        time.sleep(0.2)
+    time.sleep(1.0)                       # it is now inside the stalled leg
+    assert p.poll() is None, p.stderr.read().decode()[-3000:]
+    p.send_signal(signal.SIGKILL)
+    p.wait()
+    data += p.stdout.read() or b""
+    import bench
+    out = bench.last_record(data.decode())
+    assert out is not None and out["record"]["stage"] == "extra.scoring" and out["record"]["final"] is False
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in out, key
+    assert out["steps"] == 12 and out["warmup"] == 3 and out["value"] > 0 and out["config"]["settle_steps_before_warmup"] > 0
+    rf = out["roofline"]
+    assert rf["avg_launch_ms"] > 0 and rf["kernel"] in ("k_forward", "k_backward") and "HIP events" in rf["avg_launch_ms_from"]
+    assert rf["compulsory_hbm_bytes_per_step"] > 0 and 0 < rf["hbm_floor_ms"] < out["ms_per_step"] and 0 < rf["step_ceiling_frac"] <= 1.0
+    assert out["cpu_baseline"]["value"] > 0 and out["sustained"]["steps"] > 0 and out["extra"]["scoring"]["value"] > 0
+    assert "hbm_resident" not in out["extra"]
+    lines = [json.loads(ln) for ln in data.decode().splitlines() if ln.strip().startswith("{") and ln.strip().endswith("}")]
+    assert [ln["record"]["stage"] for ln in lines][:2] == ["headline", "cpu_baseline"] and all(ln["value"] == out["value"] for ln in lines)

@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 
 import oracle
+from sparkfm_amd import _ffi  # noqa: F401  (the tuning keys' names)
 from helpers import f, kat_arrays, random_problem
 
 pytestmark = pytest.mark.gpu
@@ -162,7 +163,7 @@ def test_kernel_variants_agree_with_the_oracle(fmhip, fwd, bwd, tile):
     from sparkfm_amd import _ffi
     L = _ffi.load()
     try:
-        L.fmhip_tune(0, fwd), L.fmhip_tune(1, bwd), L.fmhip_tune(2, tile)
+        L.fmhip_tune(_ffi.TUNE_FORWARD_KERNEL, fwd), L.fmhip_tune(_ffi.TUNE_BACKWARD_KERNEL, bwd), L.fmhip_tune(_ffi.TUNE_TILE_ROWS, tile)
         for k in (8, 32, 64, 128):
             a = random_problem(300 + k, 700, 300, k, 0, 30, empty_rows=(1, 699))
             ds, fm = make(fmhip, a, batch_rows=256)
@@ -184,18 +185,18 @@ def test_kernel_variants_agree_with_the_oracle(fmhip, fwd, bwd, tile):
             ds.unpersist()
             fm.close()
     finally:
-        L.fmhip_tune(0, 60), L.fmhip_tune(1, 1), L.fmhip_tune(2, 0)
+        L.fmhip_tune(_ffi.TUNE_FORWARD_KERNEL, 60), L.fmhip_tune(_ffi.TUNE_BACKWARD_KERNEL, 1), L.fmhip_tune(_ffi.TUNE_TILE_ROWS, 0)
 
 
 @pytest.mark.parametrize("rb", [64, 100, 1000])
 def test_row_blocked_transposes(fmhip, rb):
-    """fmhip_tune(3, rb): the batch transposes are sorted by (row block of `rb` rows, feature); a
+    """fmhip_tune(_ffi.TUNE_ROW_BLOCK, rb): the batch transposes are sorted by (row block of `rb` rows, feature); a
     feature occurring in several blocks is cut into pieces summed by k_fixup2.  Same gradient (to fp32
     reassociation), same transposes through the read-back API, deterministic."""
     from sparkfm_amd import _ffi
     L = _ffi.load()
     try:
-        L.fmhip_tune(3, rb)
+        L.fmhip_tune(_ffi.TUNE_ROW_BLOCK, rb)
         for k in (8, 32, 64):
             a = random_problem(700 + k, 900, 150, k, 0, 25, empty_rows=(2, 450))
             for r in range(900):                                    # feature 1 in (almost) every row: many pieces
@@ -228,7 +229,7 @@ def test_row_blocked_transposes(fmhip, rb):
             ds.unpersist()
             fm.close()
     finally:
-        L.fmhip_tune(3, 0)
+        L.fmhip_tune(_ffi.TUNE_ROW_BLOCK, 0)
 
 
 def hot_problem(seed, n_rows, n1, k, n_hot, dup_feature=None, zero_feature=None, n_low=0):
@@ -266,25 +267,25 @@ def hot_problem(seed, n_rows, n1, k, n_hot, dup_feature=None, zero_feature=None,
                                                       (32, 90, 60, 70, 6)])
 @pytest.mark.parametrize("flat", [0, 1])
 def test_dense_hot_block(fmhip, request, k, n_hot, dup, zero, pages, flat):
-    """fmhip_tune(5, 1): the most frequent features (>= 10 % of the rows, none that occurs twice in a row or with a stored
+    """fmhip_tune(_ffi.TUNE_HOT_BLOCK, 1): the most frequent features (>= 10 % of the rows, none that occurs twice in a row or with a stored
     zero) are held in dense [rows][16] pages: the 16 most frequent leave the sparse streams on both sides, up to 112 more
     (fmhip_tune key 12 = pages, at most 8) leave the transposes only and get their gradient rows from the same MFMA block
     product.  Forward, gradient, transposes, epochs and the feature-chunked backward must not notice.  k <= 32 forms all 8
     pages in one pass over P, k = 64 four pages per pass (so 8 pages take two), k = 100 (Kp = 128) one pass per page.  flat=1: the same on the flat-address kernels (fmhip_tune key 8)."""
     from sparkfm_amd import _ffi
     L = _ffi.load()
-    L.fmhip_tune(8, flat)
-    request.addfinalizer(lambda: L.fmhip_tune(8, 0))
+    L.fmhip_tune(_ffi.TUNE_FLAT_ADDRESS, flat)
+    request.addfinalizer(lambda: L.fmhip_tune(_ffi.TUNE_FLAT_ADDRESS, 0))
     a, hot_ids = hot_problem(100 + k, 3000, 500, k, n_hot, dup, zero)
     a["val"] = a["val"].astype(np.float32).astype(np.float64)       # exactly representable in fp32
     n_rows, br = 3000, 700
     try:
-        L.fmhip_tune(5, 1)
-        L.fmhip_tune(12, pages)
+        L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, 1)
+        L.fmhip_tune(_ffi.TUNE_HOT_PAGES, pages)
         ds, fm = make(fmhip, a, batch_rows=br)
     finally:
-        L.fmhip_tune(5, 1)
-        L.fmhip_tune(12, 4)
+        L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, 1)
+        L.fmhip_tune(_ffi.TUNE_HOT_PAGES, 4)
     lay = ds.layout()
     refused = {int(hot_ids[i]) for i in (dup, zero) if i is not None}
     dense = set(lay["hot_ids_all"])
@@ -424,10 +425,10 @@ def test_dense_hot_block_chunked_backward(fmhip):
     L = _ffi.load()
     a, hot_ids = hot_problem(77, 2500, 600, 32, 14)
     try:
-        L.fmhip_tune(5, 1)
+        L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, 1)
         ds, fm = make(fmhip, a, batch_rows=900, stream=torch_stream())
     finally:
-        L.fmhip_tune(5, 1)
+        L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, 1)
     import torch
     from sparkfm_amd.distributed import HipEngine
     eng = HipEngine(fm, ds)
@@ -455,7 +456,7 @@ def test_dense_hot_block_chunked_backward(fmhip):
 
 @pytest.mark.parametrize("k,hot", [(32, 1), (32, 0), (64, 1), (16, 1)])
 def test_band_affine_placement_of_the_backward(fmhip, request, k, hot):
-    """fmhip_model_tune(m, 4, 2): the whole-batch backward takes its ranges from per-XCD lists — the ranges of long columns
+    """fmhip_model_tune(m, _ffi.TUNE_XCD_PLACEMENT, 2): the whole-batch backward takes its ranges from per-XCD lists — the ranges of long columns
     that fall into an XCD's own row bands first (fmhip_dataset.hip: plan_bands) — and forms no wave sums.  Which slot walks a
     range changes nothing about what the range contributes: the gradient must agree with the default placement (to the
     summation order of the cut columns' partials) and with the oracle, run to run bit-identical, and training must track
@@ -463,8 +464,8 @@ def test_band_affine_placement_of_the_backward(fmhip, request, k, hot):
     columns span hundreds of ranges, with and without the dense hot block."""
     from sparkfm_amd import _ffi, synth
     L = _ffi.load()
-    L.fmhip_tune(5, hot)
-    request.addfinalizer(lambda: L.fmhip_tune(5, 1))
+    L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, hot)
+    request.addfinalizer(lambda: L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, 1))
     d = synth.make_zipf(4100 + k, 40_000, 3000, 10, 30, zipf_s=1.05)
     rng = np.random.default_rng(k)
     a = dict(n1=3000, k=k, row_ptr=d["row_ptr"], col=d["col"], val=d["val"].astype(np.float64), y=d["y"].astype(np.float64),
@@ -475,7 +476,7 @@ def test_band_affine_placement_of_the_backward(fmhip, request, k, hot):
     assert lay["planned_ranges"] == lay["ranges"] > 2048 and 0 < lay["band_affine_ranges"] < lay["ranges"]
     grads = {}
     for mode in (0, 2, 2):
-        _ffi.check(L.fmhip_model_tune(fm.handle, 4, mode))
+        _ffi.check(L.fmhip_model_tune(fm.handle, _ffi.TUNE_XCD_PLACEMENT, mode))
         grads.setdefault(mode, []).append(fm.batchGradient(ds, 1))
     (gv0, gw0, g00, st0), = grads[0]
     (gv2, gw2, g02, st2), (gv2b, gw2b, _, _) = grads[2]
@@ -594,7 +595,7 @@ def test_row_lengths_around_the_step_boundaries(fmhip, k, flat):
     from sparkfm_amd import _ffi
     L = _ffi.load()
     if flat:
-        L.fmhip_tune(8, 1)
+        L.fmhip_tune(_ffi.TUNE_FLAT_ADDRESS, 1)
     try:
         ds, fm = make(fmhip, a, batch_rows=1300)               # two batches: the dense hot block may form, too
         yh = fm.predict(ds)
@@ -612,7 +613,7 @@ def test_row_lengths_around_the_step_boundaries(fmhip, k, flat):
         fm.close()
     finally:
         if flat:
-            L.fmhip_tune(8, 0)
+            L.fmhip_tune(_ffi.TUNE_FLAT_ADDRESS, 0)
 
 
 def test_hot_columns_split_over_many_ranges(fmhip):
@@ -988,10 +989,10 @@ def test_full_size_properties(fmhip, config):
 
     def build(hot):
         try:
-            L.fmhip_tune(5, hot)
+            L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, hot)
             ds = fmhip.DataSet.from_arrays(d, batch_rows=br).cache()
         finally:
-            L.fmhip_tune(5, 1)
+            L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, 1)
         fm = fmhip.FMModel(n1 - 1, k, stream=torch_stream())
         fm.w0, fm.w, fm.v = w0, w, v
         return ds, fm
@@ -1106,11 +1107,11 @@ def test_random_shapes_property(fmhip, flat):
     kernels that tables of 4 GiB and more select."""
     from sparkfm_amd import _ffi
     L = _ffi.load()
-    L.fmhip_tune(8, flat)
+    L.fmhip_tune(_ffi.TUNE_FLAT_ADDRESS, flat)
     try:
         _random_shapes(fmhip, L)
     finally:
-        L.fmhip_tune(8, 0)
+        L.fmhip_tune(_ffi.TUNE_FLAT_ADDRESS, 0)
 
 
 def _random_shapes(fmhip, L, seed=20261003, cases=40, skip_diverged=False, ks=(1, 2, 5, 8, 13, 16, 32, 40, 64)):
@@ -1131,10 +1132,10 @@ def _random_shapes(fmhip, L, seed=20261003, cases=40, skip_diverged=False, ks=(1
                     a["col"][s.start] = hot[0]
         regs = (0.01, 0.01, 0.01) if case % 4 else (0.0, 0.0, 0.0)   # no decay: the fused step may update touched rows only
         try:
-            L.fmhip_tune(5, 0 if case % 5 == 4 else 1)               # dense hot block off in a fifth of the cases
+            L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, 0 if case % 5 == 4 else 1)               # dense hot block off in a fifth of the cases
             ds, fm = make(fmhip, a, batch_rows=batch_rows)
         finally:
-            L.fmhip_tune(5, 1)
+            L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, 1)
         info = ds.info()
         nb = info["n_batches"]
         b = int(rng.integers(0, nb))
@@ -1267,13 +1268,13 @@ def test_the_residual_rides_in_the_p_row_exactly(fmhip, k, flat):
     y = rng.normal(0, 1, n_rows) * 10.0 ** rng.integers(-30, 31, n_rows)
     y[:8] = [0.0, -0.0, 1e-38, -1e-38, 3e38, -3e38, 1.0, -1.0]
     a = dict(k=k, n1=n1, w0=0.01, w=rng.normal(0, 0.05, n1), v=rng.normal(0, 0.05, (k, n1)), row_ptr=row_ptr, col=col, val=val, y=y)
-    L.fmhip_tune(8, flat)
+    L.fmhip_tune(_ffi.TUNE_FLAT_ADDRESS, flat)
     try:
         ds, fm = make(fmhip, a, batch_rows=0)
         e = fm.residual(ds).astype(np.float32)
         _, gw, _, _ = fm.batchGradient(ds, 0)
     finally:
-        L.fmhip_tune(8, 0)
+        L.fmhip_tune(_ffi.TUNE_FLAT_ADDRESS, 0)
     got = gw[n_shared:].astype(np.float32)
     assert np.array_equal(got.view(np.uint32), e.view(np.uint32)), int((got.view(np.uint32) != e.view(np.uint32)).sum())
     ds.unpersist()
@@ -1291,7 +1292,7 @@ def test_two_pass_forward_equals_the_forward(fmhip, k, hot):
     from sparkfm_amd import _ffi, synth
     from sparkfm_amd.distributed import HipEngine
     L = _ffi.load()
-    _ffi.check(L.fmhip_tune(5, hot))
+    _ffi.check(L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, hot))
     try:
         n1 = 900
         d = synth.make_zipf(515 + k, 6000, n1, 3, 28, zipf_s=1.05)
@@ -1335,7 +1336,7 @@ def test_two_pass_forward_equals_the_forward(fmhip, k, hot):
         ds.unpersist()
         fm.close()
     finally:
-        _ffi.check(L.fmhip_tune(5, 1))
+        _ffi.check(L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, 1))
 
 
 def test_partitioned_rows_keep_the_als_learner_right(fmhip):

@@ -217,15 +217,18 @@ def test_bench_with_eight_thread_ranks():
     and its wall time are what is tested."""
     import time
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--transport", "threads", "--steps", "4", "--warmup", "2",
-           "--rows", "100000", "--batch-rows", "50000", "--cpu-budget", "3"]
+           "--rows", "100000", "--batch-rows", "50000", "--cpu-budget", "3", "--tune-budget", "12"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     t0 = time.time()
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     wall = time.time() - t0
     assert r.returncode == 0, r.stderr.decode()[-4000:]
-    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
-    assert len(lines) == 1, lines
-    out = json.loads(lines[0])
+    # the record is re-written after every leg: every line is a complete JSON object, the LAST one is the record
+    lines = [json.loads(ln) for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) >= 2 and lines[0]["record"]["stage"] == "headline" and lines[-1]["record"]["final"] is True, [ln["record"] for ln in lines]
+    assert all(ln["value"] == lines[0]["value"] and ln["roofline"] is not None for ln in lines)       # the headline never changes
+    out = lines[-1]
+    assert not out["legs"]["skipped"], out["legs"]
     assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["steps"] == 4 and out["warmup"] == 2
     assert out["config"]["global_batch"] == 8 * out["config"]["batch_rows_per_gpu"]        # one job: the global batch is what is fixed
     assert out["metric"] == "nnz_per_sec_fm_sgd_training" and out["value"] > 0 and out["ms_per_step"] > 0
@@ -235,7 +238,7 @@ def test_bench_with_eight_thread_ranks():
     # the communicator passed its self-test on every rank, and after the timed steps the replicas hold the same bits
     assert "passed" in x["selftest"] and x["replicas"]["identical"] is True and x["replicas"]["rows_compared"] > 1000
     assert {t["exchange"] for t in x["cut_tuning"]} == {"dense", "sharded", "pipelined"} and all(t["ms_per_step"] > 0 for t in x["cut_tuning"])
-    assert any(len(t["cuts"]) == 2 and all(c % 8 == 0 for c in t["cuts"]) for t in x["cut_tuning"] if t["exchange"] == "sharded")
+    assert any(len(t["cuts"]) >= 2 and all(c % 8 == 0 for c in t["cuts"]) for t in x["cut_tuning"] if t["exchange"] == "sharded")
     assert x["exposed_comm_ms"] >= 0 and x["comm_busy_ms"] > 0
     assert x["c3_on_every_gpu"]["value"] > 0 and x["per_gpu_without_exchange"]["value"] > 0
     assert x["c4_one_gpu"]["value"] > 0 and x["scaling_vs_c4_one_gpu"] > 0

@@ -13,17 +13,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol():
+    """Both headers against the binding's two symbol lists and the library: include/fmhip.h is the product surface (what
+    INTEGRATION.md section 1 maps to a reference interface + the data-parallel step), include/fmhip_experimental.h the
+    measurement / experiment surface; no symbol sits in both, the library exports all of them, and the tuning keys are a
+    named enum whose values the binding (and the kernels' own enum, by static_assert in fmhip_api.hip) agree with."""
     from sparkfm_amd import _ffi
     hdr = open(os.path.join(ROOT, "include", "fmhip.h")).read()
+    exp = open(os.path.join(ROOT, "include", "fmhip_experimental.h")).read()
     declared = set(re.findall(r"\b(fmhip_[a-z0-9_]+)\s*\(", hdr))
+    declared_exp = set(re.findall(r"\b(fmhip_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", exp, flags=re.S)))
     assert declared == set(_ffi.SYMBOLS)
+    assert declared_exp == set(_ffi.SYMBOLS_EXPERIMENTAL)
+    assert not declared & declared_exp
+    # the lab equipment is NOT in the product header
+    for name in ("fmhip_tune", "fmhip_comm_emulate", "fmhip_ablation_mask", "fmhip_dataset_band_plan", "fmhip_device_read", "fmhip_profile_begin"):
+        assert name not in declared and name in declared_exp, name
+    assert len(declared) <= 64
     L = _ffi.load()
-    for name in declared:
+    for name in declared | declared_exp:
         assert hasattr(L, name), name
     m = re.search(r"#define FMHIP_VERSION (\d+)", hdr)
-    assert L.fmhip_version() == int(m.group(1)) == 400
+    assert L.fmhip_version() == int(m.group(1)) == 500
     m = re.search(r"#define FMHIP_RANGE_LEN (\d+)", hdr)
     assert int(m.group(1)) == _ffi.RANGE_LEN
+    keys = dict((k, int(v)) for k, v in re.findall(r"\bFMHIP_TUNE_([A-Z_]+) = (\d+)", exp))
+    assert keys.pop("KEY_COUNT") == len(keys) == len(_ffi.TUNE) and keys == _ffi.TUNE
 
 
 def test_shipped_build_carries_no_ablation():
@@ -209,16 +223,20 @@ def test_split_by_random():
 
 
 def test_plain_c_consumer_of_the_header(tmp_path):
-    """include/fmhip.h is C, not just C++: tests/c_abi_smoke.c compiles as strict C99, links against
-    libfmhip.so and exercises the entry points that need no GPU."""
+    """include/fmhip.h is C, not just C++, and is ENOUGH: tests/c_abi_smoke.c includes the slim product header alone,
+    compiles as strict C99, links against libfmhip.so and exercises the entry points that need no GPU;
+    tests/c_abi_experimental_smoke.c does the same for include/fmhip_experimental.h."""
     import subprocess
     from sparkfm_amd import _build
-    exe = str(tmp_path / "c_abi_smoke")
-    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "c_abi_smoke.c"), "-L" + _build.LIBDIR, "-lfmhip",
-                           "-Wl,-rpath," + _build.LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
-    out = subprocess.check_output([exe]).decode()
-    assert "c_abi_smoke ok" in out
+    for name in ("c_abi_smoke", "c_abi_experimental_smoke"):
+        src = open(os.path.join(ROOT, "tests", name + ".c")).read()
+        assert ('#include "fmhip_experimental.h"' in src) == (name != "c_abi_smoke") and ('#include "fmhip.h"' in src) == (name == "c_abi_smoke")
+        exe = str(tmp_path / name)
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", name + ".c"), "-L" + _build.LIBDIR, "-lfmhip",
+                               "-Wl,-rpath," + _build.LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+        out = subprocess.check_output([exe]).decode()
+        assert name + " ok" in out
 
 
 def test_jni_shim_compiles_and_marshals_like_the_c_abi(tmp_path):
@@ -469,3 +487,63 @@ def test_jvm_class_has_no_duplicate_members():
     assert len(every) == len(set(every)), sorted(n for n in every if every.count(n) > 1)
     code = re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", scala, flags=re.S))      # comments may hold "[lo, hi)"
     assert code.count("{") == code.count("}") and code.count("(") == code.count(")") and code.count("[") == code.count("]")
+
+
+def test_bench_record_survives_a_kill_inside_an_optional_leg(tmp_path):
+    """benchkit/emit.py: bench.py writes the WHOLE record as one JSON line as soon as the headline exists and re-writes it after
+    every leg, each leg started only if the wall-clock budget covers its estimate.  Here a stand-in process (no GPU needed) emits
+    a headline, one enriched line, then hangs in an "optional leg" with half a line on stdout; it is killed, and the last COMPLETE
+    line still parses as a valid record — with the enrichment, without the leg that hung; a leg the budget cannot cover is
+    recorded as skipped instead of started."""
+    import json
+    import signal
+    import subprocess
+    import time
+    prog = tmp_path / "emit_then_hang.py"
+    prog.write_text('''
+import os, sys, time
+sys.path.insert(0, %r)
+from benchkit.emit import Budget, Emitter
+b = Budget(30.0)
+e = Emitter(1, b)
+rec = {"metric": "nnz_per_sec_fm_sgd_training", "value": 1.0, "roofline": {"frac": 0.5}, "cpu_baseline": None}
+e.emit(rec, "headline")
+rec["cpu_baseline"] = b.run("cpu_baseline", 1.0, lambda: {"value": 2.0})
+assert b.run("too_long", 1000.0, lambda: 1 / 0) is None          # never started: the estimate does not fit
+e.emit(rec, "cpu_baseline")
+os.write(1, b'{"metric": "half a li')                              # a leg that dies mid-write
+time.sleep(600)
+''' % ROOT)
+    p = subprocess.Popen([sys.executable, str(prog)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    t0, data = time.time(), b""
+    os.set_blocking(p.stdout.fileno(), False)
+    while time.time() - t0 < 60 and b"half a li" not in data:
+        chunk = p.stdout.read()
+        data += chunk or b""
+        time.sleep(0.05)
+    p.send_signal(signal.SIGKILL)
+    p.wait()
+    assert b"half a li" in data, (data, p.stderr.read())
+    from benchkit.emit import last_record
+    rec = last_record(data.decode())
+    assert rec["record"] == {"line": 2, "stage": "cpu_baseline", "final": False, "note": rec["record"]["note"]}
+    assert rec["cpu_baseline"] == {"value": 2.0} and rec["roofline"]["frac"] == 0.5 and rec["value"] == 1.0
+    assert "too_long" in rec["legs"]["skipped"] and "cpu_baseline" in rec["legs"]["seconds"] and rec["legs"]["time_budget_s"] == 30.0
+    first = json.loads(data.decode().splitlines()[0])
+    assert first["record"]["stage"] == "headline" and first["cpu_baseline"] is None and first["value"] == 1.0
+
+
+def test_bench_roofline_says_what_bounds_the_step():
+    """benchkit/roofline.py (VERDICT r4 #8): the compulsory HBM bytes of a C3 step (every stream once, the hot pages once, one
+    pass each over P, V and G) are ~0.25-0.3 GB = ~35 us at 8 TB/s — a fraction of the measured step — and an algorithmic
+    fraction above 1 is labelled as a model that is not a bound."""
+    import bench
+    comp = bench.compulsory_hbm_bytes(32, 250_000, 8_000_000, 6_600_000, 90_000, 100_004, 4)
+    assert comp["total"] == comp["streams"] + comp["xhot"] + comp["P_V_G_one_pass_each"] and 2.0e8 < comp["total"] < 3.5e8
+    roof = {"algorithmic_frac": 1.31, "frac": 0.66}
+    bench.annotate_roofline(roof, comp, 0.2415, 0.74)
+    assert roof["compulsory_hbm_bytes_per_step"] == comp["total"] and 0.02 < roof["hbm_floor_ms"] < 0.05
+    assert 0.1 < roof["hbm_floor_share_of_step"] < 0.2 and roof["step_ceiling_frac"] == 0.74
+    assert roof["algorithmic_label"].startswith("model not a bound: tables cache-resident, hot block gathers nothing")
+    roof2 = bench.annotate_roofline({"algorithmic_frac": 0.8}, comp, 0.3)
+    assert "algorithmic_label" not in roof2 and "step_ceiling_frac" not in roof2

@@ -40,25 +40,25 @@ def main():
     n1 = cfg["features"]
     w0, w, v = synth.init_params(1, n1, k)
     if args.row_block:
-        _ffi.load().fmhip_tune(3, args.row_block)
-    _ffi.load().fmhip_tune(5, args.hot)
-    _ffi.load().fmhip_tune(6, args.fwd_occ)
-    _ffi.load().fmhip_tune(7, args.row_order)
+        _ffi.load().fmhip_tune(_ffi.TUNE_ROW_BLOCK, args.row_block)
+    _ffi.load().fmhip_tune(_ffi.TUNE_HOT_BLOCK, args.hot)
+    _ffi.load().fmhip_tune(_ffi.TUNE_FORWARD_OCCUPANCY, args.fwd_occ)
+    _ffi.load().fmhip_tune(_ffi.TUNE_ROW_ORDER, args.row_order)
     ds = DataSet.from_arrays(d, batch_rows=min(args.batch_rows, rows)).cache()
     fm = FMModel(n1 - 1, k)
     fm.w0, fm.w, fm.v = w0, w, v
     L = _ffi.load()
     hm, hd, nb = fm.handle, ds.handle, ds.n_batches
     if args.tile:
-        L.fmhip_tune(2, args.tile)
+        L.fmhip_tune(_ffi.TUNE_TILE_ROWS, args.tile)
     if args.xcd:
-        L.fmhip_tune(4, args.xcd)
+        L.fmhip_tune(_ffi.TUNE_XCD_PLACEMENT, args.xcd)
     variants = list(itertools.product([int(x) for x in args.fwd.split(",")], [int(x) for x in args.bwd.split(",")]))
     res = {vv: [] for vv in variants}
     for rnd in range(args.rounds + 1):
         for vv in variants:
-            L.fmhip_tune(0, vv[0])
-            L.fmhip_tune(1, vv[1])
+            L.fmhip_tune(_ffi.TUNE_FORWARD_KERNEL, vv[0])
+            L.fmhip_tune(_ffi.TUNE_BACKWARD_KERNEL, vv[1])
             _ffi.check(L.fmhip_profile_begin(hm))
             for j in range(nb):
                 _ffi.check(L.fmhip_sgd_step(hm, hd, j, 0.02, 0.0, 1e-4, 1e-4, None))

@@ -19,7 +19,7 @@ from test_gpu_parity import make  # noqa: E402
 seed, want = int(sys.argv[1]), int(sys.argv[2])
 ks = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [1, 2, 5, 8, 13, 16, 32, 40, 64]
 L = _ffi.load()
-L.fmhip_tune(8, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
+L.fmhip_tune(_ffi.TUNE_FLAT_ADDRESS, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
 rng = np.random.default_rng(seed)
 for case in range(want + 1):
     k = int(rng.choice(ks))
@@ -110,9 +110,9 @@ if os.environ.get("QUICK"):
 # as each differs from the oracle, it is the dynamics.
 gpu_v, gpu_w0 = fm.v.copy(), fm.w0
 ds.unpersist(); fm.close()
-L.fmhip_tune(5, 0)
+L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, 0)
 ds, fm = make(fmhip, a, batch_rows=batch_rows)
-L.fmhip_tune(5, 1)
+L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, 1)
 fmhip.HipSGD(eta=eta, reg0=regs[0], regw=regs[1], regv=regs[2]).learn(fm, ds)
 print("hot block off: |v - oracle| %.3e, |v - v(hot on)| %.3e (hot on vs oracle: %.3e); w0 %.9g vs %.9g (hot on) vs %.9g (oracle)"
       % (np.linalg.norm(fm.v - v), np.linalg.norm(fm.v - gpu_v), np.linalg.norm(gpu_v - v), fm.w0, gpu_w0, w0))
@@ -121,9 +121,9 @@ print("hot block off: |v - oracle| %.3e, |v - v(hot on)| %.3e (hot on vs oracle:
 # where does a hot-block deviation enter: predictions and the first batch's gradient at the INITIAL parameters, block on / off
 for hot_on in (1, 0):
     ds.unpersist(); fm.close()
-    L.fmhip_tune(5, hot_on)
+    L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, hot_on)
     ds, fm = make(fmhip, a, batch_rows=batch_rows)
-    L.fmhip_tune(5, 1)
+    L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, 1)
     yh = fm.predict(ds)
     oy = oracle.predict(a["w0"], a["w"], a["v"], a["row_ptr"], a["col"], a["val"])
     bi = ds.batch_info(0)

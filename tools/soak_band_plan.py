@@ -34,17 +34,17 @@ for seed in range(first, first + n_cases):
     a = dict(n1=n1, k=k, row_ptr=d["row_ptr"], col=d["col"], val=d["val"].astype(np.float64), y=d["y"].astype(np.float64),
              w0=0.1, w=rng.normal(0, 0.05, n1), v=rng.normal(0, 0.05, (k, n1)))
     try:
-        L.fmhip_tune(5, hot)
+        L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, hot)
         ds, fm = make(fmhip, a, batch_rows=br)
     finally:
-        L.fmhip_tune(5, 1)
+        L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, 1)
     lay = ds.layout()
     try:
         for b in (0, ds.n_batches - 1):
             r0, r1 = b * br, min(n_rows, (b + 1) * br)
             g = {}
             for mode in (0, 2, 2):
-                _ffi.check(L.fmhip_model_tune(fm.handle, 4, mode))
+                _ffi.check(L.fmhip_model_tune(fm.handle, _ffi.TUNE_XCD_PLACEMENT, mode))
                 g.setdefault(mode, []).append(fm.batchGradient(ds, b))
             (gv0, gw0, g00, st0), = g[0]
             (gv2, gw2, g02, st2), (gv2b, gw2b, _, _) = g[2]

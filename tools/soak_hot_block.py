@@ -42,10 +42,10 @@ for seed in range(first, first + n_cases):
         a["w"] = np.concatenate([a["w"], rng.normal(0, 0.1, pad)])
         a["v"] = np.concatenate([a["v"], rng.normal(0, 0.1, (k, pad))], axis=1)
     try:
-        L.fmhip_tune(8, flat), L.fmhip_tune(5, 1), L.fmhip_tune(12, pages)
+        L.fmhip_tune(_ffi.TUNE_FLAT_ADDRESS, flat), L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, 1), L.fmhip_tune(_ffi.TUNE_HOT_PAGES, pages)
         ds, fm = make(fmhip, a, batch_rows=br)
     finally:
-        L.fmhip_tune(8, 0), L.fmhip_tune(5, 1), L.fmhip_tune(12, 4)
+        L.fmhip_tune(_ffi.TUNE_FLAT_ADDRESS, 0), L.fmhip_tune(_ffi.TUNE_HOT_BLOCK, 1), L.fmhip_tune(_ffi.TUNE_HOT_PAGES, 4)
     try:
         yh = fm.predict(ds)
         oy = oracle.predict(a["w0"], a["w"], a["v"], a["row_ptr"], a["col"], a["val"])

@@ -19,9 +19,9 @@ ks = tuple(int(x) for x in sys.argv[4].split(",")) if len(sys.argv) > 4 else (1,
 L = _ffi.load()
 for s in range(n_seeds):
     for flat in (0, 1):
-        L.fmhip_tune(8, flat)
+        L.fmhip_tune(_ffi.TUNE_FLAT_ADDRESS, flat)
         try:
             t._random_shapes(sparkfm_amd, L, seed=20261003 + first + s, cases=cases, skip_diverged=True, ks=ks)
         finally:
-            L.fmhip_tune(8, 0)
+            L.fmhip_tune(_ffi.TUNE_FLAT_ADDRESS, 0)
         print("seed %d flat %d: %d cases ok" % (20261003 + first + s, flat, cases), flush=True)
