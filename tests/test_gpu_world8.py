@@ -359,3 +359,148 @@ def test_a_transport_that_fails_in_mid_step_is_an_error_not_a_crash(exchange):
     _ffi.check(L.fmhip_comm_destroy(h))
     fm.close(discard=True)
     ds.unpersist()
+
+
+@pytest.mark.parametrize("fault", ["different_orders", "not_a_permutation"])
+def test_ranks_that_disagree_about_the_epoch_order_fail_together(fault):
+    """fmhip_dp_epoch_order: the order array is "the same on every rank by contract" — the mistake the check
+    exists to catch is a rank whose copy differs.  The order's validity and a hash of its content travel in the epoch's opening
+    max-reduce, so a bad or different array on ONE rank makes EVERY rank return FMHIP_ERR_INVALID before the first step's
+    collective; nobody is left waiting in one, and the same communicator then runs a regular epoch."""
+    import dp_cases
+    from sparkfm_amd import DataSet, FMModel, _ffi
+    from sparkfm_amd.distributed import HipDataParallelSGD, ThreadStagedComm, run_thread_ranks
+    L = _ffi.load()
+    cfg = case8(rows=[1500, 1500, 1000], exchange="dense", batch_rows=500, epochs=1)
+    w0, w, v = dp_cases.init(cfg)
+
+    def body(r, g):
+        ds = DataSet.from_arrays(dp_cases.shard(cfg, r), batch_rows=500, device=0).cache()
+        fm = FMModel(cfg["n1"] - 1, 32, device=0)
+        fm.w0, fm.w, fm.v = w0, w, v
+        comm = ThreadStagedComm(fm, r, g)
+        dp = HipDataParallelSGD(comm, eta=0.05, regw=1e-3, regv=1e-3, exchange="dense", upper_fractions=(0.3,))
+        dp.plan(fm, ds)
+        order = np.array([2, 0, 1], np.int64)
+        if r == 1:
+            order = np.array([1, 0, 2], np.int64) if fault == "different_orders" else np.array([2, 2, 1], np.int64)
+        rc = L.fmhip_dp_epoch_order(fm.handle, ds.handle, comm.handle, 0.05, 0.0, 1e-3, 1e-3, _ffi.ptr(order), 3, None)
+        msg = L.fmhip_last_error().decode()
+        n_calls = len(getattr(comm, "calls", []))
+        g.barrier()
+        dp.learn(fm, ds, order=[2, 0, 1])                 # the communicator is as good as before
+        out = (rc, msg, n_calls, fm.v.copy())
+        g.barrier()
+        comm.close()
+        ds.unpersist()
+        fm.close(discard=True)
+        return out
+
+    res = run_thread_ranks(3, body, timeout=120.0)
+    for r, (rc, msg, _, _) in enumerate(res):
+        assert rc == -1, (r, rc, msg)                      # FMHIP_ERR_INVALID on every rank
+        assert ("DIFFERENT orders" in msg) if fault == "different_orders" else ("permutation" in msg), (r, msg)
+    assert res[0][2] == res[1][2] == res[2][2]             # ... after the same collectives (the plan's and the epoch's agreement, no step's)
+    np.testing.assert_array_equal(res[0][3], res[1][3])
+    np.testing.assert_array_equal(res[0][3], res[2][3])
+
+
+@pytest.mark.parametrize("exchange", ["dense", "sharded"])
+def test_a_run_of_steps_survives_a_batch_only_one_rank_rejects(exchange):
+    """fmhip_dp_steps in the non-pipelined modes: a position whose batch fails a check only ONE rank can see
+    (here: a dataset the plan has not seen, with a larger batch) must not end that rank's run — its peers would be alone in
+    the next position's collectives.  The rank contributes zeros to every such position, takes every step, and gets the error
+    afterwards; the other rank's run completes and equals the oracle over its own rows."""
+    import dp_cases
+    from sparkfm_amd import DataSet, FMModel, _ffi
+    from sparkfm_amd.distributed import HipDataParallelSGD, ThreadStagedComm, run_thread_ranks
+    L = _ffi.load()
+    cfg = case8(rows=[1000, 1000], exchange=exchange, batch_rows=500, epochs=1, n1=808)
+    w0, w, v = dp_cases.init(cfg)
+    positions = np.array([0, 1, 0], np.int64)
+
+    def body(r, g):
+        ds = DataSet.from_arrays(dp_cases.shard(cfg, r), batch_rows=500, device=0).cache()
+        fm = FMModel(cfg["n1"] - 1, 32, device=0)
+        fm.w0, fm.w, fm.v = w0, w, v
+        comm = ThreadStagedComm(fm, r, g)
+        dp = HipDataParallelSGD(comm, eta=0.05, regw=1e-3, regv=1e-3, exchange=exchange, upper_fractions=(0.3,))
+        dp.plan(fm, ds)
+        run_ds = ds
+        if r == 1:      # the same rows cut into ONE batch of 1000: larger than anything the plan agreed on
+            run_ds = DataSet.from_arrays(dp_cases.shard(cfg, r), batch_rows=1000, device=0).cache()
+        rc = L.fmhip_dp_steps(fm.handle, run_ds.handle, _ffi.ptr(positions), 3, comm.handle, 0.05, 0.0, 1e-3, 1e-3)
+        msg = L.fmhip_last_error().decode()
+        fm._device_updated()
+        out = (rc, msg, fm.w0, fm.w.copy(), fm.v.copy())
+        g.barrier()
+        comm.close()
+        if run_ds is not ds:
+            run_ds.unpersist()
+        ds.unpersist()
+        fm.close(discard=True)
+        return out
+
+    r0, r1 = run_thread_ranks(2, body, timeout=120.0)
+    assert r0[0] == 0, r0[:2]
+    assert r1[0] == -1 and "contributed zeros" in r1[1] and "fmhip_dp_plan" in r1[1], r1[:2]
+    # both replicas took the same three steps over rank 0's rows alone (rank 1's position 1 does not exist in its one-batch
+    # dataset and position 0 was refused: zeros every time) and hold the same bits
+    np.testing.assert_array_equal(r0[4], r1[4])
+    d0 = dp_cases.shard(cfg, 0)
+    ow0, ow, ov = w0, w.copy(), v.copy()
+    for p in positions:
+        ow0, ow, ov, _ = oracle.sgd_step(ow0, ow, ov, int(p) * 500, int(p) * 500 + 500, d0["row_ptr"], d0["col"], d0["val"].astype(np.float64),
+                                         d0["y"].astype(np.float64), 0.05, 0.0, 1e-3, 1e-3)
+    assert np.linalg.norm(r0[4] - ov) <= 1e-5 * np.linalg.norm(ov) and np.linalg.norm(r0[3] - ow) <= 1e-5 * np.linalg.norm(ow)
+
+
+def test_two_models_on_one_dataset_under_the_pipelined_exchange():
+    """the pipelined exchange partitions every row's entries at its plan's top cut.  The partition lives in
+    a COPY of the stream (the dataset's own streams never move, so another thread scoring with the dataset is not disturbed),
+    is made under the dataset's own lock, and is held while a run walks it: a second model whose plan has ANOTHER top cut gets
+    an error that says so (and contributes zeros: no peer hangs) instead of re-partitioning under the first run's launches.
+    Here, one rank per model over real one-rank communicators: model A runs pipelined epochs on the shared dataset while a second
+    thread scores through a frozen model on the SAME dataset — the scores are the bits a lone caller gets; then the partition is
+    re-made for a plan with another cut once nobody holds it."""
+    import sparkfm_amd
+    from sparkfm_amd import _ffi, synth
+    from sparkfm_amd.distributed import HipDataParallelSGD, RcclComm
+    L = _ffi.load()
+    d = synth.make_zipf(77, 6000, 1200, 4, 30, zipf_s=1.05)
+    w0, w, v = synth.init_params(8, 1200, 32, stdev=0.05)
+    ds = sparkfm_amd.DataSet.from_arrays(d, batch_rows=1500).cache()
+    frozen = sparkfm_amd.FMModel(1199, 32)
+    frozen.w0, frozen.w, frozen.v = 0.1, np.random.default_rng(2).normal(0, 0.05, 1200), v
+    want = frozen.predict(ds)
+    fm = sparkfm_amd.FMModel(1199, 32)
+    fm.w0, fm.w, fm.v = w0, w, v
+    comm = RcclComm(fm, 0, 1).selftest()
+    dp = HipDataParallelSGD(comm, eta=0.05, regw=1e-3, regv=1e-3, upper_fractions=(0.1, 0.4), exchange="pipelined")
+    dp.plan(fm, ds)
+    got, stop = [], threading.Event()
+
+    def scorer():
+        while not stop.is_set():
+            got.append(frozen.predict(ds))
+
+    t = threading.Thread(target=scorer)
+    t.start()
+    for _ in range(6):
+        dp.learn(fm, ds)
+    _ffi.check(L.fmhip_synchronize(fm.handle))
+    stop.set()
+    t.join()
+    assert len(got) >= 1 and all(np.array_equal(g, want) for g in got)
+    cuts_a = list(dp.cuts)
+    # another plan, another top cut: once the first run is over the partition is simply re-made
+    dp.upper_fractions = (0.3,)
+    dp.plan(fm, ds)
+    assert max(dp.cuts) != max(cuts_a)
+    dp.learn(fm, ds)
+    fm._device_updated()
+    assert np.isfinite(fm.v).all()
+    comm.close()
+    ds.unpersist()
+    fm.close(discard=True)
+    frozen.close(discard=True)

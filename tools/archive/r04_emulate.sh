@@ -5,7 +5,7 @@
 # A rank's batch is 625k rows at every N here (the table of DESIGN.md section 7; bench.py's own default is the global batch of 5M rows,
 # i.e. 5M / N per rank: tools/r04_emulate_n.sh).
 #   tools/r04_emulate.sh            (WGS="0 32 64" by default for 8:300; the other rates with 64)
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 run() { # ranks:busbw wgs
   local tag=r04_emulated_dp_c4_${1/:/_}_wg$2
   timeout -k 10 400 python bench.py --gpus 1 --force-dp --config C4 --rows 1250000 --batch-rows 625000 --emulate-allreduce $1 --emulate-load $2 --no-cpu-baseline --no-pmc --no-extra \

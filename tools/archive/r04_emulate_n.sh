@@ -4,7 +4,7 @@
 #   per-rank batch fixed at 625k rows (the N = 8 line's; round 3/4's bench default at every N), and
 #   GLOBAL batch fixed at 5M rows (per-rank batch 5M / N: the same SGD trajectory whatever N).
 # Bus bandwidths: 56 % and 84 % of the links' one-way sum ((N-1) x 76.8 GB/s) - the 300 and 450 GB/s of the N = 8 table.
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 run() { # ranks busbw batch_rows rows
   local tag=r04_emulated_dp_c4_$1_$2_b$3
   timeout -k 10 500 python3 bench.py --gpus 1 --force-dp --config C4 --rows $4 --batch-rows $3 --emulate-allreduce $1:$2 --emulate-load 32 \

@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX: the three dense-family exchange modes (dense, sharded, pipelined) at C4 against emulated collectives with
 # their footprint — one real rank plays rank 0 of N; cut and mode tuned by the bench itself (exchange.cut_tuning holds every
 # candidate).  RATES = "ranks:busbw ..." (default: 8:300 8:450 8:200); a rank's batch is 625k rows.
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 for r in ${RATES:-8:300 8:450 8:200}; do
   tag=r04_emulated_dp_c4_${r/:/_}_wg64_modes3

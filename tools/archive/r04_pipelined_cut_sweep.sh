@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.." 2>/dev/null
+cd "$(dirname "$0")/../.." 2>/dev/null
 for fr in "0.04,0.1,0.3" "0.035,0.09,0.3" "0.04,0.1,0.25" "0.045,0.11,0.35" "0.04,0.12,0.3" "0.03,0.08,0.25" "0.05,0.1,0.3" "0.04,0.08,0.3" "0.04,0.1,0.2,0.45" "0.04,0.1,0.4"; do
   timeout -k 10 200 python bench.py --gpus 1 --force-dp --config C4 --rows 1250000 --batch-rows 625000 --emulate-allreduce 8:300 --emulate-load 64 \
       --no-cpu-baseline --no-pmc --no-extra --dp-exchange pipelined --upper-fractions $fr > gpurun_out/sweep_one.json 2> gpurun_out/sweep_one.err

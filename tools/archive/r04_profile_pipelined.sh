@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX: rocprofv3 kernel trace of the pipelined data-parallel step at C4's width against emulated 8 x 300 GB/s
 # collectives (one real rank; cuts (0.04, 0.1, 0.3)) -> gpurun_out/r04_pipelined_kernel_stats.csv, condensed into
 # gpurun_out/r04_pipelined_summary.txt (what profiles/r04_pipelined_summary.txt is a copy of).
-root=$(cd "$(dirname "$0")/.." && pwd)
+root=$(cd "$(dirname "$0")/../.." && pwd)
 export TMPDIR=/tmp
 mkdir -p $root/gpurun_out
 cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_pipe -o pipe --output-format csv -- \
