@@ -381,105 +381,73 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
     sync()
     barrier()
 
-    # ---- N > 1: measure, don't guess — the best cut, and which exchange mode pays, depend on the collectives' real bandwidth
-    # on this node.  Candidates in order of likely merit, 8 steps each, under a WALL-CLOCK budget: every rank learns every
-    # candidate's agreed (max over ranks) cost, so all of them stop after the same candidate.
-    tuning = tuning_note = None
-    if exchange == "rccl" and args.upper_fractions == "auto" and (world > 1 or args.emulate_allreduce or dp.exchange == "touched"):
-        tuning = []
-        if dp.exchange == "touched":
-            order = [("touched", c_) for c_ in TOUCHED_CANDS]
-        elif args.dp_exchange == "auto":
-            order = list(TUNE_ORDER)
-        else:
-            order = [(m_, c_) for m_, c_ in TUNE_ORDER if m_ == dp.exchange]
-            order += [(dp.exchange, c_) for c_ in sorted({c_ for _, c_ in TUNE_ORDER}) if (dp.exchange, c_) not in order]
-        spent, seen_modes = 0.0, set()
-        for mode, cand in order:
-            # every mode gets its first candidate whatever the budget says (a record without one of the modes cannot say which is best)
-            if spent > args.tune_budget and mode in seen_modes:
-                continue
-            t_c = time.perf_counter()
-            dp.set_exchange(mode)
-            dp.upper_fractions = cand
-            dp.plan(fm, ds)
-            step(0)
-            sync()
-            barrier()
-            t0 = time.perf_counter()
-            steps_run(0, 8)          # (8: a pipelined run's first forward pass and last slice are not overlapped with anything)
-            sync()
-            tt = ctl.allreduce([time.perf_counter() - t0, time.perf_counter() - t_c], "max")
-            tuning.append({"exchange": mode, "upper_fractions": list(cand), "cuts": list(dp.cuts), "ms_per_step": tt[0] / 8 * 1e3})
-            spent += tt[1]
-            seen_modes.add(mode)
-        tuning_note = "%d of %d candidates timed in %.1f s (--tune-budget %.0f s; every mode at least once)" % (len(tuning), len(order), spent, args.tune_budget)
-        log("cut / mode sweep: " + tuning_note)
-        best = min(tuning, key=lambda x: x["ms_per_step"])
-        dp.set_exchange(best["exchange"])
-        dp.upper_fractions = tuple(best["upper_fractions"])
-        dp.plan(fm, ds)
-        steps_run(0, 4)
-        sync()
-        barrier()
-
-    # ---- the timed region: exactly K steps between barriers, no event records inside
-    sync()
-    barrier()
-    t0 = time.perf_counter()
-    steps_run(args.warmup, args.steps)
-    enqueue_s = time.perf_counter() - t0          # what the HOST needed to queue the steps (it must stay ahead of the GPU)
-    sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    local_nnz = sum(bnnz[j % nb] for j in range(args.warmup, args.warmup + args.steps))
-    elapsed = ctl.allreduce([elapsed], "max")[0]
-    total_nnz = ctl.allreduce([float(local_nnz)], "sum")[0]
-    st = _ffi.Stats()
-    _ffi.check(L.fmhip_step_stats(hm, C.byref(st)))
-    log("timed region done: %d steps, %.4f ms/step" % (args.steps, elapsed / max(args.steps, 1) * 1e3))
-
-    # ---- per-kernel times: a pass of the same steps right behind the timed region, every kernel of every step between a pair
-    # of HIP events on the library's own stream (the records cost ~4 us each between the kernels, nothing inside them)
-    prof = _ffi.Profile()
+    elapsed = total_nnz = enqueue_s = value = step_ms = 0.0
+    st = prof = cprof = replicas = None
     kernel_pass_steps = 0
-    if not os.environ.get("FMHIP_BENCH_NO_EVENTS"):
-        kernel_pass_steps = int(min(max(args.steps, 12), 48))
-        _ffi.check(L.fmhip_profile_begin(hm))
-        steps_run(args.warmup, kernel_pass_steps)
-        sync()
-        _ffi.check(L.fmhip_profile_end(hm, C.byref(prof)))
-    cprof = None
-    if comm is not None:
-        # the exchange's own timers (a dozen event records per step) run in a short pass of their own too
-        _ffi.check(L.fmhip_comm_profile_begin(comm.handle))
-        steps_run(0, 12)
-        sync()
-        cp = _ffi.CommProfile()
-        _ffi.check(L.fmhip_comm_profile_end(comm.handle, C.byref(cp)))
-        cprof = cp.as_dict()
-        barrier()
 
-    # ---- do the replicas still agree?  Every rank has taken the same steps up to here (rank 0's legs below are its own): 4,160
-    # parameter rows spread over every feature interval, and w0, must be the SAME BITS on all ranks — a collective that moved the
-    # wrong elements, or an update that differed, shows here and not as a throughput number from models that have drifted apart
-    replicas = None
-    if use_dp:
-        ids = np.unique(np.concatenate([np.arange(min(64, n1)), np.linspace(0, n1 - 1, 4096).astype(np.int64)])).astype(np.int32)
-        rw, rv = fm.rows(ids)
-        wts = np.cos(np.arange(rv.size, dtype=np.float64) * 0.7310585786)           # fixed weights: a permutation of rows shows too
-        sums = [float(fm.w0), float(rw.sum()), float(rv.sum()), float(np.dot(rv.ravel(order="F"), wts))]
-        hi_ = ctl.allreduce(sums, "max")
-        lo_ = ctl.allreduce([-x for x in sums], "max")
-        finite = all(np.isfinite(x) for x in sums)
-        replicas = {"identical": bool(finite and all(a == -b for a, b in zip(hi_, lo_))), "rows_compared": int(len(ids)), "finite": bool(finite),
-                    "note": "w0 and %d parameter rows spread over all feature intervals: plain and weighted fp64 sums, max == min over the ranks" % len(ids)}
-        if not replicas["identical"]:
-            log("REPLICAS DIFFER after the timed steps: max %r, -min %r" % (hi_, lo_))
+    # ---- the timed region: exactly K steps between barriers, no event records inside; then the per-kernel pass, the
+    # exchange's own timers and the replica check.  A function: at N > 1 it runs TWICE — once with the default plan BEFORE the
+    # cut / mode sweep, so that a headline line exists whatever the sweep then does on a node nobody has seen (a mode that hangs
+    # over real RCCL must not cost the record), and once with the plan the sweep chose.
+    def measure():
+        nonlocal elapsed, total_nnz, enqueue_s, st, prof, kernel_pass_steps, cprof, replicas, value, step_ms
+        sync()
+        barrier()
+        t0 = time.perf_counter()
+        steps_run(args.warmup, args.steps)
+        enqueue_s = time.perf_counter() - t0          # what the HOST needed to queue the steps (it must stay ahead of the GPU)
+        sync()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        local_nnz = sum(bnnz[j % nb] for j in range(args.warmup, args.warmup + args.steps))
+        elapsed = ctl.allreduce([elapsed], "max")[0]
+        total_nnz = ctl.allreduce([float(local_nnz)], "sum")[0]
+        st = _ffi.Stats()
+        _ffi.check(L.fmhip_step_stats(hm, C.byref(st)))
+        log("timed region done: %d steps, %.4f ms/step" % (args.steps, elapsed / max(args.steps, 1) * 1e3))
+
+        # ---- per-kernel times: a pass of the same steps right behind the timed region, every kernel of every step between a pair
+        # of HIP events on the library's own stream (the records cost ~4 us each between the kernels, nothing inside them)
+        prof = _ffi.Profile()
+        kernel_pass_steps = 0
+        if not os.environ.get("FMHIP_BENCH_NO_EVENTS"):
+            kernel_pass_steps = int(min(max(args.steps, 12), 48))
+            _ffi.check(L.fmhip_profile_begin(hm))
+            steps_run(args.warmup, kernel_pass_steps)
+            sync()
+            _ffi.check(L.fmhip_profile_end(hm, C.byref(prof)))
+        cprof = None
+        if comm is not None:
+            # the exchange's own timers (a dozen event records per step) run in a short pass of their own too
+            _ffi.check(L.fmhip_comm_profile_begin(comm.handle))
+            steps_run(0, 12)
+            sync()
+            cp = _ffi.CommProfile()
+            _ffi.check(L.fmhip_comm_profile_end(comm.handle, C.byref(cp)))
+            cprof = cp.as_dict()
+            barrier()
+
+        # ---- do the replicas still agree?  Every rank has taken the same steps up to here (rank 0's legs below are its own): 4,160
+        # parameter rows spread over every feature interval, and w0, must be the SAME BITS on all ranks — a collective that moved the
+        # wrong elements, or an update that differed, shows here and not as a throughput number from models that have drifted apart
+        replicas = None
+        if use_dp:
+            ids = np.unique(np.concatenate([np.arange(min(64, n1)), np.linspace(0, n1 - 1, 4096).astype(np.int64)])).astype(np.int32)
+            rw, rv = fm.rows(ids)
+            wts = np.cos(np.arange(rv.size, dtype=np.float64) * 0.7310585786)           # fixed weights: a permutation of rows shows too
+            sums = [float(fm.w0), float(rw.sum()), float(rv.sum()), float(np.dot(rv.ravel(order="F"), wts))]
+            hi_ = ctl.allreduce(sums, "max")
+            lo_ = ctl.allreduce([-x for x in sums], "max")
+            finite = all(np.isfinite(x) for x in sums)
+            replicas = {"identical": bool(finite and all(a == -b for a, b in zip(hi_, lo_))), "rows_compared": int(len(ids)), "finite": bool(finite),
+                        "note": "w0 and %d parameter rows spread over all feature intervals: plain and weighted fp64 sums, max == min over the ranks" % len(ids)}
+            if not replicas["identical"]:
+                log("REPLICAS DIFFER after the timed steps: max %r, -min %r" % (hi_, lo_))
+
+        value = total_nnz / elapsed
+        step_ms = elapsed / args.steps * 1e3
 
     # ---- the record (rank 0 builds and re-writes it; the other ranks only take part in the collective legs)
-    value = total_nnz / elapsed
-    step_ms = elapsed / args.steps * 1e3
     kp = 32
     while kp < k:
         kp *= 2
@@ -577,7 +545,10 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
                 xc["emulated"] += "; the delay is spent by %d workgroups streaming the payload through HBM (read + write, twice per all-reduce)" % args.emulate_load
         out["exchange"] = xc
 
-    if rank == 0:
+    def headline(stage):
+        """Rank 0 (re)builds the record from the latest measure() and writes it."""
+        if rank != 0:
+            return
         state["pmc"] = committed_pmc(config, k, batch_rows)
         out.update({
             "metric": "nnz_per_sec_fm_sgd_training", "value": value, "unit": "nnz/s",
@@ -619,8 +590,57 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
         build_roofline()
         if use_dp:
             exchange_block()
-        emitter.emit(out, "headline")
-        log("headline line written: %.2f G nnz/s" % (value / 1e9))
+        emitter.emit(out, stage)
+        log("%s line written: %.2f G nnz/s" % (stage, value / 1e9))
+
+    tuning = tuning_note = None
+    sweeping = exchange == "rccl" and args.upper_fractions == "auto" and (world > 1 or args.emulate_allreduce or dp.exchange == "touched")
+    if sweeping and world > 1:
+        measure()
+        headline("headline (default plan, before the cut / mode sweep)")
+    # ---- N > 1: measure, don't guess — the best cut, and which exchange mode pays, depend on the collectives' real bandwidth
+    # on this node.  Candidates in order of likely merit, 8 steps each, under a WALL-CLOCK budget: every rank learns every
+    # candidate's agreed (max over ranks) cost, so all of them stop after the same candidate.
+    if sweeping:
+        tuning = []
+        if dp.exchange == "touched":
+            order = [("touched", c_) for c_ in TOUCHED_CANDS]
+        elif args.dp_exchange == "auto":
+            order = list(TUNE_ORDER)
+        else:
+            order = [(m_, c_) for m_, c_ in TUNE_ORDER if m_ == dp.exchange]
+            order += [(dp.exchange, c_) for c_ in sorted({c_ for _, c_ in TUNE_ORDER}) if (dp.exchange, c_) not in order]
+        spent, seen_modes = 0.0, set()
+        for mode, cand in order:
+            # every mode gets its first candidate whatever the budget says (a record without one of the modes cannot say which is best)
+            if spent > args.tune_budget and mode in seen_modes:
+                continue
+            t_c = time.perf_counter()
+            dp.set_exchange(mode)
+            dp.upper_fractions = cand
+            dp.plan(fm, ds)
+            step(0)
+            sync()
+            barrier()
+            t0 = time.perf_counter()
+            steps_run(0, 8)          # (8: a pipelined run's first forward pass and last slice are not overlapped with anything)
+            sync()
+            tt = ctl.allreduce([time.perf_counter() - t0, time.perf_counter() - t_c], "max")
+            tuning.append({"exchange": mode, "upper_fractions": list(cand), "cuts": list(dp.cuts), "ms_per_step": tt[0] / 8 * 1e3})
+            spent += tt[1]
+            seen_modes.add(mode)
+        tuning_note = "%d of %d candidates timed in %.1f s (--tune-budget %.0f s; every mode at least once)" % (len(tuning), len(order), spent, args.tune_budget)
+        log("cut / mode sweep: " + tuning_note)
+        best = min(tuning, key=lambda x: x["ms_per_step"])
+        dp.set_exchange(best["exchange"])
+        dp.upper_fractions = tuple(best["upper_fractions"])
+        dp.plan(fm, ds)
+        steps_run(0, 4)
+        sync()
+        barrier()
+
+    measure()
+    headline("headline")
 
     # ---- rank 0 alone, the other ranks wait at the next barrier: the CPU baseline, then this run's own counter passes
     if rank == 0:

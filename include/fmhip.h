@@ -339,7 +339,9 @@ int fmhip_dp_epoch_order(fmhip_model_t m, fmhip_dataset_t d, fmhip_comm_t c, dou
 int fmhip_dp_plan_info(fmhip_comm_t c, int64_t *steps, int64_t *max_batch_rows);
 /* `n` steps in one call, at the named positions of the lock-step schedule (every rank the same list): what a caller that knows
  * its next steps hands the pipelined exchange, which overlaps each step's last slice with the next position's forward; in the
- * other modes the same as n calls of fmhip_dp_step_at. */
+ * other modes the same steps as n calls of fmhip_dp_step_at.  In EVERY mode a position whose batch fails a check only this rank
+ * can see (a dataset the plan has not seen) contributes zeros and the run goes on to its last position — the peers are never
+ * left alone in a later position's collectives; the first such error is returned afterwards. */
 int fmhip_dp_steps(fmhip_model_t m, fmhip_dataset_t d, const int64_t *positions, int64_t n, fmhip_comm_t c, double eta, double reg0,
                    double regw, double regv);
 /* Contiguous row shard [lo, hi) of `rank`, balanced by stored nonzeros (not by row count): the

@@ -134,9 +134,11 @@ int fmhip_dataset_als_levels(fmhip_dataset_t d, int64_t *n_levels, int64_t *n_co
 /* The same forward in TWO passes over every row's entries — pass 0: the features below a cut, pass 1: the others and the row's
  * finish — so that pass 0 can run while the rows of V at or above the cut are still being exchanged (the pipelined
  * data-parallel schedule, FMHIP_EXCHANGE_PIPELINED).  fmhip_dataset_partition_rows(d, cut) prepares the dataset: a stable
- * partition of each row's stored entries at feature id `cut` (the order of a row's entries is all that changes; not while
- * another thread uses the dataset).  Pass 0 then pass 1 = fmhip_step_forward up to the order of the fp32 sums; models of up
- * to 64 padded factors.  (FMModel.predict's sum over a row's entries, S/fm/FMModel.scala:41-46,57-63, taken in two parts.) */
+ * partition of each row's stored entries at feature id `cut`, made in a COPY of the stream that only the two-pass forward reads
+ * (the dataset's own streams never move: other threads may go on scoring and training with it; one partition per dataset — it
+ * is re-made for another cut, but not while a pipelined run of some model is walking it: that call fails and says so).  A
+ * feature of the dense hot block's forward page at or above the cut moves the block's prologue from pass 0 to pass 1.  Pass 0
+ * then pass 1 = fmhip_step_forward up to the order of the fp32 sums; models of up to 64 padded factors.  (FMModel.predict's sum over a row's entries, S/fm/FMModel.scala:41-46,57-63, taken in two parts.) */
 int fmhip_dataset_partition_rows(fmhip_dataset_t d, int64_t cut_feature);
 int fmhip_step_forward_pass(fmhip_model_t m, fmhip_dataset_t d, int64_t batch, int pass);
 

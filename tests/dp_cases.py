@@ -10,8 +10,13 @@ def shard(cfg, rank):
     rows = cfg["rows"][rank]
     if rows == 0:
         return dict(row_ptr=np.zeros(1, np.int64), col=np.zeros(0, np.int32), val=np.zeros(0, np.float32), y=np.zeros(0, np.float32))
-    return synth.make_zipf(cfg["seed"], rows, cfg["n1_data"], cfg["lo"], cfg["hi"], zipf_s=cfg.get("zipf_s", 1.05),
-                           row_begin=int(sum(cfg["rows"][:rank])))
+    d = synth.make_zipf(cfg["seed"], rows, cfg["n1_data"], cfg["lo"], cfg["hi"], zipf_s=cfg.get("zipf_s", 1.05),
+                        row_begin=int(sum(cfg["rows"][:rank])))
+    if cfg.get("reverse_ids"):
+        # ids NOT ranked by frequency: the most frequent features carry the highest ids (hashed / field-ordered ids do that to
+        # some of them) — the dense hot block's features then sit at or above a data-parallel plan's cuts
+        d = dict(d, col=(cfg["n1_data"] - 1 - d["col"]).astype(np.int32))
+    return d
 
 
 def init(cfg):

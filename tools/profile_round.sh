@@ -9,7 +9,7 @@ tag=${1:-r02}; shift || true
 cd "$(dirname "$0")/.."
 root=$PWD
 export TMPDIR=/tmp
-BENCH="python3 $root/bench.py --no-cpu-baseline --no-extra --no-pmc --steps 12 --warmup 4 $*"
+BENCH="python3 $root/bench.py --no-cpu-baseline --no-extra --no-pmc --steps 12 --warmup 4 --settle 0.1 $*"
 if [ -n "$LEG" ]; then BENCH="python3 $root/$LEG"; fi      # LEG="tools/pmc_leg.py c4 ...": another workload than the bench's own
 run() { # name, rocprof args...   (every pass bounded: a counter set the hardware refuses makes rocprofv3 abort and then hang)
   local name=$1; shift

@@ -41,6 +41,8 @@ def make_case(seed):
                fractions=[[], [0.3], [0.1, 0.4], [0.05, 0.15, 0.3, 0.55]][int(rng.integers(0, 4))], epochs=int(rng.choice([1, 2])),
                eta=0.02, regw=float(rng.choice([0.0, 1e-3])), regv=float(rng.choice([0.0, 1e-3])),
                shuffle_seed=None if rng.random() < 0.6 else int(rng.integers(0, 1000)))
+    if rng.random() < 0.35:
+        cfg["reverse_ids"] = True          # the frequent features carry the HIGHEST ids (round 5: the hot block above the plan's cuts)
     return cfg
 
 
@@ -56,7 +58,7 @@ def main():
         json.dump(cfg, open(path, "w"))
         world = len(cfg["rows"])
         tag = "case %d %s" % (seed, {k_: cfg[k_] for k_ in ("rows", "n1_data", "n1", "k", "lo", "hi", "batch_rows", "exchange", "fractions", "epochs", "regw", "regv",
-                                                            "shuffle_seed")})
+                                                            "shuffle_seed")}) + (" reverse_ids" if cfg.get("reverse_ids") else "")
         if world > 3:
             r = subprocess.run([sys.executable, worker, "threads", path], stdout=subprocess.PIPE, timeout=900)
             assert r.returncode == 0, tag
