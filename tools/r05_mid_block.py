@@ -3,6 +3,7 @@
 read at dataset creation).  Run ON THE GPU BOX, once per setting, C3's shape (1M rows x 100k features, k = 32, 250k-row batches):
     python3 tools/r05_mid_block.py <gradient.npy> [merged]      # env FMHIP_MID_BLOCK unset: writes the reference gradient of batch 1
     FMHIP_MID_BLOCK=1000:10000 python3 tools/r05_mid_block.py <gradient.npy> [merged]   # compares with it, then times the step's kernels
+Needs the experiment patch (git apply profiles/r05_mid_block.patch; not part of the library).
 `merged`: leave the merged finish on (wrong with pieces: timing only)."""
 import ctypes as C
 import os
