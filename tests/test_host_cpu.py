@@ -293,7 +293,7 @@ def test_committed_bench_line_keeps_the_contract():
     driver's contract plus the roofline / cpu_baseline objects; the roofline is an HBM-side fraction — counter bytes per
     launch / launch time / 8 TB/s, measured in that run, <= 1 — with the algorithmic figure flagged beside it."""
     import json
-    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_c3_n1.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_c3_n1.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -316,6 +316,15 @@ def test_committed_bench_line_keeps_the_contract():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "nnz/s" and c["sample"]
     x = d["extra"]
     assert d["sustained"]["seconds"] >= 2.0 and x["hbm_resident"]["frac_of_8TBps"] <= 1.0 and x["hbm_resident"]["distinct_batches"] >= 24
+    # round 5: the record says what bounds the step, carries the HBM-resident leg's fraction at the top level, and is the run's
+    # LAST line (every leg ran: nothing skipped); the driver's short run (--steps 20 --warmup 5) reproduces it within 1 %
+    assert d["record"]["final"] is True and not d["legs"]["skipped"] and d["legs"]["elapsed_s"] < d["legs"]["time_budget_s"]
+    assert r["algorithmic_frac"] > 1.0 and r["algorithmic_label"].startswith("model not a bound")
+    assert 2.0e8 < r["compulsory_hbm_bytes_per_step"] < 3.5e8 and r["hbm_floor_ms"] == pytest.approx(r["compulsory_hbm_bytes_per_step"] / 8e12 * 1e3)
+    assert 0 < r["hbm_floor_share_of_step"] < 0.25 and 0 < r["step_ceiling_frac"] <= 1.0
+    assert r["hbm_resident"]["frac"] == pytest.approx(x["hbm_resident"]["frac_of_8TBps"]) and 0.4 < r["hbm_resident"]["frac"] <= 1.0
+    short = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_c3_driver_flags.json")))
+    assert short["steps"] == 20 and short["warmup"] == 5 and short["value"] == pytest.approx(d["value"], rel=0.01)
     assert x["hbm_resident"]["ids_as_hashed"]["value"] > 0 and x["c4_one_gpu"]["value"] > 0 and len(x["als_long_columns"]) == 3
     assert d["config"]["backward_band_plan"]["band_affine"] > 0
     # round 4: the hit rates the ceilings are blended with come from a counter pass of the run itself; every kernel of the
