@@ -1066,3 +1066,34 @@ def test_bench_killed_inside_an_optional_leg_has_left_its_record():
     assert "hbm_resident" not in out["extra"]
     lines = [json.loads(ln) for ln in data.decode().splitlines() if ln.strip().startswith("{") and ln.strip().endswith("}")]
     assert [ln["record"]["stage"] for ln in lines][:2] == ["headline", "cpu_baseline"] and all(ln["value"] == out["value"] for ln in lines)
+
+
+def test_bench_under_the_drivers_launcher():
+    """The driver starts an N > 1 bench as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` (one rank per GPU, env:// rendezvous from RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_*).  That launch path — not the bench's own spawn_ranks — with two ranks on the one GPU of the test box
+    (`--transport host`: RCCL refuses two ranks on a device): the launcher's environment (OMP_NUM_THREADS=1 and all) reaches the
+    ranks, the gloo control plane forms over env://, rank 0's JSON lines are the launcher's stdout and nothing else is, the
+    first headline comes BEFORE the cut / mode sweep, the final line is complete."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "host", "--steps", "4", "--warmup", "2",
+           "--rows", "200000", "--batch-rows", "100000", "--no-pmc", "--cpu-budget", "2", "--tune-budget", "6"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "FMHIP_BENCH_RDZV")}
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-4000:]
+    out_lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert all(ln.startswith("{") and ln.endswith("}") for ln in out_lines), [ln[:80] for ln in out_lines if not ln.startswith("{")]
+    lines = [json.loads(ln) for ln in out_lines]
+    stages = [ln["record"]["stage"] for ln in lines]
+    assert stages[0].startswith("headline (default plan") and "headline" in stages[1:] and lines[-1]["record"]["final"] is True, stages
+    out = lines[-1]
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 2 and out["value"] > 0 and out["scaling"] == "strong"
+    x = out["exchange"]
+    assert x["nranks"] == 2 and "passed" in x["selftest"] and x["replicas"]["identical"] is True
+    assert {t["exchange"] for t in x["cut_tuning"]} == {"dense", "sharded", "pipelined"}
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["cores"] >= 2          # the launcher's OMP_NUM_THREADS=1 did not pin the baseline to one thread
+    assert out["sustained"]["steps"] > 0 and not out["legs"]["skipped"]
