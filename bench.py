@@ -32,15 +32,17 @@ kernels run on).  `cpu_baseline` times the fp64 CPU oracle (a port — SparkFM i
 sample of the same workload; `extra.hbm_resident` is a Criteo-width model (V = 8.6 GB, k=64: the only configuration whose
 tables do not live in L2 / Infinity Cache) with weight decay; its counter fraction is copied into `roofline.hbm_resident`.
 
-Parts: benchkit/roofline.py (byte accounting, ceilings, the roofline block), benchkit/counters.py (rocprofv3 --pmc child
-passes), benchkit/legs.py (CPU baseline and the optional legs), benchkit/ranks.py (multi-rank launch and control plane),
-benchkit/emit.py (the line and its budget).
+Parts: this file = the argument parser and one rank's flow (setup, settle, measure, legs); benchkit/roofline.py (byte accounting,
+ceilings, the roofline block), benchkit/counters.py (rocprofv3 --pmc child passes), benchkit/record.py (the line's `config` and
+`exchange` blocks), benchkit/legs.py (CPU baseline and the N = 1 legs), benchkit/dp_legs.py (the N > 1 cut / mode sweep, one-GPU
+denominators, C3 twin), benchkit/ranks.py (multi-rank launch and control plane), benchkit/emit.py (the line and its budget).
 """
 import argparse
 import ctypes as C
 import os
 import sys
 import time
+import types
 
 T_PROCESS_START = time.monotonic()
 
@@ -49,6 +51,7 @@ import numpy as np  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from benchkit import dp_legs, record  # noqa: E402
 from benchkit.counters import PMC_STATE, STEP_KERNELS, committed_pmc, live_pmc, pmc_pass  # noqa: E402,F401  (re-exported: tools/, tests/)
 from benchkit.emit import Budget, Emitter, last_record  # noqa: E402,F401
 from benchkit.legs import (DP_GLOBAL_BATCH_ROWS, als_c1, als_fields, als_long, c4_one_gpu_leg, cpu_baseline, hbm_resident_leg,  # noqa: E402,F401
@@ -56,18 +59,6 @@ from benchkit.legs import (DP_GLOBAL_BATCH_ROWS, als_c1, als_fields, als_long, c
 from benchkit.ranks import NoCtl, ThreadCtl, TorchCtl, init_process_group, spawn_ranks  # noqa: E402,F401
 from benchkit.roofline import (CEIL, HBM_PEAK, L2_BYTES_PER_XCD, MALL_BYTES, alg_bytes, annotate_roofline, compulsory_hbm_bytes,  # noqa: E402,F401
                                gather_ceiling, kernel_table, requested_bytes, roofline_block)
-
-# the pipelined schedule likes a small top slice (it should take about as long on the wire as the next position's pass A), a
-# cheap second interval that starts the wire, and few launches; the dense / sharded schedules like a deeper pipeline.
-# Ordered by what won on emulated 8 x 200-450 GB/s collectives (profiles/r04_emulated_dp_c4_*_modes3.json): under a time
-# budget the sweep covers the likely winners first.
-TUNE_ORDER = [("pipelined", (0.04, 0.1, 0.3)), ("dense", (0.05, 0.15, 0.3, 0.55)), ("sharded", (0.05, 0.15, 0.3, 0.55)),
-              ("pipelined", (0.05, 0.12, 0.35)), ("dense", (0.12, 0.4)), ("pipelined", (0.04, 0.1)), ("sharded", (0.12, 0.4)),
-              ("dense", (0.08, 0.25, 0.5)), ("pipelined", (0.04, 0.09, 0.2, 0.5)), ("dense", ()), ("pipelined", (0.05, 0.15, 0.3, 0.55)),
-              ("dense", (0.3,)), ("sharded", (0.08, 0.25, 0.5)), ("pipelined", (0.08, 0.25, 0.5)), ("dense", (0.04, 0.1, 0.2, 0.35, 0.6)),
-              ("sharded", ()), ("pipelined", (0.12, 0.4)), ("dense", (0.2,)), ("pipelined", (0.03, 0.07, 0.13, 0.22, 0.35, 0.6)),
-              ("sharded", (0.3,)), ("pipelined", (0.04, 0.1, 0.2, 0.35, 0.6)), ("sharded", (0.2,)), ("sharded", (0.04, 0.1, 0.2, 0.35, 0.6))]
-TOUCHED_CANDS = ((), (0.3,), (0.12, 0.4), (0.05, 0.15, 0.3, 0.55))
 
 
 def parse_args(argv=None):
@@ -454,6 +445,11 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
     out, state = {}, {"pmc": {}, "live": None, "hbm_resident": None}
     lay = ds.layout() if rank == 0 else None
     nnz_all = int(d["row_ptr"][-1])
+    # the run's context for benchkit.record / benchkit.dp_legs (everything below this line only reads these)
+    x = types.SimpleNamespace(args=args, rank=rank, world=world, local_rank=local_rank, ctl=ctl, L=L, ffi=_ffi, fm=fm, ds=ds, hm=hm, hd=hd, nb=nb, bnnz=bnnz,
+                              dp=dp, comm=comm, regs=regs, exchange=exchange, config=config, cfg=cfg, rows=rows, k=k, kp=kp, n1=n1, batch_rows=batch_rows,
+                              dp_world=dp_world, relabelled=relabelled, lay=lay, nnz_all=nnz_all, settled=settled, step=step, steps_run=steps_run, sync=sync,
+                              barrier=barrier, log=log, comm_note=comm_note, selftest_note=selftest_note)
 
     def build_roofline():
         """(Re)builds `roofline`, `step_roofline` and `kernels` from the kernel pass and whatever counter figures exist by now."""
@@ -491,59 +487,10 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
             roof["hbm_resident"] = state["hbm_resident"]
         out["roofline"] = roof
 
-    def exchange_block(sustained=None, twin=None, no_exchange=None, one_gpu_plain=None):
-        gf = C.c_int64()
-        _ffi.check(L.fmhip_grad_floats(hm, C.byref(gf)))
-        payload = int(gf.value) * 4
-        xc = {"nranks": world, "allreduce_bytes_per_step": payload, "backend": exchange, "transport": args.transport,
-              "mode": dp.exchange if exchange == "rccl" else "dense"}
-        if exchange == "rccl" and dp.exchange == "pipelined":
-            xc["mode_note"] = ("pipelined (FMHIP_EXCHANGE_PIPELINED): the dense exchange with consecutive steps overlapped — the coldest feature "
-                               "interval is walked and sent last, and while its slice travels the next position's forward runs over every feature "
-                               "below the top cut (a two-pass forward over rows partitioned at that cut; fmhip_dp_steps hands the library the whole "
-                               "run of positions); same sums and update as the dense mode, the forward's fp32 sums in another order")
-        if exchange == "rccl" and dp.exchange == "touched":
-            info = dp.exchange_info()
-            xc["mode_note"] = ("touched rows (fmhip_dp_exchange): the union of the rows every position's batches touch is planned ONCE "
-                               "(fmhip_dp_plan: all-gather of ids, sort, unique); a step writes its gradient into a compact buffer with one "
-                               "row per union feature, all-reduces it in feature-interval slices under the backward, and applies the "
-                               "rows-only update with lazy weight decay — no id exchange, sort or read-back in the step")
-            xc["dense_gradient_bytes"] = payload
-            xc["id_slots_per_rank"] = info["id_slots_per_rank"]
-            xc["mean_union_rows"] = info["mean_union_rows"]
-            xc["allreduce_bytes_per_step"] = int((32 + info["mean_union_rows"] * (kp + 2)) * 4)
-            xc["allgather_bytes_per_step"] = int(info["id_slots_per_rank"] * world * 4)
-        if cprof and cprof["steps"]:
-            xc["exposed_comm_ms"] = cprof["exposed_ms"] / cprof["steps"]
-            xc["comm_busy_ms"] = cprof["comm_ms"] / cprof["steps"]
-            # ring all-reduce moves 2(N-1)/N of the payload per rank
-            busy = max(cprof["comm_ms"] / cprof["steps"], 1e-9)
-            xc["alg_GBps"] = payload / busy / 1e6
-            xc["bus_GBps"] = payload * (2.0 * (world - 1) / max(world, 1)) / busy / 1e6
-        if twin:
-            xc["c3_on_every_gpu"] = twin
-        if no_exchange:
-            xc["per_gpu_without_exchange"] = no_exchange
-            xc["efficiency_vs_no_exchange"] = value / (world * no_exchange["value"])
-        if one_gpu_plain:
-            # the like-for-like scaling of THIS line: the job's throughput over what one GPU does alone on the same workload
-            # (C4's shard and batch, the plain step) — the driver's N = 1 line is C3, another width
-            xc["%s_one_gpu" % config.lower()] = one_gpu_plain
-            xc["scaling_vs_%s_one_gpu" % config.lower()] = value / one_gpu_plain["value"]
-        if comm_note:
-            xc["note"] = comm_note
-        if selftest_note:
-            xc["selftest"] = selftest_note
-        if replicas:
-            xc["replicas"] = replicas
-        if tuning:
-            xc["cut_tuning"] = tuning
-            xc["cut_tuning_note"] = tuning_note
-        if args.emulate_allreduce:
-            xc["emulated"] = "ring all-reduce over %s GPUs at bus bandwidth %s GB/s, as a delay on the comm stream (one real rank)" % tuple(args.emulate_allreduce.split(":"))
-            if args.emulate_load:
-                xc["emulated"] += "; the delay is spent by %d workgroups streaming the payload through HBM (read + write, twice per all-reduce)" % args.emulate_load
-        out["exchange"] = xc
+    legs_dp = {"twin": None, "no_exchange": None, "one_gpu_plain": None}
+
+    def exchange_block():
+        out["exchange"] = record.exchange_block(x, value, cprof, replicas, tuning, tuning_note, **legs_dp)
 
     def headline(stage):
         """Rank 0 (re)builds the record from the latest measure() and writes it."""
@@ -555,32 +502,7 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_ms, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d rows x %d features per GPU, k=%d, %s, fp32 mini-batch SGD" %
-                                   (config, rows, n1, k, ("39 hashed Criteo-shaped fields" + (", ids relabelled by frequency at load" if relabelled else ""))
-                                    if cfg.get("criteo") else
-                                    "nnz/row U{%d..%d}, ids Zipf(%.2f)" % (cfg["nnz_lo"], cfg["nnz_hi"], cfg["zipf_s"])),
-                       "rows_per_gpu": rows, "features": n1, "k": k, "batch_rows_per_gpu": batch_rows,
-                       "global_batch": batch_rows * dp_world,
-                       "batches_per_gpu": nb, "nnz_per_gpu": nnz_all, "eta": args.eta, "regs": regs,
-                       "settle_steps_before_warmup": settled,
-                       "dense_hot_block": {"pages": lay["hot_pages"], "features_forward_and_backward": len(lay["hot_ids"]),
-                                           "features_backward": len(lay["hot_ids_all"]),
-                                           "share_of_nonzeros_left_to_the_forward": lay["nnz_sparse"] / max(nnz_all, 1),
-                                           "share_of_nonzeros_left_to_the_backward": lay["nnz_sparse_backward"] / max(nnz_all, 1)},
-                       "backward_band_plan": {"ranges": lay["ranges"], "planned": lay["planned_ranges"], "band_affine": lay["band_affine_ranges"],
-                                              "share_band_affine": lay["band_affine_ranges"] / max(lay["ranges"], 1),
-                                              "note": "ranges of long columns walked on the XCD that owns their row band (FMHIP_TUNE_XCD_PLACEMENT)"},
-                       "parallelism": "dp%d" % world, "exchange": exchange,
-                       "transport": ("host-staged gloo over fmhip_comm_create_external, all ranks on GPU 0 (a rehearsal of the N-rank flow, "
-                                     "not a measurement)" if args.transport == "host" and use_dp else
-                                     ("host-staged between the ranks-as-threads of ONE process over fmhip_comm_create_external, all on GPU 0 (a "
-                                      "rehearsal of the N-rank flow, not a measurement)" if args.transport == "threads" else ("RCCL" if use_dp else "none"))),
-                       "allreduce": ("inside the library, touched rows only" if exchange == "rccl" and dp.exchange == "touched" else
-                                     ("inside the library, %s, overlapped with the feature-chunked backward, cuts at features %s" %
-                                      ("reduce-scatter -> sharded update -> all-gather" if dp.exchange == "sharded" else "all-reduce, every rank updates every row", dp.cuts))
-                                     if exchange == "rccl" and dp.cuts else
-                                     ("inside the library, one %s per step" % ("reduce-scatter + all-gather" if dp.exchange == "sharded" else "all-reduce") if exchange == "rccl" else
-                                      ("torch.distributed, orchestrated from Python" if exchange == "torch" else "none")))},
+            "config": record.config_block(x),
             "roofline": None,
             "cpu_baseline": None,
             "train": {"last_batch_mse": st.sse / max(st.rows, 1), "nonfinite": st.nonfinite},
@@ -598,46 +520,8 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
     if sweeping and world > 1:
         measure()
         headline("headline (default plan, before the cut / mode sweep)")
-    # ---- N > 1: measure, don't guess — the best cut, and which exchange mode pays, depend on the collectives' real bandwidth
-    # on this node.  Candidates in order of likely merit, 8 steps each, under a WALL-CLOCK budget: every rank learns every
-    # candidate's agreed (max over ranks) cost, so all of them stop after the same candidate.
     if sweeping:
-        tuning = []
-        if dp.exchange == "touched":
-            order = [("touched", c_) for c_ in TOUCHED_CANDS]
-        elif args.dp_exchange == "auto":
-            order = list(TUNE_ORDER)
-        else:
-            order = [(m_, c_) for m_, c_ in TUNE_ORDER if m_ == dp.exchange]
-            order += [(dp.exchange, c_) for c_ in sorted({c_ for _, c_ in TUNE_ORDER}) if (dp.exchange, c_) not in order]
-        spent, seen_modes = 0.0, set()
-        for mode, cand in order:
-            # every mode gets its first candidate whatever the budget says (a record without one of the modes cannot say which is best)
-            if spent > args.tune_budget and mode in seen_modes:
-                continue
-            t_c = time.perf_counter()
-            dp.set_exchange(mode)
-            dp.upper_fractions = cand
-            dp.plan(fm, ds)
-            step(0)
-            sync()
-            barrier()
-            t0 = time.perf_counter()
-            steps_run(0, 8)          # (8: a pipelined run's first forward pass and last slice are not overlapped with anything)
-            sync()
-            tt = ctl.allreduce([time.perf_counter() - t0, time.perf_counter() - t_c], "max")
-            tuning.append({"exchange": mode, "upper_fractions": list(cand), "cuts": list(dp.cuts), "ms_per_step": tt[0] / 8 * 1e3})
-            spent += tt[1]
-            seen_modes.add(mode)
-        tuning_note = "%d of %d candidates timed in %.1f s (--tune-budget %.0f s; every mode at least once)" % (len(tuning), len(order), spent, args.tune_budget)
-        log("cut / mode sweep: " + tuning_note)
-        best = min(tuning, key=lambda x: x["ms_per_step"])
-        dp.set_exchange(best["exchange"])
-        dp.upper_fractions = tuple(best["upper_fractions"])
-        dp.plan(fm, ds)
-        steps_run(0, 4)
-        sync()
-        barrier()
+        tuning, tuning_note = dp_legs.tune_sweep(x)
 
     measure()
     headline("headline")
@@ -702,100 +586,21 @@ def run_rank(args, rank, world, local_rank, ctl, json_fd, torch, group=None):
             out["sustained"] = sustained
             emitter.emit(out, "sustained")
 
-    # ---- the same shard and batch WITHOUT the exchange (what one GPU of the job does alone)
-    no_exchange = one_gpu_plain = None
+    # ---- the same shard and batch WITHOUT the exchange (what one GPU of the job does alone): rank 0, the others wait
     if use_dp and rank == 0 and not args.no_extra and budget.allows("one_gpu_legs", 10.0):
-        n_leg = int(min(max(args.steps, 8), 64))
-        sync()
-        for j in range(4):
-            _ffi.check(L.fmhip_step_compute(hm, hd, j % nb))
-            _ffi.check(L.fmhip_step_apply(hm, args.eta, *regs))
-        sync()
-        t0 = time.perf_counter()
-        for j in range(n_leg):
-            _ffi.check(L.fmhip_step_compute(hm, hd, j % nb))
-            _ffi.check(L.fmhip_step_apply(hm, args.eta, *regs))
-        sync()
-        dt = time.perf_counter() - t0
-        no_exchange = {"value": sum(bnnz[j % nb] for j in range(n_leg)) / dt, "unit": "nnz/s", "ms_per_step": dt / n_leg * 1e3,
-                       "note": "rank 0 alone, same shard and batch, dense update, no all-reduce"}
-        # ... and the plain one-GPU step (fmhip_sgd_step: the update merged into the fixup launch or rows-only, as N = 1 runs
-        # it) on the same shard and batch: the denominator for this line's scaling, measured in the same process
-        for j in range(4):
-            _ffi.check(L.fmhip_sgd_step(hm, hd, j % nb, args.eta, *regs, None))
-        sync()
-        t0 = time.perf_counter()
-        for j in range(n_leg):
-            _ffi.check(L.fmhip_sgd_step(hm, hd, j % nb, args.eta, *regs, None))
-        sync()
-        dt = time.perf_counter() - t0
-        one_gpu_plain = {"value": sum(bnnz[j % nb] for j in range(n_leg)) / dt, "unit": "nnz/s", "ms_per_step": dt / n_leg * 1e3,
-                         "note": "rank 0 alone, same shard and batch, the plain one-GPU step (fmhip_sgd_step), while the other ranks wait"}
-        exchange_block(None, None, no_exchange, one_gpu_plain)
+        legs_dp["no_exchange"], legs_dp["one_gpu_plain"] = dp_legs.one_gpu_legs(x)
+        exchange_block()
         emitter.emit(out, "one_gpu_legs")
     barrier()
 
-    # ---- the N = 1 line's own workload under the exchange: C3 on every GPU (weak scaling in the strict sense — the driver's
-    # per-N values compare C3 at N = 1 with C4 at N > 1, two different widths; this leg is the like-for-like number)
-    twin = None
+    # ---- the N = 1 line's own workload under the exchange: C3 on every GPU (collective: every rank takes part)
     if exchange == "rccl" and dp.exchange != "touched" and config != "C3" and not args.no_extra and agreed(rank != 0 or budget.allows("c3_twin", 25.0)):
         test_stall("c3_twin")
         t_leg = time.monotonic()
-        c3 = synth.CONFIGS["C3"]
-        rows3 = 1_000_000 if not args.rows else min(1_000_000, max(args.rows, 1000))     # a rehearsal with --rows keeps the twin small too
-        d3 = synth.make_config("C3", rows=rows3, row_begin=rank * rows3)
-        ds3 = DataSet.from_arrays(d3, name="C3", batch_rows=min(250_000, rows3), device=local_rank).cache()
-        fm3 = FMModel(c3["features"] - 1, c3["k"], seed=c3["seed"] + 1000, device=local_rank, init_on_device=True)
-        nb3 = ds3.n_batches
-        nnz3 = [ds3.batch_info(b)["nnz"] for b in range(nb3)]
-        n_leg = int(min(max(args.steps, 8), 64))
-
-        def step3(j):
-            _ffi.check(L.fmhip_dp_step_at(fm3.handle, ds3.handle, j % nb3, comm.handle, args.eta, regs[0], regs[1], regs[2]))
-        keep, keep_mode = dp.upper_fractions, dp.exchange
-        best3 = None
-        for mode3 in (("dense", "sharded") if args.dp_exchange == "auto" else (dp.exchange,)):
-            dp.set_exchange(mode3)
-            for cand in ((), (0.3,), (0.12, 0.4), (0.05, 0.15, 0.3, 0.55)):        # a 13.6 MB gradient wants fewer cuts than C4's 136 MB
-                dp.upper_fractions = cand
-                dp.plan(fm3, ds3)
-                for j in range(3):
-                    step3(j)
-                _ffi.check(L.fmhip_synchronize(fm3.handle))
-                barrier()
-                t0 = time.perf_counter()
-                for j in range(8):
-                    step3(j)
-                _ffi.check(L.fmhip_synchronize(fm3.handle))
-                tt = ctl.allreduce([time.perf_counter() - t0], "max")
-                if best3 is None or tt[0] < best3[0]:
-                    best3 = (tt[0], cand, mode3)
-        dp.set_exchange(best3[2])
-        dp.upper_fractions = best3[1]
-        dp.plan(fm3, ds3)
-        for j in range(4):
-            step3(j)
-        _ffi.check(L.fmhip_synchronize(fm3.handle))
-        barrier()
-        t0 = time.perf_counter()
-        for j in range(n_leg):
-            step3(j)
-        _ffi.check(L.fmhip_synchronize(fm3.handle))
-        barrier()
-        tm = ctl.allreduce([time.perf_counter() - t0], "max")
-        t3 = ctl.allreduce([float(sum(nnz3[j % nb3] for j in range(n_leg)))], "sum")
-        twin = {"workload": "C3 on every GPU: %d rows x 100000 features per GPU, k=32, batch %d rows per GPU — the N = 1 line's workload" % (rows3, min(250_000, rows3)),
-                "value": t3[0] / tm[0], "unit": "nnz/s", "ms_per_step": tm[0] / n_leg * 1e3,
-                "allreduce_bytes_per_step": 4 * (32 + (c3["features"] + 31) // 32 * 32 * 34), "cuts": list(dp.cuts), "exchange": dp.exchange}
-        ds3.unpersist()
-        fm3.close(discard=True)
-        dp.set_exchange(keep_mode)
-        dp.upper_fractions = keep
-        dp.plan(fm, ds)
-        barrier()
+        legs_dp["twin"] = dp_legs.c3_twin_leg(x)
         if rank == 0:
             budget.spent["c3_twin"] = time.monotonic() - t_leg
-            exchange_block(None, twin, no_exchange, one_gpu_plain)
+            exchange_block()
             emitter.emit(out, "c3_twin")
 
     # ---- N = 1: the legs beside the headline (scoring, the HBM-resident model, C4 on one GPU, ALS), each under the budget
