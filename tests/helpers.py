@@ -71,3 +71,17 @@ def build_jni_harness(tmp_path, sanitize=False):
                            os.path.join(root, "tests", "jni_harness.c"), os.path.join(root, "jvm", "fmhip_jni.c"),
                            "-L" + _build.LIBDIR, "-lfmhip", "-Wl,-rpath," + _build.LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     return exe
+
+
+def build_cpp_mirror(tmp_path):
+    """tests/cpp_mirror.cpp — a consumer of include/sparkfm.hpp (header-only C++ mirror of the reference's host classes over the
+    product C ABI) — compiled as strict C++17 with warnings as errors and linked against libfmhip.so; -> the executable."""
+    import os
+    import subprocess
+    from sparkfm_amd import _build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cpp_mirror")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp_mirror.cpp"), "-L" + _build.LIBDIR, "-lfmhip",
+                           "-Wl,-rpath," + _build.LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    return exe

@@ -1097,3 +1097,66 @@ def test_bench_under_the_drivers_launcher():
     assert {t["exchange"] for t in x["cut_tuning"]} == {"dense", "sharded", "pipelined"}
     assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["cores"] >= 2          # the launcher's OMP_NUM_THREADS=1 did not pin the baseline to one thread
     assert out["sustained"]["steps"] > 0 and not out["legs"]["skipped"]
+
+
+def test_cpp_mirror_runs_the_reference_flow_bit_for_bit_with_the_python_mirror(tmp_path):
+    """include/sparkfm.hpp on the GPU: tests/cpp_mirror.cpp runs the reference's own flow — FM(dataset, k, maxIteration)
+    .learnWith(learner), computeRMSE / predict on a second dataset (S/fm/impl/FactorizationMachines.scala:30-51,
+    S/driver.scala:100-112) — with HipSGD over mini-batches and with HipALS (the reference's learner) on a problem made of exact
+    rationals; the same flow through the Python mirror makes the same C-ABI calls, so every number must be the SAME BITS: the
+    RMSE of every iteration, w0 / w / v after the fit, held-out RMSE, every prediction; and the oracle is matched."""
+    import numpy as np
+    from helpers import build_cpp_mirror
+    from sparkfm_amd import FM, DataSet, HipALS, HipSGD
+    path = str(tmp_path / "cpp.bin")
+    r = subprocess.run([build_cpp_mirror(tmp_path), "gpu", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0 and b"flow ok" in r.stdout, r.stderr.decode()[-2000:]
+    got = np.fromfile(path, dtype=np.float64)
+    n_rows, n1, k = 3000, 97, 8
+    rp, col, val, y = [0], [], [], []
+    for rr in range(n_rows):
+        for j in range(3 + rr % 5):
+            col.append((rr * 7 + j * 31) % n1)
+            val.append(0.25 + ((rr + 3 * j) % 8) / 8.0)
+        rp.append(len(col))
+        y.append(((rr * 37) % 11) / 5.0 - 1.0)
+    rp, col, val, y = np.array(rp, np.int64), np.array(col, np.int32), np.array(val), np.array(y)
+    dim = int(col.max())
+    i = np.arange(dim + 1)
+    w0 = 0.125
+    w = ((i * 29) % 17 - 8) / 160.0
+    v = np.asfortranarray(((np.arange(k)[:, None] * 7 + i[None, :] * 13) % 23 - 11) / 220.0)
+    want = []
+    # HipSGD
+    ds = DataSet(rp, col, val, y, batch_rows=700)
+    fit = FM(ds, k, maxIteration=3)
+    fm = fit.learnWith(HipSGD.run(eta=0.05, regw=1e-3, regv=1e-3), init=(w0, w, v))
+    test = DataSet(rp, col, val, y, batch_rows=0).cache()
+    sgd_v = fm.v.copy()
+    want += list(fit.rmse_history) + [fm.w0] + list(fm.w) + list(fm.v.ravel(order="F")) + [fm.computeRMSE(test)] + list(fm.predict(test))
+    a, b = int(rp[5]), int(rp[6])
+    want += [fm.predict((col[a:b], val[a:b])), float(n_rows)]              # (HipSGD.last_stats: the epoch's totals)
+    test.unpersist()
+    fm.close()
+    # HipALS
+    ds1 = DataSet(rp, col, val, y, batch_rows=0)
+    fit1 = FM(ds1, k, maxIteration=2)
+    fm1 = fit1.learnWith(HipALS.run(), init=(w0, w, v))
+    ds1.cache()
+    want += list(fit1.rmse_history) + [fm1.w0] + list(fm1.w) + list(fm1.v.ravel(order="F")) + [fm1.computeRMSE(ds1)]
+    als = (fm1.w0, fm1.w.copy(), fm1.v.copy())
+    ds1.unpersist()
+    fm1.close()
+    want = np.array(want, np.float64)
+    assert got.shape == want.shape
+    bad = np.flatnonzero(got != want)
+    assert bad.size == 0, (bad[:10].tolist(), got[bad[:5]].tolist(), want[bad[:5]].tolist(), "sections: sgd rmse 0-2, w0 3, w 4-%d, v -%d, ..." % (3 + dim + 1, 3 + (dim + 1) * (k + 1)))
+    # ... and both are the oracle's: 3 SGD epochs / 2 ALS epochs from the injected parameters
+    o0, ow, ov = w0, w.copy(), v.copy()
+    for _ in range(3):
+        o0, ow, ov, _ = oracle.sgd_epoch(o0, ow, ov, 700, rp, col, val, y, 0.05, 0.0, 1e-3, 1e-3)
+    assert np.linalg.norm(sgd_v - ov) <= 1e-5 * np.linalg.norm(ov)
+    a0, aw, av = w0, w.copy(), v.copy()
+    for _ in range(2):
+        a0, aw, av = oracle.als_epoch(a0, aw, av, 0.0, 0.0, 10.0, rp, col, val, y)
+    assert abs(als[0] - a0) <= 1e-8 and np.abs(als[1] - aw).max() <= 1e-8 and np.abs(als[2] - av).max() <= 1e-8

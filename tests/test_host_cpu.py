@@ -580,3 +580,16 @@ def test_host_arithmetic_under_the_sanitizers(tmp_path):
     # the library itself links this translation unit (not a copy): the build lists it and the host entry points answer the same
     from sparkfm_amd import _build
     assert "fmhip_host.cpp" in _build.HIP_SOURCES
+
+
+def test_cpp_mirror_of_the_reference_classes_compiles_and_reports_errors(tmp_path):
+    """include/sparkfm.hpp: SparkFM's host classes (DataSet, FMModel, FMLearn, HipSGD / HipALS, FM + the fit loop) for a COMPILED
+    host, header-only over the product C ABI (the reference is compiled JVM code; no JVM exists here).  CPU part: strict C++17,
+    warnings as errors, only include/fmhip.h behind it; the model's shapes and defaults are the reference's
+    (S/fm/FMModel.scala:17-22,29-31), and a library error arrives as sparkfm::Error carrying fmhip_last_error()."""
+    import subprocess
+    from helpers import build_cpp_mirror
+    hpp = open(os.path.join(ROOT, "include", "sparkfm.hpp")).read()
+    assert '#include "fmhip.h"' in hpp and "fmhip_experimental" not in hpp
+    out = subprocess.check_output([build_cpp_mirror(tmp_path), "host"]).decode()
+    assert "cpp_mirror host: checks ok" in out
