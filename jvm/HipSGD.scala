@@ -90,11 +90,12 @@ class HipSGD protected (eta: Double, reg0: Double, regw: Double, regv: Double, b
       else {
         val n1 = fm.num_attribute + 1
         val counts = parts.mapPartitions { rows =>
-          // A native call per CHUNK of at most 2^26 ids (not per row: every call copies the n1-long counts array in and
+          // A native call per CHUNK of at most 2^24 ids (not per row: every call copies the n1-long counts array in and
           // out; not per partition: a partition may hold more than 2^31 - 1 ids, and flattening it whole doubles its
-          // memory).  featureCounts accumulates into `c`, so the chunks just follow each other.
+          // memory; 64 MB of staging whatever the partition's size).  featureCounts accumulates into `c`, so the chunks
+          // just follow each other.
           val c = new Array[Long](n1)
-          val chunk = new Array[Int](1 << 26)
+          val chunk = new Array[Int](1 << 24)
           var o = 0
           def flush(): Unit = if (o > 0) { HipSGD.featureCounts(java.util.Arrays.copyOf(chunk, o), n1, c); o = 0 }
           rows.foreach { case (_, sv) =>
