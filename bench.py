@@ -155,6 +155,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    node_env(world)
 
     import torch
     import torch.distributed as dist
@@ -177,6 +178,19 @@ def main():
     run_rank(args, rank, world, local_rank, ctl, json_fd, torch)
     if use_dp:
         dist.destroy_process_group()
+
+
+def node_env(world):
+    """Environment a multi-process GPU run of ONE node needs, set before anything initialises the GPU (a launcher may not have):
+    dmabuf IPC (the pool's host driver supports nothing else: without it RCCL fails in hipIpcGetMemHandle), and — when this host's
+    name does not resolve, which gloo's default device needs — the loopback interface for the control plane."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 1 and os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost") and "GLOO_SOCKET_IFNAME" not in os.environ:
+        import socket
+        try:
+            socket.gethostbyname(socket.gethostname())
+        except OSError:
+            os.environ["GLOO_SOCKET_IFNAME"] = "lo"
 
 
 def tune_key(name):
