@@ -410,8 +410,13 @@ int reduce_regions(fmhip_model_t m, fmhip_comm_t c, const Region *reg, int n_reg
     }
     if (group) NCCL_TRY(rccl().GroupEnd());
     if (c->emu_wgs > 0) {
-        for (int i = 0; i < n_reg; ++i)
-            if (reg[i].n) TRY(emu_delay(c, (double)reg[i].n * sizeof(float), c->cs, reg[i].p, reg[i].n));
+        // a grouped call is ONE kernel on the wire's stream: the whole call's duration, its footprint on the largest region (the
+        // G_V rows: 32 of every 34 floats).  (One stand-in per region — three launches, two of them a few microseconds long —
+        // put ~16 us of launch latency into every slice that a grouped RCCL call does not have: r05_experiments.md section 7c)
+        int big = 0;
+        for (int i = 1; i < n_reg; ++i)
+            if (reg[i].n > reg[big].n) big = i;
+        TRY(emu_delay(c, (double)bytes, c->cs, reg[big].p, reg[big].n));
     } else {
         TRY(emu_delay(c, (double)bytes, c->cs));
     }
