@@ -174,7 +174,8 @@ int fmhip_comm_emulate(fmhip_comm_t c, double payload_gb_per_s);
 /* ... with the collective's FOOTPRINT on this GPU instead of an idle wait: for the emulated duration `workgroups` workgroups
  * (RCCL keeps a few dozen resident) stream the payload through HBM — read and written back unchanged, twice for an all-reduce,
  * once for a reduce-scatter or an all-gather — so the backward beside it loses the CU slots and the memory bandwidth a real
- * collective takes.  0 = the idle wait (default). */
+ * collective takes.  A grouped call (an interval's three regions) is ONE such kernel: the call's whole duration, its footprint on
+ * the largest region — as RCCL runs a group.  0 = the idle wait (default). */
 int fmhip_comm_emulate_load(fmhip_comm_t c, int workgroups);
 /* ... and for the sharded update: pretend to be rank 0 of `ranks` (one real rank only): intervals are cut into `ranks` shares,
  * this rank updates and zeroes only the first, the reduce-scatter / all-gather delays are those of `ranks` GPUs (half an
